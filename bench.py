@@ -1,0 +1,275 @@
+#!/usr/bin/env python
+"""GET hot-path benchmark: claim-evidence pairs/s, forward + backward (+ gradient all-reduce + Adam),
+on synthetic Snopes-shaped batches (BASELINE.json configs[1]: B=32 claims x 30 evidences, L=30, R=100,
+D=H=300, 5 word heads / 2 evidence heads, window 3, gsl_rate 0.6, fp32).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = graph build from token ids + full model forward + cross-entropy + backward + one flat
+gradient all-reduce (N>1) + fused Adam, with the batch already resident in HBM.  Rank 0 prints ONE
+JSON line.  Weak scaling: every rank runs its own B=32 batch (claims are independent; the only
+exchange is the gradient all-reduce).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from get_amd.synth import SynthConfig, make_embeddings, make_raw_batch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, spec
+PEAK_HBM_GBPS = 8000.0           # HBM3E spec (6.3 TB/s achievable)
+
+
+def flops_per_pair(cfg: SynthConfig, nnz_per_graph: float) -> dict:
+    """Minimal-formulation FLOPs per claim-evidence pair (SURVEY.md 8(d) formulas as functions)."""
+    R, D, H, hw = cfg.len_right, cfg.emb_dim, cfg.hidden, cfg.word_heads
+
+    def cell(din, dout, agg):
+        return 2 * R * din * dout + 12 * R * dout * dout + agg * dout
+
+    agg = 2 * nnz_per_graph
+    att = 2 * H * H + 2 * R * H * H + 2 * R * H * hw + 2 * R * H * hw
+    fwd = cell(D, H, agg) + cell(H, 1, agg) + cell(H, H, agg) + att
+    return {"fwd": fwd, "fwd_bwd": 3 * fwd - 2 * R * D * H}
+
+
+def build_workload(batch=32, n_evd=30, seed=20240229, device="cuda:0", cfg: SynthConfig = None, lr=1e-4):
+    """Model (random init, reference init scheme), a seeded synthetic batch resident on `device`, and
+    the native-path kargs.  Also returns `oracle_slice(k)`: CPU-oracle logits of the first k claims."""
+    from get_amd import modules, ops
+    cfg = cfg or SynthConfig(batch=batch, n_evd=n_evd)
+    emb, art, clm = make_embeddings(cfg, seed)
+    torch.manual_seed(seed)
+    model = modules.Graph_basedSemantiStructure(cfg.model_params(emb, art, clm)).to(device)
+    raw = make_raw_batch(cfg, seed)
+    dev = torch.device(device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    claim_tokens, claim_len = t(raw["claim_tokens"]), t(raw["claim_len"])
+    evd_tokens, evd_len = t(raw["evd_tokens"]), t(raw["evd_len"])
+    counts = t(raw["evd_counts"])
+    b1 = int(raw["evd_counts"].sum())
+    n = cfg.fixed_num_evidences
+    # slot of every pair inside the (B, n, R) padded evidence tensor
+    offs = np.concatenate([[0], np.cumsum(raw["evd_counts"])])[:-1]
+    p2c = np.repeat(np.arange(cfg.batch), raw["evd_counts"])
+    slot = t((p2c * n + (np.arange(b1) - offs[p2c])).astype(np.int64))
+    labels = t(raw["labels"])
+
+    def make_inputs():
+        """The per-step device work that replaces the reference's host graph construction + H2D of
+        dense float64 adjacency: ids -> packed graphs (interactions.py:334-351)."""
+        qa, q_ids, q_n = ops.graph_build(claim_tokens, claim_len, cfg.window)
+        da, d_ids, d_n = ops.graph_build(evd_tokens, evd_len, cfg.window)
+        document = torch.zeros((cfg.batch * n, cfg.len_right), device=dev, dtype=torch.int32)
+        document.index_copy_(0, slot, d_ids)
+        kargs = {
+            "query_lens": q_n, "docs_lens": None, "doc_lens_indices": None,
+            "doc_content_without_padding_evidences": d_ids, "evd_cnt_each_query": counts,
+            "fixed_num_evidences": n, "query_adj": qa, "docs_adj": da,
+            "doc_sources": t_doc_sources, "query_sources": t_query_sources,
+        }
+        return q_ids, document.view(cfg.batch, n, cfg.len_right), kargs
+
+    t_doc_sources, t_query_sources = t(raw["doc_sources"]), t(raw["query_sources"])
+    query, document, kargs = make_inputs()
+    nnz = float(torch.count_nonzero(kargs["docs_adj"].to_dense()).item()) / max(b1, 1)
+
+    def oracle_slice(k: int):
+        from oracle import get_oracle as O
+        from oracle.assemble import assemble_inputs
+        sub_cfg = SynthConfig(**{**cfg.__dict__, "batch": k, "evd_counts": [int(c) for c in raw["evd_counts"][:k]]})
+        nb1 = int(raw["evd_counts"][:k].sum())
+        sub = dict(claim_tokens=raw["claim_tokens"][:k], claim_len=raw["claim_len"][:k],
+                   evd_tokens=raw["evd_tokens"][:nb1], evd_len=raw["evd_len"][:nb1],
+                   evd_counts=raw["evd_counts"][:k], doc_sources=raw["doc_sources"][:k],
+                   query_sources=raw["query_sources"][:k], labels=raw["labels"][:k])
+        inp = assemble_inputs(sub, sub_cfg, O.convert_text)
+        p = {kk: v.detach().cpu().clone() for kk, v in model.state_dict().items()}
+        T = torch.from_numpy
+        phi, ww, ew = O.model_forward(p, sub_cfg.__dict__, T(inp["query"]), T(inp["document"]), T(inp["query_adj"]),
+                                      T(inp["doc_ids"]), T(inp["doc_adj"]), T(inp["query_lens"]), inp["evd_counts"],
+                                      T(inp["doc_sources"]), T(inp["query_sources"]))
+        return dict(phi=phi.detach(), word_w=ww.detach(), inp=inp, params=p, cfg=sub_cfg)
+
+    return dict(cfg=cfg, model=model, raw=raw, query=query, document=document, kargs=kargs, labels=labels, b1=b1,
+                make_inputs=make_inputs, oracle_slice=oracle_slice, nnz_per_graph=nnz)
+
+
+def cpu_baseline(wl, budget_s=15.0, claims=2):
+    """The CPU oracle (a port of the reference's PyTorch path) timed on this host's cores on a bounded
+    sample: forward + backward of the first `claims` claims of the same batch, repeated for ~budget_s."""
+    from oracle import get_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    s = wl["oracle_slice"](claims)
+    inp, cfg = s["inp"], s["cfg"]
+    T = torch.from_numpy
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and k != "embedding.weight") for k, v in s["params"].items()}
+    pairs = int(inp["evd_counts"].sum())
+
+    def one():
+        for v in p.values():
+            v.grad = None
+        phi, _, _ = O.model_forward(p, cfg.__dict__, T(inp["query"]), T(inp["document"]), T(inp["query_adj"]),
+                                    T(inp["doc_ids"]), T(inp["doc_adj"]), T(inp["query_lens"]), inp["evd_counts"],
+                                    T(inp["doc_sources"]), T(inp["query_sources"]))
+        O.cross_entropy(phi, T(inp["labels"])).backward()
+
+    one()
+    t0 = time.time()
+    n = 0
+    while True:
+        one()
+        n += 1
+        if time.time() - t0 >= budget_s or n >= 50:
+            break
+    dt = time.time() - t0
+    return {"value": pairs * n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fwd+bwd (eval mode) on the first {claims} claims = {pairs} pairs of the same batch, "
+                      f"{n} repeats in {dt:.1f} s, torch CPU {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="claims per GPU")
+    ap.add_argument("--n-evd", type=int, default=30, help="evidences per claim (<=0: ragged U[1,30])")
+    ap.add_argument("--eval-mode", action="store_true", help="disable dropout (parity mode)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    device = f"cuda:{local_rank if world > 1 else 0}"
+
+    from get_amd import _lib
+    from get_amd.dist import FlatTrainer
+    _lib.load()
+
+    wl = build_workload(batch=args.batch, n_evd=args.n_evd, seed=20240229 + rank, device=device)
+    model, cfg = wl["model"], wl["cfg"]
+    if world > 1:      # identical replicas: broadcast rank 0's parameters
+        for p in model.parameters():
+            dist.broadcast(p.data, src=0)
+    trainer = FlatTrainer(model, lr=1e-4, weight_decay=1e-3)
+    model.train(not args.eval_mode)
+
+    def step():
+        trainer.zero_grad()
+        query, document, kargs = wl["make_inputs"]()
+        phi = model(query, document, **kargs)
+        loss = torch.nn.functional.cross_entropy(phi, wl["labels"])
+        loss.backward()
+        trainer.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_profile:
+        _lib.profile_enable(True)
+        _lib.profile_collect()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = None
+    if not args.no_profile:
+        prof = _lib.profile_collect()
+        _lib.profile_enable(False)
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    pairs = torch.tensor([wl["b1"]], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pairs, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    total_pairs = float(pairs.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        value = total_pairs * args.steps / dt
+        fl = flops_per_pair(cfg, wl["nnz_per_graph"])
+        out = {
+            "metric": "claim-evidence pairs/sec fwd+bwd (B=32, h=300)", "value": value, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: Snopes-shaped synthetic batch, "
+                                   f"B={cfg.batch} claims x {args.n_evd if args.n_evd > 0 else 'U[1,30]'} evidences per GPU "
+                                   f"(B1={wl['b1']} pairs), L_left={cfg.len_left}, L_right={cfg.len_right}, D=H={cfg.hidden}, "
+                                   f"{cfg.word_heads} word heads / {cfg.evd_heads} evidence heads, gnn_window={cfg.window}, "
+                                   f"gsl_rate={cfg.gsl_rate}",
+                       "step": "device graph build + forward + CE loss + backward + flat grad all-reduce + fused Adam",
+                       "mode": "eval (dropout off)" if args.eval_mode else "train (dropout on)",
+                       "parallelism": f"dp{world}", "pairs_per_gpu": wl["b1"], "loss": float(loss.item())},
+            "path_tflops": {"flops_per_pair_fwd_bwd": fl["fwd_bwd"],
+                            "achieved_tflops_per_gpu": fl["fwd_bwd"] * value / world / 1e12,
+                            "frac_of_f32_mfma_peak": fl["fwd_bwd"] * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS},
+        }
+        if prof is not None:
+            kernels = {}
+            for name, r in prof.items():
+                if r["launches"] == 0:
+                    continue
+                per_step = r["ms"] / args.steps
+                rate = r["work"] / (r["ms"] * 1e-3) if r["ms"] > 0 else 0.0
+                entry = {"ms_per_step": per_step, "launches_per_step": r["launches"] / args.steps,
+                         "avg_launch_ms": r["ms"] / r["launches"]}
+                if name.startswith("gemm"):
+                    entry.update(bound="mfma", achieved_tflops=rate / 1e12, frac=rate / 1e12 / PEAK_F32_MFMA_TFLOPS)
+                else:
+                    entry.update(bound="hbm", achieved_gbps=rate / 1e9, frac=rate / 1e9 / PEAK_HBM_GBPS)
+                kernels[name] = entry
+            dom = max((k for k in kernels if k.startswith("gemm")), key=lambda k: kernels[k]["ms_per_step"])
+            d = kernels[dom]
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["achieved_tflops"],
+                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": d["frac"], "traffic": None,
+                               "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_per_step"],
+                               "alg_flops_per_launch": prof[dom]["work"] / prof[dom]["launches"]}
+            out["kernels"] = kernels
+        if world == 1 and not args.no_cpu_baseline:
+            model.train(False)
+            with torch.no_grad():
+                q, d_, k_ = wl["make_inputs"]()
+                phi_gpu = model(q, d_, **k_)[:4].cpu()
+            par = wl["oracle_slice"](4)
+            out["parity"] = {"max_abs_logit_diff_vs_cpu_oracle_first_4_claims": float((phi_gpu - par["phi"]).abs().max())}
+            out["cpu_baseline"] = cpu_baseline(wl, budget_s=args.cpu_budget)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

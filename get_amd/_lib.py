@@ -1,0 +1,112 @@
+"""ctypes binding of libget_hip.so (the C-ABI declared in include/get_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is
+raised.  The product never routes through the oracle or a torch re-implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libget_hip.so")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_L = ctypes.c_int64
+
+# name -> argtypes (mirrors include/get_hip.h; tests/test_abi.py checks the two agree)
+SIGNATURES = {
+    "gh_graph_build": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
+    "gh_adj_pack_f64": [_P, _I, _I, _P, _P, _P],
+    "gh_adj_pack_f32": [_P, _I, _I, _P, _P, _P],
+    "gh_spmm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gh_transpose": [_P, _P, _I, _I, _P],
+    "gh_ggnn_cell_fwd": [_P] * 6 + [_I] * 4 + [_P] * 10 + [_P] * 7 + [_P],
+    "gh_ggnn_cell_bwd": [_P] * 6 + [_I] * 4 + [_P] * 7 + [_P] * 7 + [_P] * 5 + [_P] * 11 + [_P],
+    "gh_scorer_gsl": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "gh_gsl_topk": [_P, _I, _I, _I, _P, _P],
+    "gh_adj_unpack": [_P, _P, _P, _P, _I, _I, _P, _P],
+    "gh_concat_att_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gh_concat_att_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gh_linear_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "gh_linear_bwd": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "gh_seg_offsets": [_P, _I, _P, _P, _I, _P],
+    "gh_seg_broadcast": [_P, _P, _P, _I, _I, _P],
+    "gh_seg_sum": [_P, _P, _P, _I, _I, _P],
+    "gh_seg_pad": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "gh_seg_unpad": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "gh_masked_mean_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "gh_masked_mean_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "gh_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
+    "gh_profile_enable": [_I],
+    "gh_profile_collect": [_P, _I],
+}
+
+PROFILE_ROWS = ["gemm_128x304", "gemm_128x304_tn", "gemm_32x320", "gemm_32x320_tn", "spmm", "scorer_gsl",
+                "graph_build", "att_softmax_fwd", "att_softmax_bwd", "att_dpre", "gate_bwd_pre", "colsum", "adam"]
+
+
+def profile_enable(on: bool):
+    call("gh_profile_enable", 1 if on else 0)
+
+
+def profile_collect() -> dict:
+    """{kernel: {"ms": total, "work": total algorithmic flops|bytes, "launches": n}} since the last collect."""
+    buf = (ctypes.c_double * (len(PROFILE_ROWS) * 3))()
+    call("gh_profile_collect", ctypes.cast(buf, ctypes.c_void_p), len(PROFILE_ROWS))
+    return {name: {"ms": buf[3 * i], "work": buf[3 * i + 1], "launches": int(buf[3 * i + 2])}
+            for i, name in enumerate(PROFILE_ROWS)}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"get_amd: HIP library not found at {LIB_PATH}. Build it with "
+            "`python -c \"import __graft_entry__ as g; g.build()\"` or `make -C get_amd/csrc`. "
+            "There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.gh_abi_version.restype = _I
+    lib.gh_last_error.restype = ctypes.c_char_p
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.argtypes = args
+        fn.restype = _I
+    if lib.gh_abi_version() != 1:
+        raise RuntimeError(f"get_amd: ABI version mismatch ({lib.gh_abi_version()} != 1)")
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "get_amd: non-contiguous tensor handed to the C-ABI"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"get_amd: {name} failed (rc={rc}): {lib.gh_last_error().decode(errors='replace')}")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("get_amd: tensors must live on a ROCm device (cuda:N); there is no CPU path")

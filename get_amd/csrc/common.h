@@ -1,0 +1,60 @@
+// Shared host-side helpers of libget_hip.so (error reporting, internal launch prototypes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace gh {
+
+void set_error(const char* fmt, ...);
+
+#define GH_CHECK_HIP(expr)                                                                  \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      gh::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));   \
+      return 1;                                                                             \
+    }                                                                                       \
+  } while (0)
+
+#define GH_REQUIRE(cond, ...)                     \
+  do {                                            \
+    if (!(cond)) {                                \
+      gh::set_error(__VA_ARGS__);                 \
+      return 2;                                   \
+    }                                             \
+  } while (0)
+
+#define GH_LAUNCH_CHECK() GH_CHECK_HIP(hipGetLastError())
+
+inline int words_for(int r) { return (r + 63) / 64; }
+
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's live roofline numbers).
+// Tags index the rows gh_profile_collect() returns; `work` is the launch's algorithmic flops (GEMMs)
+// or algorithmic HBM bytes (streaming kernels).
+enum ProfTag : int {
+  PROF_GEMM_BIG = 0, PROF_GEMM_BIG_TN, PROF_GEMM_SMALL, PROF_GEMM_SMALL_TN,
+  PROF_SPMM, PROF_SCORER_GSL, PROF_GRAPH_BUILD, PROF_ATT_SOFTMAX_FWD, PROF_ATT_SOFTMAX_BWD, PROF_ATT_DPRE,
+  PROF_GATE_BWD_PRE, PROF_COLSUM, PROF_ADAM, PROF_NTAGS
+};
+bool prof_enabled();
+void prof_begin(hipStream_t s);
+void prof_end(int tag, double work, hipStream_t s);
+
+// internal launchers implemented in graph_ops.hip / misc_ops.hip, used by the fused entry points
+int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const float* x,
+                float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s);
+int launch_gate_bwd_pre(const float* g, const float* z, const float* hh, const float* xp, float* dhp, float* dzp,
+                        float* dxp, size_t count, hipStream_t s);
+int launch_colsum3(const float* a, const float* b, const float* c, float* oa, float* ob, float* oc, int m, int h,
+                   hipStream_t s);
+int launch_colsum(const float* a, float* oa, int m, int h, hipStream_t s);
+int launch_att_softmax_fwd(const float* e, const float* mask, const float* right, int b, int l, int dr, int heads,
+                           float* weights, float* attended, hipStream_t s);
+int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w, int b,
+                           int l, int dr, int heads, float* de, float* dright, hipStream_t s);
+int launch_att_dpre(const float* de, const float* w2, const float* t, int b, int l, int ha, int heads, float* dpre,
+                    float* du, hipStream_t s);
+
+}  // namespace gh

@@ -1,0 +1,306 @@
+// Fused entry points built on the grouped MFMA GEMM: GGNN cell fwd/bwd, concat attention fwd/bwd,
+// plain linear fwd/bwd.  See include/get_hip.h for the contract of each.
+#include "../../include/get_hip.h"
+#include "common.h"
+#include "gemm.hip.h"
+
+namespace gh {
+
+template <int WM, int WN, int NI>
+static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
+  const int n_outer = tn ? L.ksplit : L.m_tiles;
+  const int n_inner = tn ? L.m_tiles * L.nprob : L.nprob;
+  const int grid = 8 * ((n_outer + 7) / 8) * n_inner;
+  if (grid <= 0) return hipSuccess;
+  double flops = 0.0;
+  if (prof_enabled()) {
+    for (int i = 0; i < L.nprob; ++i)
+      for (int j = 0; j < L.p[i].nseg; ++j) flops += 2.0 * L.p[i].M * L.p[i].N * (double)L.p[i].seg[j].K;
+    prof_begin(s);
+  }
+  if (tn) hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, true>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
+  else hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, false>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
+  prof_end((WM == 4 ? PROF_GEMM_BIG : PROF_GEMM_SMALL) + (tn ? 1 : 0), flops, s);
+  return hipGetLastError();
+}
+
+// Collects problems that share their row space, splits wide outputs into column blocks the tile
+// can hold, and launches them GH_MAX_PROBLEMS at a time.
+struct Batch {
+  Launch L;
+  bool tn, big;
+  hipStream_t s;
+  int bm, bn;
+  hipError_t err = hipSuccess;
+  int k_total = 0;
+
+  Batch(bool tn_, int rows_hint, hipStream_t s_) : tn(tn_), s(s_) {
+    big = tn_ || rows_hint >= 512;
+    bm = big ? 128 : 32;
+    bn = big ? GH_BN_BIG : GH_BN_SMALL;
+    reset();
+  }
+  void reset() { L.nprob = 0; L.m_tiles = 0; L.ksplit = 1; L.kchunk = 0; k_total = 0; }
+
+  void add(const Problem& p) {
+    if (p.epi == EPI_ATT && p.N > bn) { err = hipErrorInvalidValue; return; }
+    for (int n0 = 0; n0 < p.N; n0 += bn) {
+      Problem q = p;
+      q.N = (p.N - n0 < bn) ? p.N - n0 : bn;
+      for (int i = 0; i < q.nseg; ++i) {
+        q.seg[i].B += n0;
+        q.seg[i].vecB = vec_ok(q.seg[i].B, q.seg[i].ldb, q.N);
+      }
+      q.C += n0;
+      if (q.bias) q.bias += n0;
+      if (q.out1) q.out1 += n0;
+      if (q.in0) q.in0 += n0;
+      if (q.in1) q.in1 += n0;
+      if (L.nprob == GH_MAX_PROBLEMS) flush();
+      L.p[L.nprob++] = q;
+      const int mt = (q.M + bm - 1) / bm;
+      if (mt > L.m_tiles) L.m_tiles = mt;
+      if (q.seg[0].K > k_total) k_total = q.seg[0].K;
+    }
+  }
+
+  void flush() {
+    if (L.nprob == 0 || err != hipSuccess) { reset(); return; }
+    if (tn) {
+      const int n_inner = L.m_tiles * L.nprob;
+      int ks = (768 + n_inner - 1) / n_inner;
+      const int ks_max = (k_total / 512 > 1) ? k_total / 512 : 1;
+      if (ks > ks_max) ks = ks_max;
+      if (ks < 1) ks = 1;
+      int chunk = (k_total + ks - 1) / ks;
+      chunk = ((chunk + 15) / 16) * 16;
+      L.kchunk = chunk;
+      L.ksplit = (k_total + chunk - 1) / chunk;
+    }
+    hipError_t e = big ? launch_cfg<4, 1, 19>(L, tn, s) : launch_cfg<1, 4, 5>(L, tn, s);
+    if (e != hipSuccess) err = e;
+    reset();
+  }
+};
+
+static Problem gemm_problem(int M, int N, int epi, float* C, int ldc, const float* A, int lda, const float* B, int ldb,
+                            int K, const int32_t* gatherA = nullptr) {
+  Problem p = make_problem(M, N, epi, C, ldc);
+  p.seg[0] = make_seg(A, lda, B, ldb, K, N, gatherA, nullptr);
+  return p;
+}
+static void add_seg(Problem& p, const float* A, int lda, const float* B, int ldb, int K) {
+  p.seg[p.nseg++] = make_seg(A, lda, B, ldb, K, p.N);
+}
+static Problem tn_problem(int I, int J, float* C, int ldc, const float* A, int lda, const float* B, int ldb, int K,
+                          const int32_t* gatherB = nullptr) {
+  Problem p = make_problem(I, J, EPI_ATOMIC, C, ldc);
+  p.seg[0] = make_seg_tn(A, lda, I, B, ldb, J, K, nullptr, gatherB);
+  return p;
+}
+
+}  // namespace gh
+
+using namespace gh;
+
+extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                                const float* x, const int32_t* ids, int n, int r, int din, int h,
+                                const float* wt_p, const float* wt_z0, const float* wt_z1, const float* wt_r0,
+                                const float* wt_r1, const float* wt_h0, const float* wt_h1,
+                                const float* b_z, const float* b_r, const float* b_h,
+                                float* xp, float* a, float* z, float* rr, float* rx, float* hh, float* out,
+                                gh_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int M = n * r;
+  GH_REQUIRE(n > 0 && r > 0 && din > 0 && h > 0, "ggnn_cell_fwd: bad sizes n=%d r=%d din=%d h=%d", n, r, din, h);
+  {  // xp = x Wp^T   (wrapper.py:191), embedding rows gathered in the A loader when ids != NULL
+    Batch b(false, M, s);
+    b.add(gemm_problem(M, h, EPI_STORE, xp, h, x, din, wt_p, h, din, ids));
+    b.flush();
+    GH_CHECK_HIP(b.err);
+  }
+  if (int e = launch_spmm(bits, dinv, vals, keep, xp, a, n, r, h, 0, 0, s)) return e;   // a = A_hat xp (:192)
+  {  // z, r gates (:194-200): [a | xp] . [W?0 | W?1]^T as two K segments
+    Batch b(false, M, s);
+    Problem pz = gemm_problem(M, h, EPI_SIGMOID_Z, z, h, a, h, wt_z0, h, h);
+    add_seg(pz, xp, h, wt_z1, h, h);
+    pz.bias = b_z;
+    Problem pr = gemm_problem(M, h, EPI_SIGMOID_R, rr, h, a, h, wt_r0, h, h);
+    add_seg(pr, xp, h, wt_r1, h, h);
+    pr.bias = b_r; pr.out1 = rx; pr.in0 = xp;
+    b.add(pz); b.add(pr);
+    b.flush();
+    GH_CHECK_HIP(b.err);
+  }
+  {  // h gate and the convex update (:202-206)
+    Batch b(false, M, s);
+    Problem ph = gemm_problem(M, h, EPI_TANH_H, hh, h, a, h, wt_h0, h, h);
+    add_seg(ph, rx, h, wt_h1, h, h);
+    ph.bias = b_h; ph.out1 = out; ph.in0 = z; ph.in1 = xp;
+    b.add(ph);
+    b.flush();
+    GH_CHECK_HIP(b.err);
+  }
+  return 0;
+}
+
+extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                                const float* x, const int32_t* ids, int n, int r, int din, int h,
+                                const float* w_p, const float* w_z0, const float* w_z1, const float* w_r0,
+                                const float* w_r1, const float* w_h0, const float* w_h1,
+                                const float* xp, const float* a, const float* z, const float* rr, const float* rx,
+                                const float* hh, const float* g,
+                                float* dhp, float* dzp, float* drp, float* dxp, float* da,
+                                float* dx, float* dw_p, float* dw_z0, float* dw_z1, float* dw_r0, float* dw_r1,
+                                float* dw_h0, float* dw_h1, float* db_z, float* db_r, float* db_h,
+                                gh_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int M = n * r;
+  GH_REQUIRE(n > 0 && r > 0 && din > 0 && h > 0, "ggnn_cell_bwd: bad sizes");
+  // out = h z + xp (1-z):  dhp = g z (1-h^2), dzp = g (h-xp) z (1-z), dxp = g (1-z)
+  if (int e = launch_gate_bwd_pre(g, z, hh, xp, dhp, dzp, dxp, (size_t)M * h, s)) return e;
+  {  // hp = a Wh0^T + (r xp) Wh1^T:  da = dhp Wh0 ; d(r xp) = dhp Wh1 -> drp, dxp += .
+    Batch b(false, M, s);
+    Problem p0 = gemm_problem(M, h, EPI_STORE, da, h, dhp, h, w_h0, h, h);
+    Problem p1 = gemm_problem(M, h, EPI_BWD_DRX, drp, h, dhp, h, w_h1, h, h);
+    p1.out1 = dxp; p1.in0 = xp; p1.in1 = rr;
+    b.add(p0); b.add(p1);
+    b.flush();
+    GH_CHECK_HIP(b.err);
+  }
+  {  // da += dzp Wz0 + drp Wr0 ; dxp += dzp Wz1 + drp Wr1
+    Batch b(false, M, s);
+    Problem p0 = gemm_problem(M, h, EPI_STORE, da, h, dzp, h, w_z0, h, h);
+    add_seg(p0, drp, h, w_r0, h, h);
+    p0.accumulate = 1;
+    Problem p1 = gemm_problem(M, h, EPI_STORE, dxp, h, dzp, h, w_z1, h, h);
+    add_seg(p1, drp, h, w_r1, h, h);
+    p1.accumulate = 1;
+    b.add(p0); b.add(p1);
+    b.flush();
+    GH_CHECK_HIP(b.err);
+  }
+  if (int e = launch_spmm(bits, dinv, vals, keep, da, dxp, n, r, h, 1, 1, s)) return e;   // dxp += A_hat^T da
+  if (dx) {  // dx = dxp Wp
+    Batch b(false, M, s);
+    b.add(gemm_problem(M, din, EPI_STORE, dx, din, dxp, h, w_p, din, h));
+    b.flush();
+    GH_CHECK_HIP(b.err);
+  }
+  {  // weight gradients: G^T X over the m = n*r rows, split-K with fp32 atomics
+    Batch b(true, M, s);
+    b.add(tn_problem(h, h, dw_z0, h, dzp, h, a, h, M));
+    b.add(tn_problem(h, h, dw_z1, h, dzp, h, xp, h, M));
+    b.add(tn_problem(h, h, dw_r0, h, drp, h, a, h, M));
+    b.add(tn_problem(h, h, dw_r1, h, drp, h, xp, h, M));
+    b.add(tn_problem(h, h, dw_h0, h, dhp, h, a, h, M));
+    b.add(tn_problem(h, h, dw_h1, h, dhp, h, rx, h, M));
+    b.add(tn_problem(h, din, dw_p, din, dxp, h, x, din, M, ids));
+    b.flush();
+    GH_CHECK_HIP(b.err);
+  }
+  return launch_colsum3(dzp, drp, dhp, db_z, db_r, db_h, M, h, s);
+}
+
+extern "C" int gh_concat_att_fwd(const float* left, const float* right, const float* mask, int b, int l, int xl,
+                                 int dr, int ha, int heads, const float* w1t, const float* w2,
+                                 float* u, float* t, float* e, float* weights, float* attended,
+                                 gh_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GH_REQUIRE(heads >= 1 && heads <= 8, "concat_att: heads=%d not in [1,8]", heads);
+  GH_REQUIRE(b > 0 && l > 0 && dr > 0 && ha > 0, "concat_att_fwd: bad sizes");
+  const int M = b * l;
+  GH_REQUIRE(ha <= ((M >= 512) ? GH_BN_BIG : GH_BN_SMALL), "concat_att_fwd: attention hidden %d exceeds one column block", ha);
+  if (left && xl > 0) {  // u = W1[:, :xl] . left -- once per pair, not per token (two_branches_attention.py:137-140)
+    Batch bt(false, b, s);
+    bt.add(gemm_problem(b, ha, EPI_STORE, u, ha, left, xl, w1t, ha, xl));
+    bt.flush();
+    GH_CHECK_HIP(bt.err);
+  } else {
+    GH_CHECK_HIP(hipMemsetAsync(u, 0, sizeof(float) * (size_t)b * ha, s));
+    xl = 0;
+  }
+  {  // t = tanh(W1[:, xl:] . right_t + u) ; e = W2 t  (:140-141)
+    Batch bt(false, M, s);
+    Problem p = gemm_problem(M, ha, EPI_ATT, t, ha, right, dr, w1t + (size_t)xl * ha, ha, dr);
+    p.u = u; p.ldu = ha; p.R = l; p.w2 = w2; p.heads = heads; p.e = e;
+    bt.add(p);
+    bt.flush();
+    GH_CHECK_HIP(bt.err);
+  }
+  return launch_att_softmax_fwd(e, mask, right, b, l, dr, heads, weights, attended, s);   // (:142-147)
+}
+
+extern "C" int gh_concat_att_bwd(const float* left, const float* right, int b, int l, int xl, int dr, int ha,
+                                 int heads, const float* w1, const float* w2, const float* t, const float* weights,
+                                 const float* g_att, const float* g_w, float* de, float* dpre, float* du,
+                                 float* dleft, float* dright, float* dw1, float* dw2, gh_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GH_REQUIRE(heads >= 1 && heads <= 8, "concat_att: heads=%d not in [1,8]", heads);
+  const int M = b * l;
+  if (!left) xl = 0;
+  const int ldw = xl + dr;
+  if (int e = launch_att_softmax_bwd(right, weights, g_att, g_w, b, l, dr, heads, de, dright, s)) return e;
+  if (int e = launch_att_dpre(de, w2, t, b, l, ha, heads, dpre, du, s)) return e;
+  {  // dright += dpre W1[:, xl:]
+    Batch bt(false, M, s);
+    Problem p = gemm_problem(M, dr, EPI_STORE, dright, dr, dpre, ha, w1 + xl, ldw, ha);
+    p.accumulate = 1;
+    bt.add(p);
+    bt.flush();
+    GH_CHECK_HIP(bt.err);
+  }
+  if (xl > 0 && dleft) {  // dleft = du W1[:, :xl]
+    Batch bt(false, b, s);
+    bt.add(gemm_problem(b, xl, EPI_STORE, dleft, xl, du, ha, w1, ldw, ha));
+    bt.flush();
+    GH_CHECK_HIP(bt.err);
+  }
+  {
+    Batch bt(true, M, s);
+    bt.add(tn_problem(ha, dr, dw1 + xl, ldw, dpre, ha, right, dr, M));
+    bt.add(tn_problem(heads, ha, dw2, ha, de, heads, t, ha, M));
+    bt.flush();
+    GH_CHECK_HIP(bt.err);
+  }
+  if (xl > 0) {
+    Batch bt(true, b, s);
+    bt.add(tn_problem(ha, xl, dw1, ldw, du, ha, left, xl, b));
+    bt.flush();
+    GH_CHECK_HIP(bt.err);
+  }
+  return 0;
+}
+
+extern "C" int gh_linear_fwd(const float* x, const float* wt, const float* bias, float* y, int m, int k, int n,
+                             gh_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GH_REQUIRE(m > 0 && k > 0 && n > 0, "linear_fwd: bad sizes");
+  Batch b(false, m, s);
+  Problem p = gemm_problem(m, n, EPI_STORE, y, n, x, k, wt, n, k);
+  p.bias = bias;
+  b.add(p);
+  b.flush();
+  GH_CHECK_HIP(b.err);
+  return 0;
+}
+
+extern "C" int gh_linear_bwd(const float* x, const float* w, const float* g, int m, int k, int n, float* dx,
+                             float* dw, float* db, gh_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GH_REQUIRE(m > 0 && k > 0 && n > 0, "linear_bwd: bad sizes");
+  if (dx) {
+    Batch b(false, m, s);
+    b.add(gemm_problem(m, k, EPI_STORE, dx, k, g, n, w, k, n));
+    b.flush();
+    GH_CHECK_HIP(b.err);
+  }
+  if (dw) {
+    Batch b(true, m, s);
+    b.add(tn_problem(n, k, dw, k, g, n, x, k, m));
+    b.flush();
+    GH_CHECK_HIP(b.err);
+  }
+  if (db) return launch_colsum(g, db, m, n, s);
+  return 0;
+}

@@ -1,0 +1,379 @@
+// Graph-side kernels: word-graph build, adjacency packing, bitmask aggregation (spmm),
+// fused word-scorer + GSL top-k.  All HBM-bound integer/bit work plus one streaming FMA pass;
+// no MFMA here by design.
+#include "../../include/get_hip.h"
+#include "common.h"
+
+namespace gh {
+
+constexpr int MAX_R = 256;          // padded graph size supported by the one-workgroup-per-graph kernels
+constexpr int MAX_W = MAX_R / 64;
+
+// ------------------------------------------------------------------------------------------------
+// a1  graph build (interactions.py:334-351).  One workgroup per text.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+graph_build_kernel(const int32_t* __restrict__ tokens, const int32_t* __restrict__ lengths, int R, int window,
+                   int32_t* __restrict__ node_ids, int32_t* __restrict__ n_nodes, uint64_t* __restrict__ bits,
+                   float* __restrict__ dinv) {
+  __shared__ int tok[MAX_R];
+  __shared__ int first[MAX_R];       // position of the first occurrence of tok[i]
+  __shared__ int node_of[MAX_R];     // node index of position i
+  __shared__ unsigned long long rows[MAX_R * MAX_W];
+  __shared__ int total;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int W = (R + 63) / 64;
+  int len = lengths[g];
+  len = len < 0 ? 0 : (len > R ? R : len);
+  for (int i = tid; i < R; i += blockDim.x) tok[i] = (i < len) ? tokens[(size_t)g * R + i] : 0;
+  for (int i = tid; i < R * W; i += blockDim.x) rows[i] = 0ull;
+  __syncthreads();
+  // first occurrence (words_list.sort(key=raw_text.index), :335-336)
+  for (int i = tid; i < len; i += blockDim.x) {
+    int f = i;
+    const int t = tok[i];
+    for (int j = 0; j < i; ++j)
+      if (tok[j] == t) { f = j; break; }
+    first[i] = f;
+  }
+  __syncthreads();
+  // node index = number of first-occurrence positions before first[i]
+  for (int i = tid; i < len; i += blockDim.x) {
+    const int f = first[i];
+    int c = 0;
+    for (int j = 0; j < f; ++j) c += (first[j] == j);
+    node_of[i] = c;
+  }
+  if (tid == 0) {
+    int c = 0;
+    for (int j = 0; j < len; ++j) c += (first[j] == j);
+    total = c;
+  }
+  __syncthreads();
+  // node list, zero padded (:349)
+  for (int i = tid; i < R; i += blockDim.x) node_ids[(size_t)g * R + i] = 0;
+  __syncthreads();
+  for (int i = tid; i < len; i += blockDim.x)
+    if (first[i] == i) node_ids[(size_t)g * R + node_of[i]] = tok[i];
+  // window links over POSITIONS, accumulated on nodes (:342-344)
+  for (int i = tid; i < len; i += blockDim.x) {
+    const int ni = node_of[i];
+    const int lo = max(i - window + 1, 0), hi = min(i + window, len);
+    for (int j = lo; j < hi; ++j) {
+      const int nj = node_of[j];
+      atomicOr(&rows[ni * W + (nj >> 6)], 1ull << (nj & 63));
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < R; i += blockDim.x) {
+    int deg = 0;
+    for (int w = 0; w < W; ++w) {
+      const unsigned long long m = rows[i * W + w];
+      bits[((size_t)g * R + i) * W + w] = m;
+      deg += __popcll(m);
+    }
+    // D^-1/2 with zero-degree rows -> 0 (interactions.py:14-16)
+    dinv[(size_t)g * R + i] = deg > 0 ? (float)(1.0 / sqrt((double)deg)) : 0.f;
+  }
+  if (tid == 0) n_nodes[g] = total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense (N,R,R) adjacency -> packed bits + fp32 values.  One wave per row, ballot builds the word.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+adj_pack_kernel(const T* __restrict__ adj, int R, uint64_t* __restrict__ bits, float* __restrict__ vals) {
+  const int g = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int W = (R + 63) / 64;
+  for (int i = wave; i < R; i += 4) {
+    const size_t rb = ((size_t)g * R + i) * R;
+    for (int w = 0; w < W; ++w) {
+      const int j = w * 64 + lane;
+      float v = 0.f;
+      if (j < R) {
+        v = (float)adj[rb + j];
+        vals[rb + j] = v;
+      }
+      const unsigned long long m = __ballot(v != 0.f);
+      if (lane == 0) bits[((size_t)g * R + i) * W + w] = m;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+adj_unpack_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
+                  const uint64_t* __restrict__ keep, int R, float* __restrict__ adj) {
+  const int g = blockIdx.x;
+  const int W = (R + 63) / 64;
+  for (int it = threadIdx.x; it < R * R; it += blockDim.x) {
+    const int i = it / R, j = it % R;
+    bool on = (bits[((size_t)g * R + i) * W + (j >> 6)] >> (j & 63)) & 1ull;
+    if (on && keep) {
+      const bool ki = (keep[(size_t)g * W + (i >> 6)] >> (i & 63)) & 1ull;
+      const bool kj = (keep[(size_t)g * W + (j >> 6)] >> (j & 63)) & 1ull;
+      on = ki || kj;
+    }
+    float v = 0.f;
+    if (on) v = vals ? vals[((size_t)g * R + i) * R + j] : dinv[(size_t)g * R + i] * dinv[(size_t)g * R + j];
+    adj[((size_t)g * R + i) * R + j] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// aggregation  y[g][i][:] (+)= sum_{j in N(i)} w_ij x[g][j][:]       (wrapper.py:192)
+// grid (graph, column slab).  The slab of x is staged in LDS once (coalesced 16 B/lane reads of the
+// feature rows), the refined neighbour bit-rows and dinv sit beside it, and every output float4
+// walks its row's set bits with ctz -- each feature row leaves HBM exactly once per slab.
+// ------------------------------------------------------------------------------------------------
+template <int V>   // V = 4: float4 columns, V = 1: scalar columns
+__global__ void __launch_bounds__(256)
+spmm_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
+            const uint64_t* __restrict__ keep, const float* __restrict__ x, float* __restrict__ y, int R, int H,
+            int slab, int transpose, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  const int W = (R + 63) / 64;
+  float* xs = reinterpret_cast<float*>(dsm);                                  // [R][slab*V]
+  const size_t xs_floats = (((size_t)R * slab * V) + 3) & ~(size_t)3;           // keep rb 16 B aligned
+  unsigned long long* rb = reinterpret_cast<unsigned long long*>(xs + xs_floats);              // [R][W]
+  float* dv = reinterpret_cast<float*>(rb + (size_t)R * W);                    // [R]
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int c0 = blockIdx.y * slab;                 // first column (in units of V floats)
+  const int HV = H / V;
+  const int ncol = min(slab, HV - c0);
+  const float* xg = x + (size_t)g * R * H;
+  for (int it = tid; it < R * ncol; it += 256) {
+    const int i = it / ncol, c = it % ncol;
+    if (V == 4) reinterpret_cast<float4*>(xs)[i * slab + c] = reinterpret_cast<const float4*>(xg + (size_t)i * H)[c0 + c];
+    else xs[i * slab + c] = xg[(size_t)i * H + c0 + c];
+  }
+  for (int it = tid; it < R * W; it += 256) {
+    const int i = it / W, w = it % W;
+    unsigned long long m = bits[((size_t)g * R + i) * W + w];
+    if (keep) {
+      const bool ki = (keep[(size_t)g * W + (i >> 6)] >> (i & 63)) & 1ull;
+      if (!ki) m &= keep[(size_t)g * W + w];          // edge survives iff keep(i) || keep(j)
+    }
+    rb[it] = m;
+  }
+  if (!vals)
+    for (int i = tid; i < R; i += 256) dv[i] = dinv[(size_t)g * R + i];
+  __syncthreads();
+  const float* vg = vals ? vals + (size_t)g * R * R : nullptr;
+  float* yg = y + (size_t)g * R * H;
+  for (int it = tid; it < R * ncol; it += 256) {
+    const int i = it / ncol, c = it % ncol;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float di = vals ? 0.f : dv[i];
+    for (int w = 0; w < W; ++w) {
+      unsigned long long m = rb[i * W + w];
+      while (m) {
+        const int j = (w << 6) + __builtin_ctzll(m);
+        m &= m - 1;
+        const float wt = vg ? (transpose ? vg[(size_t)j * R + i] : vg[(size_t)i * R + j]) : di * dv[j];
+        if (V == 4) {
+          const float4 xv = reinterpret_cast<const float4*>(xs)[j * slab + c];
+          acc.x += wt * xv.x; acc.y += wt * xv.y; acc.z += wt * xv.z; acc.w += wt * xv.w;
+        } else {
+          acc.x += wt * xs[j * slab + c];
+        }
+      }
+    }
+    if (V == 4) {
+      float4* o = reinterpret_cast<float4*>(yg + (size_t)i * H) + c0 + c;
+      if (accumulate) { const float4 p = *o; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+      *o = acc;
+    } else {
+      float* o = yg + (size_t)i * H + c0 + c;
+      *o = accumulate ? *o + acc.x : acc.x;
+    }
+  }
+}
+
+int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const float* x,
+                float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s) {
+  GH_REQUIRE(r <= MAX_R, "spmm: padded graph size %d > %d", r, MAX_R);
+  GH_REQUIRE(vals || dinv, "spmm: need dinv or vals");
+  const int W = words_for(r);
+  const bool v4 = (h % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  const int V = v4 ? 4 : 1;
+  const int hv = h / V;
+  // slab: <= 32 float4 (or 128 scalars) per row, as even as possible
+  const int slab_max = v4 ? 32 : 128;
+  const int nslab = (hv + slab_max - 1) / slab_max;
+  const int slab = (hv + nslab - 1) / nslab;
+  const size_t lds = ((((size_t)r * slab * V) + 3) & ~(size_t)3) * 4 + (size_t)r * W * 8 + (size_t)r * 4;
+  dim3 grid(n, nslab);
+  // algorithmic bytes: x in + y out (+ y in when accumulating) + bit rows + dinv (or the touched dense values)
+  const double alg_bytes = (double)n * ((2.0 + (accumulate ? 1.0 : 0.0)) * r * h * 4.0 + (double)r * W * 8.0 +
+                                        (vals ? (double)r * r * 4.0 : (double)r * 4.0));
+  prof_begin(s);
+  if (v4) {
+    static bool attr4 = false;
+    if (!attr4) { hipFuncSetAttribute((const void*)spmm_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr4 = true; }
+    hipLaunchKernelGGL(spmm_kernel<4>, grid, dim3(256), lds, s, bits, dinv, vals, keep, x, y, r, h, slab, transpose, accumulate);
+  } else {
+    static bool attr1 = false;
+    if (!attr1) { hipFuncSetAttribute((const void*)spmm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+    hipLaunchKernelGGL(spmm_kernel<1>, grid, dim3(256), lds, s, bits, dinv, vals, keep, x, y, r, h, slab, transpose, accumulate);
+  }
+  prof_end(PROF_SPMM, alg_bytes, s);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-k keep set from R scores held in LDS: rank by counting, ballot packs the 64-node words.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void topk_keep(const float* ss, int R, int k, uint64_t* keep_out, int tid) {
+  // one thread per node (R <= 256 = blockDim); wave w produces word w
+  bool kept = false;
+  if (tid < R) {
+    const float si = ss[tid];
+    int rank = 0;
+    for (int j = 0; j < R; ++j) {
+      const float sj = ss[j];
+      rank += (sj > si) || (sj == si && j < tid);
+    }
+    kept = rank < k;
+  }
+  const unsigned long long m = __ballot(kept);
+  const int W = (R + 63) / 64;
+  if ((tid & 63) == 0 && (tid >> 6) < W) keep_out[tid >> 6] = m;
+}
+
+// word scorer (GGNN 300->1, wrapper.py:167) + GSL top-k (:216-219), one workgroup per graph
+__global__ void __launch_bounds__(256)
+scorer_gsl_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
+                  const float* __restrict__ feat, const float* __restrict__ w_p, const float* __restrict__ gate,
+                  int R, int H, int k, float* __restrict__ score, uint64_t* __restrict__ keep) {
+  __shared__ float xs[MAX_R];
+  __shared__ float ss[MAX_R];
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int W = (R + 63) / 64;
+  const float* fg = feat + (size_t)g * R * H;
+  // x_j = feat_j . w_p   (proj, no bias)
+  const bool v4 = (H % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat) & 15) == 0) && ((reinterpret_cast<uintptr_t>(w_p) & 15) == 0);
+  for (int j = wave; j < R; j += 4) {
+    float acc = 0.f;
+    if (v4) {
+      const float4* fr = reinterpret_cast<const float4*>(fg + (size_t)j * H);
+      const float4* wr = reinterpret_cast<const float4*>(w_p);
+      for (int c = lane; c < H / 4; c += 64) {
+        const float4 a = fr[c], b = wr[c];
+        acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+      }
+    } else {
+      for (int c = lane; c < H; c += 64) acc += fg[(size_t)j * H + c] * w_p[c];
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) xs[j] = acc;
+  }
+  __syncthreads();
+  if (tid < R) {
+    const int i = tid;
+    float a = 0.f;
+    const float di = vals ? 0.f : dinv[(size_t)g * R + i];
+    for (int w = 0; w < W; ++w) {
+      unsigned long long m = bits[((size_t)g * R + i) * W + w];
+      while (m) {
+        const int j = (w << 6) + __builtin_ctzll(m);
+        m &= m - 1;
+        const float wt = vals ? vals[((size_t)g * R + i) * R + j] : di * dinv[(size_t)g * R + j];
+        a += wt * xs[j];
+      }
+    }
+    const float x = xs[i];
+    const float z = 1.f / (1.f + expf(-((gate[0] * a + gate[1]) + (gate[2] * x + gate[3]))));
+    const float r = 1.f / (1.f + expf(-((gate[4] * a + gate[5]) + (gate[6] * x + gate[7]))));
+    const float hh = tanhf((gate[8] * a + gate[9]) + (gate[10] * (r * x) + gate[11]));
+    const float sc = hh * z + x * (1.f - z);
+    ss[i] = sc;
+    score[(size_t)g * R + i] = sc;
+  }
+  __syncthreads();
+  topk_keep(ss, R, k, keep + (size_t)g * W, tid);
+}
+
+__global__ void __launch_bounds__(256)
+gsl_topk_kernel(const float* __restrict__ score, int R, int k, uint64_t* __restrict__ keep) {
+  __shared__ float ss[MAX_R];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  if (tid < R) ss[tid] = score[(size_t)g * R + tid];
+  __syncthreads();
+  topk_keep(ss, R, k, keep + (size_t)g * ((R + 63) / 64), tid);
+}
+
+}  // namespace gh
+
+using namespace gh;
+
+extern "C" int gh_graph_build(const int32_t* tokens, const int32_t* lengths, int n_texts, int fixed_length,
+                              int window, int32_t* node_ids, int32_t* n_nodes, uint64_t* bits, float* dinv,
+                              gh_stream_t stream) {
+  GH_REQUIRE(fixed_length > 0 && fixed_length <= MAX_R, "graph_build: fixed_length %d not in [1,%d]", fixed_length, MAX_R);
+  GH_REQUIRE(window >= 1, "graph_build: window %d < 1", window);
+  if (n_texts <= 0) return 0;
+  prof_begin((hipStream_t)stream);
+  hipLaunchKernelGGL(graph_build_kernel, dim3(n_texts), dim3(256), 0, (hipStream_t)stream, tokens, lengths,
+                     fixed_length, window, node_ids, n_nodes, bits, dinv);
+  prof_end(PROF_GRAPH_BUILD, (double)n_texts * (12.0 * fixed_length + 8.0 * fixed_length * words_for(fixed_length) + 8.0),
+           (hipStream_t)stream);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gh_adj_pack_f64(const double* adj, int n, int r, uint64_t* bits, float* vals, gh_stream_t stream) {
+  GH_REQUIRE(r > 0 && r <= MAX_R, "adj_pack: r=%d not in [1,%d]", r, MAX_R);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(adj_pack_kernel<double>, dim3(n), dim3(256), 0, (hipStream_t)stream, adj, r, bits, vals);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int gh_adj_pack_f32(const float* adj, int n, int r, uint64_t* bits, float* vals, gh_stream_t stream) {
+  GH_REQUIRE(r > 0 && r <= MAX_R, "adj_pack: r=%d not in [1,%d]", r, MAX_R);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(adj_pack_kernel<float>, dim3(n), dim3(256), 0, (hipStream_t)stream, adj, r, bits, vals);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gh_adj_unpack(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, int n,
+                             int r, float* adj, gh_stream_t stream) {
+  GH_REQUIRE(r > 0 && r <= MAX_R, "adj_unpack: r=%d not in [1,%d]", r, MAX_R);
+  GH_REQUIRE(vals || dinv, "adj_unpack: need dinv or vals");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(adj_unpack_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, bits, dinv, vals, keep, r, adj);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gh_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                       const float* x, float* y, int n, int r, int h, int transpose, int accumulate,
+                       gh_stream_t stream) {
+  if (n <= 0) return 0;
+  return launch_spmm(bits, dinv, vals, keep, x, y, n, r, h, transpose, accumulate, (hipStream_t)stream);
+}
+
+extern "C" int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const float* feat,
+                             const float* w_p, const float* gate, int n, int r, int h, int k, float* score,
+                             uint64_t* keep, gh_stream_t stream) {
+  GH_REQUIRE(r > 0 && r <= MAX_R, "scorer_gsl: r=%d not in [1,%d]", r, MAX_R);
+  GH_REQUIRE(vals || dinv, "scorer_gsl: need dinv or vals");
+  if (n <= 0) return 0;
+  prof_begin((hipStream_t)stream);
+  hipLaunchKernelGGL(scorer_gsl_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, bits, dinv, vals, feat, w_p,
+                     gate, r, h, k, score, keep);
+  prof_end(PROF_SCORER_GSL, (double)n * (4.0 * r * h + 8.0 * r * words_for(r) + 8.0 * r + 8.0 * words_for(r)),
+           (hipStream_t)stream);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gh_gsl_topk(const float* score, int n, int r, int k, uint64_t* keep, gh_stream_t stream) {
+  GH_REQUIRE(r > 0 && r <= MAX_R, "gsl_topk: r=%d not in [1,%d]", r, MAX_R);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gsl_topk_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, score, r, k, keep);
+  GH_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,502 @@
+// Streaming (HBM-bound) kernels around the GEMMs: gate-backward elementwise, column sums, masked
+// softmax + weighted reduce of the concat attention (fwd/bwd), ragged claim<->evidence helpers,
+// weight transpose, fused flat Adam.  Plus the library's error plumbing.
+#include "../../include/get_hip.h"
+#include "common.h"
+#include <stdarg.h>
+#include <vector>
+
+namespace gh {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------------------- event profiler
+struct ProfRec { hipEvent_t a, b; int tag; double work; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+static hipEvent_t g_prof_cur = nullptr;
+
+static hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+bool prof_enabled() { return g_prof_on; }
+void prof_begin(hipStream_t s) {
+  if (!g_prof_on) return;
+  g_prof_cur = prof_event();
+  if (g_prof_cur) (void)hipEventRecord(g_prof_cur, s);
+}
+void prof_end(int tag, double work, hipStream_t s) {
+  if (!g_prof_on || !g_prof_cur) return;
+  hipEvent_t b = prof_event();
+  if (!b) return;
+  (void)hipEventRecord(b, s);
+  g_prof_recs.push_back(ProfRec{g_prof_cur, b, tag, work});
+  g_prof_cur = nullptr;
+}
+
+// ---------------------------------------------------------------------------- transpose
+__global__ void __launch_bounds__(256)
+transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    if (r < rows && c < cols) tile[j][tx] = w[(size_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;      // output row = c, output col = r
+    if (r < rows && c < cols) wt[(size_t)c * rows + r] = tile[tx][j];
+  }
+}
+
+// ---------------------------------------------------------------------------- GGNN gate backward (elementwise part)
+// out = h z + xp (1 - z)  (wrapper.py:206):  dhp = g z (1-h^2) ; dzp = g (h-xp) z (1-z) ; dxp = g (1-z)
+__global__ void __launch_bounds__(256)
+gate_bwd_pre_kernel(const float4* __restrict__ g, const float4* __restrict__ z, const float4* __restrict__ hh,
+                    const float4* __restrict__ xp, float4* __restrict__ dhp, float4* __restrict__ dzp,
+                    float4* __restrict__ dxp, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 G = g[i], Z = z[i], Hh = hh[i], X = xp[i];
+    float4 a, b, c;
+#define GH_ONE(f)                                      \
+    a.f = G.f * Z.f * (1.f - Hh.f * Hh.f);             \
+    b.f = G.f * (Hh.f - X.f) * Z.f * (1.f - Z.f);      \
+    c.f = G.f * (1.f - Z.f);
+    GH_ONE(x) GH_ONE(y) GH_ONE(z) GH_ONE(w)
+#undef GH_ONE
+    dhp[i] = a; dzp[i] = b; dxp[i] = c;
+  }
+}
+__global__ void __launch_bounds__(256)
+gate_bwd_pre_scalar_kernel(const float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ hh,
+                           const float* __restrict__ xp, float* __restrict__ dhp, float* __restrict__ dzp,
+                           float* __restrict__ dxp, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float G = g[i], Z = z[i], Hh = hh[i], X = xp[i];
+    dhp[i] = G * Z * (1.f - Hh * Hh);
+    dzp[i] = G * (Hh - X) * Z * (1.f - Z);
+    dxp[i] = G * (1.f - Z);
+  }
+}
+
+int launch_gate_bwd_pre(const float* g, const float* z, const float* hh, const float* xp, float* dhp, float* dzp,
+                        float* dxp, size_t count, hipStream_t s) {
+  if (count == 0) return 0;
+  const uintptr_t al = (uintptr_t)g | (uintptr_t)z | (uintptr_t)hh | (uintptr_t)xp | (uintptr_t)dhp | (uintptr_t)dzp | (uintptr_t)dxp;
+  if (count % 4 == 0 && (al & 15) == 0) {
+    const size_t n4 = count / 4;
+    const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    prof_begin(s);
+    hipLaunchKernelGGL(gate_bwd_pre_kernel, dim3(grid), dim3(256), 0, s, (const float4*)g, (const float4*)z,
+                       (const float4*)hh, (const float4*)xp, (float4*)dhp, (float4*)dzp, (float4*)dxp, n4);
+    prof_end(PROF_GATE_BWD_PRE, 7.0 * 4.0 * (double)count, s);
+  } else {
+    const int grid = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gate_bwd_pre_scalar_kernel, dim3(grid), dim3(256), 0, s, g, z, hh, xp, dhp, dzp, dxp, count);
+  }
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------- column sums (bias gradients), += via atomics
+constexpr int CS_ROWS = 256;
+__global__ void __launch_bounds__(256)
+colsum_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+              float* __restrict__ oa, float* __restrict__ ob, float* __restrict__ oc, int m, int h) {
+  const int r0 = blockIdx.x * CS_ROWS, r1 = min(m, r0 + CS_ROWS);
+  for (int col = threadIdx.x; col < h; col += 256) {
+    float sa = 0.f, sb = 0.f, sc = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      sa += a[(size_t)r * h + col];
+      if (b) sb += b[(size_t)r * h + col];
+      if (c) sc += c[(size_t)r * h + col];
+    }
+    atomicAdd(oa + col, sa);
+    if (b) atomicAdd(ob + col, sb);
+    if (c) atomicAdd(oc + col, sc);
+  }
+}
+int launch_colsum3(const float* a, const float* b, const float* c, float* oa, float* ob, float* oc, int m, int h,
+                   hipStream_t s) {
+  if (m <= 0) return 0;
+  prof_begin(s);
+  hipLaunchKernelGGL(colsum_kernel, dim3((m + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, s, a, b, c, oa, ob, oc, m, h);
+  prof_end(PROF_COLSUM, 4.0 * (double)m * h * (1 + (b != nullptr) + (c != nullptr)), s);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+int launch_colsum(const float* a, float* oa, int m, int h, hipStream_t s) {
+  return launch_colsum3(a, nullptr, nullptr, oa, nullptr, nullptr, m, h, s);
+}
+
+// ---------------------------------------------------------------------------- concat attention: masked softmax + weighted reduce
+// e [b][l][C] -> weights = softmax over l (two_branches_attention.py:142-146), attended[b][d][c] = sum_l right[b][l][d] w[l][c] (:147)
+__global__ void __launch_bounds__(256)
+att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ mask, const float* __restrict__ right,
+                       int L, int Dr, int C, float* __restrict__ weights, float* __restrict__ attended) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  float* ws = reinterpret_cast<float*>(dsm);   // [L][C]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* eb = e + (size_t)b * L * C;
+  const float* mb = mask + (size_t)b * L;
+  for (int c = wave; c < C; c += 4) {
+    float mx = -INFINITY;
+    for (int l = lane; l < L; l += 64)
+      if (mb[l] != 0.f) mx = fmaxf(mx, eb[l * C + c]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int l = lane; l < L; l += 64) {
+      const float p = (mb[l] != 0.f) ? expf(eb[l * C + c] - mx) : 0.f;
+      ws[l * C + c] = p;
+      sum += p;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.f / sum;          // all-masked row: 0/0 = NaN, as the reference's softmax of -inf
+    for (int l = lane; l < L; l += 64) ws[l * C + c] = (sum > 0.f) ? ws[l * C + c] * inv : NAN;
+  }
+  __syncthreads();
+  if (blockIdx.y == 0)
+    for (int i = tid; i < L * C; i += 256) weights[(size_t)b * L * C + i] = ws[i];
+  const int d = blockIdx.y * 256 + tid;
+  if (d < Dr) {
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    const float* rb = right + (size_t)b * L * Dr + d;
+    for (int l = 0; l < L; ++l) {
+      const float rv = rb[(size_t)l * Dr];
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < C) acc[c] += rv * ws[l * C + c];
+    }
+    float* o = attended + ((size_t)b * Dr + d) * C;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < C) o[c] = acc[c];
+  }
+}
+
+int launch_att_softmax_fwd(const float* e, const float* mask, const float* right, int b, int l, int dr, int heads,
+                           float* weights, float* attended, hipStream_t s) {
+  const size_t lds = (size_t)l * heads * 4;
+  GH_REQUIRE(lds <= 64 * 1024, "att_softmax_fwd: sequence %d x heads %d too large", l, heads);
+  prof_begin(s);
+  hipLaunchKernelGGL(att_softmax_fwd_kernel, dim3(b, (dr + 255) / 256), dim3(256), lds, s, e, mask, right, l, dr,
+                     heads, weights, attended);
+  prof_end(PROF_ATT_SOFTMAX_FWD, 4.0 * (double)b * ((double)l * dr + 2.0 * l * heads + l + (double)dr * heads), s);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
+// backward of the softmax/reduce: dw[l][c] = sum_d right[l][d] g_att[d][c] (+ g_w) ; de = w (dw - sum_l w dw) ;
+// dright[l][d] = sum_c w[l][c] g_att[d][c]  (first contribution; the GEMM adds dpre W1r on top)
+__global__ void __launch_bounds__(256)
+att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict__ weights,
+                       const float* __restrict__ g_att, const float* __restrict__ g_w, int L, int Dr, int C,
+                       float* __restrict__ de, float* __restrict__ dright) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  float* ga = reinterpret_cast<float*>(dsm);   // [Dr][C]
+  float* ws = ga + (size_t)Dr * C;             // [L][C]
+  float* dw = ws + (size_t)L * C;              // [L][C]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < Dr * C; i += 256) ga[i] = g_att[(size_t)b * Dr * C + i];
+  for (int i = tid; i < L * C; i += 256) ws[i] = weights[(size_t)b * L * C + i];
+  __syncthreads();
+  for (int l = wave; l < L; l += 4) {
+    float part[8], wl[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { part[c] = 0.f; wl[c] = (c < C) ? ws[l * C + c] : 0.f; }
+    const float* rr = right + ((size_t)b * L + l) * Dr;
+    float* dr_ = dright + ((size_t)b * L + l) * Dr;
+    for (int d = lane; d < Dr; d += 64) {
+      const float rv = rr[d];
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < C) {
+          const float gv = ga[d * C + c];
+          acc += wl[c] * gv;
+          part[c] += rv * gv;
+        }
+      dr_[d] = acc;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float v = part[c];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0 && c < C) dw[l * C + c] = v + (g_w ? g_w[((size_t)b * L + l) * C + c] : 0.f);
+    }
+  }
+  __syncthreads();
+  for (int c = wave; c < C; c += 4) {
+    float sum = 0.f;
+    for (int l = lane; l < L; l += 64) sum += ws[l * C + c] * dw[l * C + c];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    for (int l = lane; l < L; l += 64)
+      de[((size_t)b * L + l) * C + c] = ws[l * C + c] * (dw[l * C + c] - sum);
+  }
+}
+
+int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w, int b,
+                           int l, int dr, int heads, float* de, float* dright, hipStream_t s) {
+  const size_t lds = ((size_t)dr * heads + 2 * (size_t)l * heads) * 4;
+  GH_REQUIRE(lds <= 160 * 1024, "att_softmax_bwd: %zu B of LDS needed", lds);
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)att_softmax_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  prof_begin(s);
+  hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(b), dim3(256), lds, s, right, weights, g_att, g_w, l, dr, heads, de,
+                     dright);
+  prof_end(PROF_ATT_SOFTMAX_BWD, 4.0 * (double)b * (2.0 * l * dr + 3.0 * l * heads + (double)dr * heads), s);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
+// dpre[m][n] = (sum_c de[m][c] w2[c][n]) (1 - t[m][n]^2) ; du[b][n] = sum_l dpre[b*L+l][n]
+__global__ void __launch_bounds__(256)
+att_dpre_kernel(const float* __restrict__ de, const float* __restrict__ w2, const float* __restrict__ t, int L,
+                int Ha, int C, float* __restrict__ dpre, float* __restrict__ du) {
+  const int b = blockIdx.x;
+  const int n = blockIdx.y * 256 + threadIdx.x;
+  if (n >= Ha) return;
+  float wc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) wc[c] = (c < C) ? w2[c * Ha + n] : 0.f;
+  float acc = 0.f;
+  for (int l = 0; l < L; ++l) {
+    const size_t m = (size_t)b * L + l;
+    float dt = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < C) dt += de[m * C + c] * wc[c];
+    const float tv = t[m * Ha + n];
+    const float dp = dt * (1.f - tv * tv);
+    dpre[m * Ha + n] = dp;
+    acc += dp;
+  }
+  du[(size_t)b * Ha + n] = acc;
+}
+
+int launch_att_dpre(const float* de, const float* w2, const float* t, int b, int l, int ha, int heads, float* dpre,
+                    float* du, hipStream_t s) {
+  prof_begin(s);
+  hipLaunchKernelGGL(att_dpre_kernel, dim3(b, (ha + 255) / 256), dim3(256), 0, s, de, w2, t, l, ha, heads, dpre, du);
+  prof_end(PROF_ATT_DPRE, 4.0 * (double)b * (2.0 * l * ha + (double)l * heads + ha), s);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------- ragged helpers (basic_fc_model.py:80-121)
+__global__ void __launch_bounds__(256)
+seg_offsets_kernel(const int64_t* __restrict__ counts, int B, int32_t* __restrict__ offsets,
+                   int32_t* __restrict__ pair2claim, int b1) {
+  __shared__ int total;
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int b = 0; b < B; ++b) { offsets[b] = acc; acc += (int)counts[b]; }
+    offsets[B] = acc;
+    total = acc;
+  }
+  __syncthreads();
+  __threadfence_block();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const int lo = offsets[b], hi = min(offsets[b + 1], b1);
+    for (int p = lo; p < hi; ++p) pair2claim[p] = b;
+  }
+  (void)total;
+}
+
+__global__ void __launch_bounds__(256)
+seg_broadcast_kernel(const float* __restrict__ src, const int32_t* __restrict__ pair2claim, float* __restrict__ dst,
+                     int b1, int X) {
+  const int p = blockIdx.x;
+  const float* s = src + (size_t)pair2claim[p] * X;
+  for (int i = threadIdx.x; i < X; i += blockDim.x) dst[(size_t)p * X + i] = s[i];
+}
+
+__global__ void __launch_bounds__(256)
+seg_sum_kernel(const float* __restrict__ src, const int32_t* __restrict__ offsets, float* __restrict__ dst, int X) {
+  const int b = blockIdx.x;
+  const int lo = offsets[b], hi = offsets[b + 1];
+  for (int i = threadIdx.x; i < X; i += blockDim.x) {
+    float acc = 0.f;
+    for (int p = lo; p < hi; ++p) acc += src[(size_t)p * X + i];
+    dst[(size_t)b * X + i] = acc;
+  }
+}
+
+// dst[b][slot][0:X] = src[offsets[b]+slot] for slot < count(b), else 0   (dst row pitch dst_ld >= X)
+__global__ void __launch_bounds__(256)
+seg_pad_kernel(const float* __restrict__ src, const int32_t* __restrict__ offsets, float* __restrict__ dst, int n_max,
+               int X, int dst_ld) {
+  const int b = blockIdx.x / n_max, slot = blockIdx.x % n_max;
+  const int lo = offsets[b], cnt = offsets[b + 1] - lo;
+  float* d = dst + ((size_t)b * n_max + slot) * dst_ld;
+  if (slot < cnt) {
+    const float* s = src + (size_t)(lo + slot) * X;
+    for (int i = threadIdx.x; i < X; i += blockDim.x) d[i] = s[i];
+  } else {
+    for (int i = threadIdx.x; i < X; i += blockDim.x) d[i] = 0.f;
+  }
+}
+__global__ void __launch_bounds__(256)
+seg_unpad_kernel(const float* __restrict__ src, const int32_t* __restrict__ offsets, float* __restrict__ dst,
+                 int n_max, int X, int src_ld) {
+  const int b = blockIdx.x / n_max, slot = blockIdx.x % n_max;
+  const int lo = offsets[b], cnt = offsets[b + 1] - lo;
+  if (slot >= cnt) return;
+  const float* s = src + ((size_t)b * n_max + slot) * src_ld;
+  float* d = dst + (size_t)(lo + slot) * X;
+  for (int i = threadIdx.x; i < X; i += blockDim.x) d[i] = s[i];
+}
+
+// claim vector: sum_l hid[b][l][:] [ids[b][l] > 0] / len[b]   (graph_based_semantic_structure.py:145,153)
+__global__ void __launch_bounds__(256)
+masked_mean_fwd_kernel(const float* __restrict__ hid, const int32_t* __restrict__ ids, const float* __restrict__ lens,
+                       float* __restrict__ dst, int L, int H) {
+  const int b = blockIdx.x;
+  const float inv = 1.f / lens[b];
+  for (int i = threadIdx.x; i < H; i += blockDim.x) {
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l)
+      if (ids[b * L + l] > 0) acc += hid[((size_t)b * L + l) * H + i];
+    dst[(size_t)b * H + i] = acc * inv;
+  }
+}
+__global__ void __launch_bounds__(256)
+masked_mean_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ ids, const float* __restrict__ lens,
+                       float* __restrict__ dhid, int L, int H) {
+  const int b = blockIdx.x / L, l = blockIdx.x % L;
+  const float sc = (ids[b * L + l] > 0) ? 1.f / lens[b] : 0.f;
+  for (int i = threadIdx.x; i < H; i += blockDim.x) dhid[((size_t)b * L + l) * H + i] = g[(size_t)b * H + i] * sc;
+}
+
+// ---------------------------------------------------------------------------- flat Adam (torch.optim.Adam, L2 weight decay)
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+            size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float w = p[i];
+    const float gr = g[i] * gscale + wd * w;
+    const float mi = b1 * m[i] + (1.f - b1) * gr;
+    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mi; v[i] = vi;
+    // torch: denom = sqrt(v)/sqrt(bias_correction2) + eps ; p -= (lr / bias_correction1) * m / denom
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = w - (lr / bc1) * (mi / denom);
+  }
+}
+
+}  // namespace gh
+
+using namespace gh;
+
+extern "C" int gh_abi_version(void) { return GH_ABI_VERSION; }
+extern "C" const char* gh_last_error(void) { return g_err; }
+
+extern "C" int gh_profile_enable(int on) {
+  g_prof_on = on != 0;
+  return 0;
+}
+// out[PROF_NTAGS][3] = {total ms, total work, launches}; waits for the recorded events, then resets.
+extern "C" int gh_profile_collect(double* out, int rows) {
+  GH_REQUIRE(rows >= PROF_NTAGS, "profile_collect: need %d rows", (int)PROF_NTAGS);
+  for (int i = 0; i < rows * 3; ++i) out[i] = 0.0;
+  for (auto& r : g_prof_recs) {
+    float ms = 0.f;
+    GH_CHECK_HIP(hipEventSynchronize(r.b));
+    GH_CHECK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    out[r.tag * 3 + 0] += ms;
+    out[r.tag * 3 + 1] += r.work;
+    out[r.tag * 3 + 2] += 1.0;
+    g_prof_pool.push_back(r.a);
+    g_prof_pool.push_back(r.b);
+  }
+  g_prof_recs.clear();
+  return 0;
+}
+
+extern "C" int gh_transpose(const float* w, float* wt, int rows, int cols, gh_stream_t stream) {
+  GH_REQUIRE(rows > 0 && cols > 0, "transpose: bad sizes %d x %d", rows, cols);
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, w,
+                     wt, rows, cols);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gh_seg_offsets(const int64_t* counts, int b, int32_t* offsets, int32_t* pair2claim, int b1,
+                              gh_stream_t stream) {
+  GH_REQUIRE(b > 0, "seg_offsets: b=%d", b);
+  hipLaunchKernelGGL(seg_offsets_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counts, b, offsets, pair2claim, b1);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int gh_seg_broadcast(const float* src, const int32_t* pair2claim, float* dst, int b1, int x,
+                                gh_stream_t stream) {
+  if (b1 <= 0) return 0;
+  hipLaunchKernelGGL(seg_broadcast_kernel, dim3(b1), dim3(256), 0, (hipStream_t)stream, src, pair2claim, dst, b1, x);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int gh_seg_sum(const float* src, const int32_t* offsets, float* dst, int b, int x, gh_stream_t stream) {
+  if (b <= 0) return 0;
+  hipLaunchKernelGGL(seg_sum_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, src, offsets, dst, x);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int gh_seg_pad(const float* src, const int32_t* offsets, float* dst, int b, int n_max, int x, int dst_ld,
+                          gh_stream_t stream) {
+  if (b <= 0) return 0;
+  hipLaunchKernelGGL(seg_pad_kernel, dim3(b * n_max), dim3(256), 0, (hipStream_t)stream, src, offsets, dst, n_max, x, dst_ld);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int gh_seg_unpad(const float* src, const int32_t* offsets, float* dst, int b, int n_max, int x, int src_ld,
+                            gh_stream_t stream) {
+  if (b <= 0) return 0;
+  hipLaunchKernelGGL(seg_unpad_kernel, dim3(b * n_max), dim3(256), 0, (hipStream_t)stream, src, offsets, dst, n_max, x, src_ld);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int gh_masked_mean_fwd(const float* hid, const int32_t* ids, const float* lens, float* dst, int b, int l,
+                                  int h, gh_stream_t stream) {
+  if (b <= 0) return 0;
+  hipLaunchKernelGGL(masked_mean_fwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, hid, ids, lens, dst, l, h);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int gh_masked_mean_bwd(const float* g, const int32_t* ids, const float* lens, float* dhid, int b, int l,
+                                  int h, gh_stream_t stream) {
+  if (b <= 0) return 0;
+  hipLaunchKernelGGL(masked_mean_bwd_kernel, dim3(b * l), dim3(256), 0, (hipStream_t)stream, g, ids, lens, dhid, l, h);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gh_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int step, float grad_scale,
+                            gh_stream_t stream) {
+  GH_REQUIRE(step >= 1, "adam_step: step=%d must be >= 1", step);
+  if (count <= 0) return 0;
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const int grid = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
+  prof_begin((hipStream_t)stream);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)count, lr, beta1,
+                     beta2, eps, weight_decay, bc1, (float)sqrt(bc2), grad_scale);
+  prof_end(PROF_ADAM, 28.0 * (double)count, (hipStream_t)stream);
+  GH_LAUNCH_CHECK();
+  return 0;
+}

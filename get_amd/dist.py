@@ -1,0 +1,85 @@
+"""Data-parallel training glue: one flat fp32 bucket of the LIVE parameters, one RCCL all-reduce of
+its gradient per step, one fused Adam kernel over it.
+
+The reference is single-process; claims are independent (8(e)), so the path shards
+by claims with exactly one exchange step: all-reduce(sum) of the flat gradient, scaled by 1/world in
+the optimiser.  Parameters that never receive a gradient in GET -- the two dead LSTMs, ``trans`` and
+the GSL word scorer (no gradient flows through top-k, wrapper.py:219) -- are left out of the bucket
+and of the optimiser, matching torch.optim.Adam's skipping of ``grad is None`` (no weight decay).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+DEAD_PREFIXES = ("bilstm.", "query_bilstm.", "trans.", "ggnn_with_gsl.word_scorer1.")
+
+
+def live_parameters(model: torch.nn.Module):
+    return [(n, p) for n, p in model.named_parameters()
+            if p.requires_grad and not n.startswith(DEAD_PREFIXES)]
+
+
+def shard_claims(n_claims: int, rank: int, world: int) -> range:
+    """Contiguous, equal slices of the (already shuffled) claim list; equal claim counts keep the
+    mean-reduced loss of the union equal to the average of the per-rank losses."""
+    assert n_claims % world == 0, "global batch must divide by the number of ranks"
+    per = n_claims // world
+    return range(rank * per, (rank + 1) * per)
+
+
+class FlatTrainer:
+    """Owns flat parameter / gradient / Adam-moment buffers; ``param.data`` and ``param.grad`` of every
+    live parameter are views into them, so autograd accumulates straight into the all-reduce bucket."""
+
+    def __init__(self, model: torch.nn.Module, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 process_group=None):
+        self.model = model
+        self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.group = process_group
+        live = live_parameters(model)
+        self.live_names: List[str] = [n for n, _ in live]
+        self.params = [p for _, p in live]
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat_p = torch.empty(total, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat_m = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.flat_v = torch.zeros(total, device=dev, dtype=torch.float32)
+        off = 0
+        self._views = []
+        for p in self.params:
+            n = p.numel()
+            self.flat_p[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + n].view_as(p)
+            gv = self.flat_g[off:off + n].view_as(p)
+            p.grad = gv
+            self._views.append(gv)
+            off += n
+        self.numel = total
+        self.t = 0
+
+    @property
+    def world(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for p, gv in zip(self.params, self._views):
+            if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
+                p.grad = gv                      # re-attach if something replaced the view
+
+    def allreduce(self):
+        """One all-reduce(sum) of the whole gradient bucket (RCCL over xGMI on GPUs, gloo in CPU tests)."""
+        if self.world > 1:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+
+    def step(self):
+        """all-reduce + fused Adam on the flat bucket (gradient averaged over ranks inside the kernel)."""
+        from . import ops
+        self.allreduce()
+        self.t += 1
+        ops.adam_step_flat(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.t, lr=self.lr, betas=self.betas,
+                           eps=self.eps, weight_decay=self.weight_decay, grad_scale=1.0 / self.world)

@@ -1,0 +1,424 @@
+"""Autograd-aware host wrappers over the C-ABI (one ``torch.autograd.Function`` per fused op).
+
+PyTorch supplies device memory, streams and the autograd tape; every numerical
+step runs in libget_hip.so.  All tensors are fp32/contiguous on a ROCm device.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+_WEIGHT_EPOCH = 0
+_WT_CACHE: dict = {}
+
+
+def bump_weight_epoch():
+    """Invalidate cached transposed weights (call after updating parameters through raw pointers)."""
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+    _WT_CACHE.clear()
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def transposed(w: torch.Tensor) -> torch.Tensor:
+    """W[n_out][n_in] -> Wt[n_in][n_out]; cached per (storage, version, epoch)."""
+    w = w.detach()
+    key = (w.data_ptr(), tuple(w.shape), w._version, _WEIGHT_EPOCH)
+    hit = _WT_CACHE.get(key)
+    if hit is not None:
+        return hit
+    wc = _f32(w)
+    wt = torch.empty((wc.shape[1], wc.shape[0]), device=w.device, dtype=torch.float32)
+    call("gh_transpose", ptr(wc), ptr(wt), wc.shape[0], wc.shape[1], stream())
+    if len(_WT_CACHE) > 256:
+        _WT_CACHE.clear()
+    _WT_CACHE[key] = wt
+    return wt
+
+
+# --------------------------------------------------------------------------- packed adjacency
+class PackedAdj:
+    """Adjacency of ``n`` graphs with ``r`` padded nodes in the library's packed form
+    (include/get_hip.h): neighbour bit rows + either dinv (normalised binary graph built by
+    ``graph_build``) or dense fp32 values (any adjacency the reference API hands over), plus an
+    optional GSL keep-set."""
+
+    __slots__ = ("bits", "dinv", "vals", "keep", "n", "r")
+
+    def __init__(self, bits, dinv, vals, keep, n, r):
+        self.bits, self.dinv, self.vals, self.keep, self.n, self.r = bits, dinv, vals, keep, n, r
+
+    @property
+    def words(self):
+        return (self.r + 63) // 64
+
+    @property
+    def device(self):
+        return self.bits.device
+
+    @staticmethod
+    def from_dense(adj: torch.Tensor) -> "PackedAdj":
+        """(N,R,R) float64/float32 -> packed (exact values kept, i.e. the reference's `.float()`)."""
+        _lib.require_cuda(adj)
+        assert adj.dim() == 3 and adj.shape[1] == adj.shape[2], "adjacency must be (N,R,R)"
+        n, r, _ = adj.shape
+        if adj.dtype not in (torch.float64, torch.float32):
+            adj = adj.float()
+        adj = adj.contiguous()
+        w = (r + 63) // 64
+        bits = torch.empty((n, r, w), device=adj.device, dtype=torch.int64)
+        vals = torch.empty((n, r, r), device=adj.device, dtype=torch.float32)
+        fn = "gh_adj_pack_f64" if adj.dtype == torch.float64 else "gh_adj_pack_f32"
+        call(fn, ptr(adj), n, r, ptr(bits), ptr(vals), stream())
+        return PackedAdj(bits, None, vals, None, n, r)
+
+    def with_keep(self, keep: Optional[torch.Tensor]) -> "PackedAdj":
+        return PackedAdj(self.bits, self.dinv, self.vals, keep, self.n, self.r)
+
+    def to_dense(self) -> torch.Tensor:
+        out = torch.empty((self.n, self.r, self.r), device=self.device, dtype=torch.float32)
+        call("gh_adj_unpack", ptr(self.bits), ptr(self.dinv), ptr(self.vals), ptr(self.keep), self.n, self.r,
+             ptr(out), stream())
+        return out
+
+    def _args(self):
+        return ptr(self.bits), ptr(self.dinv), ptr(self.vals), ptr(self.keep)
+
+
+def graph_build(tokens: torch.Tensor, lengths: torch.Tensor, window: int):
+    """interactions.py:334-351 on device.  tokens (N,R) raw ids, lengths (N,).
+
+    Returns (PackedAdj, node_ids (N,R) int32, n_nodes (N,) int32)."""
+    _lib.require_cuda(tokens, lengths)
+    tokens = tokens.to(torch.int32).contiguous()
+    lengths = lengths.to(torch.int32).contiguous()
+    n, r = tokens.shape
+    w = (r + 63) // 64
+    dev = tokens.device
+    node_ids = torch.empty((n, r), device=dev, dtype=torch.int32)
+    n_nodes = torch.empty((n,), device=dev, dtype=torch.int32)
+    bits = torch.empty((n, r, w), device=dev, dtype=torch.int64)
+    dinv = torch.empty((n, r), device=dev, dtype=torch.float32)
+    call("gh_graph_build", ptr(tokens), ptr(lengths), n, r, int(window), ptr(node_ids), ptr(n_nodes), ptr(bits),
+         ptr(dinv), stream())
+    return PackedAdj(bits, dinv, None, None, n, r), node_ids, n_nodes
+
+
+def as_packed(adj) -> PackedAdj:
+    return adj if isinstance(adj, PackedAdj) else PackedAdj.from_dense(adj)
+
+
+# --------------------------------------------------------------------------- aggregation (a = A x)
+class _Spmm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, adj: PackedAdj):
+        x = _f32(x)
+        n, r, h = x.shape
+        y = torch.empty_like(x)
+        call("gh_spmm", *adj._args(), ptr(x), ptr(y), n, r, h, 0, 0, stream())
+        ctx.adj = adj
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32(g)
+        n, r, h = g.shape
+        dx = torch.empty_like(g)
+        call("gh_spmm", *ctx.adj._args(), ptr(g), ptr(dx), n, r, h, 1, 0, stream())
+        return dx, None
+
+
+def spmm(adj: PackedAdj, x: torch.Tensor) -> torch.Tensor:
+    return _Spmm.apply(x, adj)
+
+
+# --------------------------------------------------------------------------- GGNN cell
+class _GGNNCell(torch.autograd.Function):
+    """Models/BiDAF/wrapper.py:188-208 (without the input dropout, applied by the caller)."""
+
+    @staticmethod
+    def forward(ctx, x, ids, adj: PackedAdj, w_p, w_z0, b_z0, w_z1, b_z1, w_r0, b_r0, w_r1, b_r1, w_h0, b_h0, w_h1,
+                b_h1):
+        x = _f32(x)
+        n, r = adj.n, adj.r
+        h, din = w_p.shape
+        m = n * r
+        if ids is not None:
+            assert ids.dtype == torch.int32 and ids.numel() == m and x.dim() == 2 and x.shape[1] == din
+            ids = ids.contiguous()
+        else:
+            assert x.numel() == m * din, f"x has {x.numel()} elements, expected {m}x{din}"
+        dev = x.device
+        ws = [_f32(w.detach()) for w in (w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1)]
+        wts = [transposed(w) for w in (w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1)]
+        b_z = _f32((b_z0 + b_z1).detach())
+        b_r = _f32((b_r0 + b_r1).detach())
+        b_h = _f32((b_h0 + b_h1).detach())
+        buf = torch.empty((7, m, h), device=dev, dtype=torch.float32)
+        xp, a, z, rr, rx, hh, out = buf.unbind(0)
+        call("gh_ggnn_cell_fwd", *adj._args(), ptr(x), ptr(ids), n, r, din, h,
+             *[ptr(t) for t in wts], ptr(b_z), ptr(b_r), ptr(b_h),
+             ptr(xp), ptr(a), ptr(z), ptr(rr), ptr(rx), ptr(hh), ptr(out), stream())
+        ctx.adj, ctx.ids, ctx.dims = adj, ids, (n, r, din, h)
+        ctx.save_for_backward(x, buf, *ws)
+        ctx.x_needs_grad = ctx.needs_input_grad[0]
+        return out.view(n, r, h)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, buf, w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1 = ctx.saved_tensors
+        xp, a, z, rr, rx, hh, _ = buf.unbind(0)
+        n, r, din, h = ctx.dims
+        m = n * r
+        dev = g.device
+        g = _f32(g).reshape(m, h)
+        scratch = torch.empty((5, m, h), device=dev, dtype=torch.float32)
+        dhp, dzp, drp, dxp, da = scratch.unbind(0)
+        ids = ctx.ids
+        want_dx = ctx.x_needs_grad
+        dx = torch.empty((m, din), device=dev, dtype=torch.float32) if want_dx else None
+        dw_p = torch.zeros((h, din), device=dev, dtype=torch.float32)
+        dws = torch.zeros((6, h, h), device=dev, dtype=torch.float32)
+        dbs = torch.zeros((3, h), device=dev, dtype=torch.float32)
+        call("gh_ggnn_cell_bwd", *ctx.adj._args(), ptr(x), ptr(ids), n, r, din, h,
+             ptr(w_p), ptr(w_z0), ptr(w_z1), ptr(w_r0), ptr(w_r1), ptr(w_h0), ptr(w_h1),
+             ptr(xp), ptr(a), ptr(z), ptr(rr), ptr(rx), ptr(hh), ptr(g),
+             ptr(dhp), ptr(dzp), ptr(drp), ptr(dxp), ptr(da),
+             ptr(dx), ptr(dw_p), *[ptr(dws[i]) for i in range(6)], ptr(dbs[0]), ptr(dbs[1]), ptr(dbs[2]), stream())
+        if want_dx:
+            if ids is not None:      # trainable embedding table: scatter the row gradients
+                demb = torch.zeros_like(x)
+                demb.index_add_(0, ids.long(), dx)
+                dx = demb
+            else:
+                dx = dx.view(x.shape)
+        dz0, dz1, dr0, dr1, dh0, dh1 = dws.unbind(0)
+        bz, br, bh = dbs.unbind(0)
+        return (dx, None, None, dw_p, dz0, bz, dz1, bz, dr0, br, dr1, br, dh0, bh, dh1, bh)
+
+
+def ggnn_cell(adj: PackedAdj, x, ids, params):
+    """params: (w_p, w_z0, b_z0, w_z1, b_z1, w_r0, b_r0, w_r1, b_r1, w_h0, b_h0, w_h1, b_h1)."""
+    return _GGNNCell.apply(x, ids, adj, *params)
+
+
+# --------------------------------------------------------------------------- word scorer + GSL (no gradient)
+@torch.no_grad()
+def scorer_gsl(adj: PackedAdj, feat: torch.Tensor, w_p, gate12: torch.Tensor, k: int):
+    """GGNN(h->1) score of every node and the top-k keep set (wrapper.py:167-168, :215-219).
+    Returns (score (N,R) fp32, keep (N,W) int64 bit words)."""
+    feat = _f32(feat.detach())
+    n, r, h = feat.shape
+    score = torch.empty((n, r), device=feat.device, dtype=torch.float32)
+    keep = torch.empty((n, adj.words), device=feat.device, dtype=torch.int64)
+    w_p = _f32(w_p.detach().reshape(-1))
+    gate12 = _f32(gate12.detach())
+    call("gh_scorer_gsl", ptr(adj.bits), ptr(adj.dinv), ptr(adj.vals), ptr(feat), ptr(w_p), ptr(gate12), n, r, h,
+         int(k), ptr(score), ptr(keep), stream())
+    return score, keep
+
+
+@torch.no_grad()
+def gsl_topk(score: torch.Tensor, k: int) -> torch.Tensor:
+    score = _f32(score.detach())
+    n, r = score.shape
+    keep = torch.empty((n, (r + 63) // 64), device=score.device, dtype=torch.int64)
+    call("gh_gsl_topk", ptr(score), n, r, int(k), ptr(keep), stream())
+    return keep
+
+
+# --------------------------------------------------------------------------- concat attention
+class _ConcatAtt(torch.autograd.Function):
+    """two_branches_attention.py:121-148 (left given) / self_attention.py:75-100 (left None)."""
+
+    @staticmethod
+    def forward(ctx, left, right, mask, w1, w2):
+        right = _f32(right)
+        b, l, dr = right.shape
+        ha, inp = w1.shape
+        heads = w2.shape[0]
+        xl = 0
+        if left is not None:
+            left = _f32(left)
+            xl = left.shape[1]
+        assert inp == xl + dr, "linear1 input width must equal left + right widths"
+        dev = right.device
+        maskf = _f32(mask.to(torch.float32))
+        w1c, w2c = _f32(w1.detach()), _f32(w2.detach())
+        w1t = transposed(w1)
+        u = torch.empty((b, ha), device=dev, dtype=torch.float32)
+        t = torch.empty((b * l, ha), device=dev, dtype=torch.float32)
+        e = torch.empty((b * l, heads), device=dev, dtype=torch.float32)
+        weights = torch.empty((b, l, heads), device=dev, dtype=torch.float32)
+        attended = torch.empty((b, dr, heads), device=dev, dtype=torch.float32)
+        call("gh_concat_att_fwd", ptr(left), ptr(right), ptr(maskf), b, l, xl, dr, ha, heads, ptr(w1t), ptr(w2c),
+             ptr(u), ptr(t), ptr(e), ptr(weights), ptr(attended), stream())
+        ctx.dims = (b, l, xl, dr, ha, heads)
+        ctx.has_left = left is not None
+        ctx.save_for_backward(left if left is not None else right.new_empty(0), right, w1c, w2c, t, weights)
+        return attended, weights
+
+    @staticmethod
+    def backward(ctx, g_att, g_w):
+        left, right, w1, w2, t, weights = ctx.saved_tensors
+        b, l, xl, dr, ha, heads = ctx.dims
+        dev = right.device
+        if not ctx.has_left:
+            left = None
+        g_att = _f32(g_att) if g_att is not None else torch.zeros((b, dr, heads), device=dev)
+        g_w = _f32(g_w) if g_w is not None else None
+        de = torch.empty((b * l, heads), device=dev, dtype=torch.float32)
+        dpre = torch.empty((b * l, ha), device=dev, dtype=torch.float32)
+        du = torch.empty((b, ha), device=dev, dtype=torch.float32)
+        dleft = torch.empty((b, xl), device=dev, dtype=torch.float32) if left is not None else None
+        dright = torch.empty((b, l, dr), device=dev, dtype=torch.float32)
+        dw1 = torch.zeros((ha, xl + dr), device=dev, dtype=torch.float32)
+        dw2 = torch.zeros((heads, ha), device=dev, dtype=torch.float32)
+        call("gh_concat_att_bwd", ptr(left), ptr(right), b, l, xl, dr, ha, heads, ptr(w1), ptr(w2), ptr(t),
+             ptr(weights), ptr(g_att), ptr(g_w), ptr(de), ptr(dpre), ptr(du), ptr(dleft), ptr(dright), ptr(dw1),
+             ptr(dw2), stream())
+        return dleft, dright, None, dw1, dw2
+
+
+def concat_att(left, right, mask, w1, w2):
+    return _ConcatAtt.apply(left, right, mask, w1, w2)
+
+
+# --------------------------------------------------------------------------- linear
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = _f32(x).reshape(-1, x.shape[-1])
+        m, k = x2.shape
+        n = w.shape[0]
+        wc = _f32(w.detach())
+        y = torch.empty((m, n), device=x.device, dtype=torch.float32)
+        bc = _f32(b.detach()) if b is not None else None
+        call("gh_linear_fwd", ptr(x2), ptr(transposed(w)), ptr(bc), ptr(y), m, k, n, stream())
+        ctx.save_for_backward(x2, wc)
+        ctx.has_bias = b is not None
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w = ctx.saved_tensors
+        m, k = x2.shape
+        n = w.shape[0]
+        g2 = _f32(g).reshape(m, n)
+        dx = torch.empty((m, k), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dw = torch.zeros((n, k), device=g.device, dtype=torch.float32)
+        db = torch.zeros((n,), device=g.device, dtype=torch.float32) if ctx.has_bias else None
+        call("gh_linear_bwd", ptr(x2), ptr(w), ptr(g2), m, k, n, ptr(dx), ptr(dw), ptr(db), stream())
+        return (dx.view(ctx.xshape) if dx is not None else None), dw, db
+
+
+def linear(x, w, b=None):
+    return _Linear.apply(x, w, b)
+
+
+# --------------------------------------------------------------------------- ragged helpers
+class Segments:
+    """Claim -> evidence-pair segmentation of one batch (prefix sums live on the device)."""
+
+    def __init__(self, counts: torch.Tensor, b1: int, n_max: int):
+        _lib.require_cuda(counts)
+        counts = counts.to(torch.int64).contiguous()
+        self.b = counts.shape[0]
+        self.b1 = int(b1)
+        self.n_max = int(n_max)
+        self.offsets = torch.empty((self.b + 1,), device=counts.device, dtype=torch.int32)
+        self.pair2claim = torch.empty((max(self.b1, 1),), device=counts.device, dtype=torch.int32)
+        call("gh_seg_offsets", ptr(counts), self.b, ptr(self.offsets), ptr(self.pair2claim), self.b1, stream())
+
+
+class _SegBroadcast(torch.autograd.Function):       # basic_fc_model.py:80-92 _pad_left_tensor
+    @staticmethod
+    def forward(ctx, src, seg: Segments):
+        src = _f32(src)
+        x = src.shape[1]
+        dst = torch.empty((seg.b1, x), device=src.device, dtype=torch.float32)
+        call("gh_seg_broadcast", ptr(src), ptr(seg.pair2claim), ptr(dst), seg.b1, x, stream())
+        ctx.seg = seg
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32(g)
+        seg = ctx.seg
+        x = g.shape[1]
+        d = torch.empty((seg.b, x), device=g.device, dtype=torch.float32)
+        call("gh_seg_sum", ptr(g), ptr(seg.offsets), ptr(d), seg.b, x, stream())
+        return d, None
+
+
+class _SegPad(torch.autograd.Function):             # basic_fc_model.py:94-121 _pad_right_tensor
+    @staticmethod
+    def forward(ctx, src, seg: Segments):
+        src = _f32(src)
+        x = src.shape[1]
+        dst = torch.empty((seg.b, seg.n_max, x), device=src.device, dtype=torch.float32)
+        call("gh_seg_pad", ptr(src), ptr(seg.offsets), ptr(dst), seg.b, seg.n_max, x, x, stream())
+        ctx.seg = seg
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32(g)
+        seg = ctx.seg
+        x = g.shape[2]
+        d = torch.empty((seg.b1, x), device=g.device, dtype=torch.float32)
+        call("gh_seg_unpad", ptr(g), ptr(seg.offsets), ptr(d), seg.b, seg.n_max, x, x, stream())
+        return d, None
+
+
+def seg_broadcast(src, seg):
+    return _SegBroadcast.apply(src, seg)
+
+
+def seg_pad(src, seg):
+    return _SegPad.apply(src, seg)
+
+
+class _MaskedMean(torch.autograd.Function):         # graph_based_semantic_structure.py:145,153
+    @staticmethod
+    def forward(ctx, hid, ids, lens):
+        hid = _f32(hid)
+        b, l, h = hid.shape
+        lens = _f32(lens.to(torch.float32))
+        ids = ids.to(torch.int32).contiguous()
+        dst = torch.empty((b, h), device=hid.device, dtype=torch.float32)
+        call("gh_masked_mean_fwd", ptr(hid), ptr(ids), ptr(lens), ptr(dst), b, l, h, stream())
+        ctx.save_for_backward(ids, lens)
+        ctx.dims = (b, l, h)
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, lens = ctx.saved_tensors
+        b, l, h = ctx.dims
+        g = _f32(g)
+        d = torch.empty((b, l, h), device=g.device, dtype=torch.float32)
+        call("gh_masked_mean_bwd", ptr(g), ptr(ids), ptr(lens), ptr(d), b, l, h, stream())
+        return d, None, None
+
+
+def masked_mean(hid, ids, lens):
+    return _MaskedMean.apply(hid, ids, lens)
+
+
+# --------------------------------------------------------------------------- optimiser
+def adam_step_flat(p, g, m, v, step, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3, grad_scale=1.0):
+    """One Adam step on flat fp32 buffers (declare_fitter.py:58-61 semantics)."""
+    call("gh_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
+         float(eps), float(weight_decay), int(step), float(grad_scale), stream())
+    bump_weight_epoch()

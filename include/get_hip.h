@@ -1,0 +1,167 @@
+/*
+ * get_hip.h -- C-ABI of libget_hip.so, the MI355X (gfx950) implementation of the
+ * CRIPAC-DIG/GET hot path: sliding-window word-graph build, gated graph cells with
+ * graph-structure-learning (GSL) top-k refinement, and the word-/evidence-level
+ * multi-head "concat" attention.
+ *
+ * The reference has no FFI boundary of its own (it is pure Python on ATen); its
+ * boundary is the nn.Module API listed in SURVEY.md section 8(b).  Every entry
+ * point below names the reference function whose device work it replaces
+ * (paths relative to the upstream tree).  get_amd/ mirrors the reference's
+ * module classes on top of these.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host"; all float data is
+ *     fp32, dense, row-major; ids are int32; adjacency bit rows are uint64 words
+ *   - nothing allocates: outputs and scratch are caller-provided
+ *   - stream-ordered and re-entrant; `stream` is a hipStream_t passed as void*
+ *   - returns 0 on success, non-zero on error (message via gh_last_error());
+ *     never aborts the process
+ *
+ * Packed adjacency of one graph with R (padded) nodes, W = ceil(R/64):
+ *   bits[R][W]  uint64  bit j of row i set  <=>  A[i][j] != 0
+ *   dinv[R]     float   deg(i)^-1/2 of the binary graph (0 for padding rows);
+ *                       edge weight = dinv[i]*dinv[j]       ("normalised" mode)
+ *   vals[R][R]  float   optional dense edge weights; when non-NULL they are used
+ *                       instead of dinv ("weighted" mode: any dense adjacency
+ *                       the reference API hands over)
+ *   keep[W]     uint64  optional GSL keep-set; refined edge (i,j) exists iff
+ *                       bit(i,j) && (keep(i) || keep(j))    (wrapper.py:221-225)
+ */
+#ifndef GET_HIP_H
+#define GET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gh_stream_t;
+
+#define GH_ABI_VERSION 1
+
+int gh_abi_version(void);
+/* Thread-local message of the last failing call on this thread (never NULL). */
+const char* gh_last_error(void);
+
+/* ---- a1  graph build: interactions.py:334-351 convert_text + :11-18 _laplacian_normalize ----
+ * tokens[n_texts][fixed_length] raw token sequence (post-padded), lengths[n_texts].
+ * Out: node_ids[n_texts][fixed_length] de-duplicated ids in first-occurrence order (0 padded),
+ *      n_nodes[n_texts], bits[n_texts][R][W], dinv[n_texts][R]   (R = fixed_length). */
+int gh_graph_build(const int32_t* tokens, const int32_t* lengths, int n_texts, int fixed_length, int window,
+                   int32_t* node_ids, int32_t* n_nodes, uint64_t* bits, float* dinv, gh_stream_t stream);
+
+/* Dense adjacency handed over by the reference API ((N,R,R) float64 from handlers/mz_sampler.py:146,
+ * cast by `.float()` at graph_based_semantic_structure.py:99,149) -> packed bits + fp32 values. */
+int gh_adj_pack_f64(const double* adj, int n, int r, uint64_t* bits, float* vals, gh_stream_t stream);
+int gh_adj_pack_f32(const float* adj, int n, int r, uint64_t* bits, float* vals, gh_stream_t stream);
+
+/* ---- aggregation  a = A_hat x : Models/BiDAF/wrapper.py:192 `adj.matmul(x)` ----
+ * x,y [n][r][h].  transpose: use A^T (backward of the weighted mode); accumulate: y += . */
+int gh_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+            const float* x, float* y, int n, int r, int h, int transpose, int accumulate, gh_stream_t stream);
+
+/* ---- weight packing: W[n_out][n_in] -> Wt[n_in][n_out] (k-major operand of the MFMA GEMMs) ---- */
+int gh_transpose(const float* w, float* wt, int rows, int cols, gh_stream_t stream);
+
+/* ---- a2  GGNN cell: Models/BiDAF/wrapper.py:188-208 GGNN.forward ----
+ * Input rows are x[m][din] (m = n*r), or emb[ids[m]][din] when ids != NULL (fused
+ * embedding gather, graph_based_semantic_structure.py:100,150).
+ * wt_*: TRANSPOSED weights (gh_transpose of the reference's linear.weight):
+ *   wt_p[din][h]; wt_z0,wt_z1,wt_r0,wt_r1,wt_h0,wt_h1 [h][h].
+ * b_z = bz0+bz1, b_r = br0+br1, b_h = bh0+bh1 (each [h]).
+ * Saved for backward (all [m][h]): xp, a, z, r, rx, hh.  out [m][h]. */
+int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                     const float* x, const int32_t* ids, int n, int r, int din, int h,
+                     const float* wt_p, const float* wt_z0, const float* wt_z1, const float* wt_r0,
+                     const float* wt_r1, const float* wt_h0, const float* wt_h1,
+                     const float* b_z, const float* b_r, const float* b_h,
+                     float* xp, float* a, float* z, float* rr, float* rx, float* hh, float* out,
+                     gh_stream_t stream);
+
+/* Backward of the cell.  w_*: the reference's UNtransposed weights [h][h] / w_p[h][din].
+ * g [m][h] = dL/dout.  Scratch (all [m][h]): dhp, dzp, drp, dxp, da.
+ * Outputs: dx [m][din] (may be NULL: frozen embedding), and ACCUMULATED (+=) into
+ * dw_p[h][din], dw_z0..dw_h1 [h][h], db_z[h], db_r[h], db_h[h]  (caller zeroes them). */
+int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                     const float* x, const int32_t* ids, int n, int r, int din, int h,
+                     const float* w_p, const float* w_z0, const float* w_z1, const float* w_r0,
+                     const float* w_r1, const float* w_h0, const float* w_h1,
+                     const float* xp, const float* a, const float* z, const float* rr, const float* rx,
+                     const float* hh, const float* g,
+                     float* dhp, float* dzp, float* drp, float* dxp, float* da,
+                     float* dx, float* dw_p, float* dw_z0, float* dw_z1, float* dw_r0, float* dw_r1,
+                     float* dw_h0, float* dw_h1, float* db_z, float* db_r, float* db_h,
+                     gh_stream_t stream);
+
+/* ---- a2(300->1) + a3  word scorer + GSL top-k: wrapper.py:167-168, GSL.forward :215-227 ----
+ * feat [n][r][h]; w_p[h] = scorer proj.linear.weight; gate[12] = {wz0,bz0,wz1,bz1,wr0,br0,wr1,br1,
+ * wh0,bh0,wh1,bh1} (the six 1x1 linears).  k = int(rate * r) computed by the caller.
+ * Out: score[n][r], keep[n][W] (bit i set <=> node i among the k best; ties -> lower index). */
+int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const float* feat,
+                  const float* w_p, const float* gate, int n, int r, int h, int k,
+                  float* score, uint64_t* keep, gh_stream_t stream);
+/* GSL alone on given scores (GSL.forward on arbitrary score input). */
+int gh_gsl_topk(const float* score, int n, int r, int k, uint64_t* keep, gh_stream_t stream);
+/* Dense view of a (refined) packed adjacency, for callers that want GSL.forward's dense result. */
+int gh_adj_unpack(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                  int n, int r, float* adj, gh_stream_t stream);
+
+/* ---- a5/a6  concat attention: thirdparty/two_branches_attention.py:121-148 (left != NULL) and
+ *      thirdparty/self_attention.py:75-100 (left == NULL) ----
+ * left [b][xl] (or NULL, xl = 0), right [b][l][dr], mask [b][l] float (0 = padded).
+ * w1t = transpose of linear1.weight: [xl+dr][ha]; w2 = linear2.weight [heads][ha] (heads <= 8).
+ * Saved: u [b][ha] (left branch, hoisted out of the per-token product), t [b*l][ha] (tanh), e [b*l][heads].
+ * Out: weights [b][l][heads], attended [b][dr][heads]. */
+int gh_concat_att_fwd(const float* left, const float* right, const float* mask, int b, int l, int xl, int dr,
+                      int ha, int heads, const float* w1t, const float* w2,
+                      float* u, float* t, float* e, float* weights, float* attended, gh_stream_t stream);
+/* Backward.  w1 = linear1.weight [ha][xl+dr] untransposed.  g_att [b][dr][heads], g_w [b][l][heads] or NULL.
+ * Scratch: de [b*l][heads], dpre [b*l][ha], du [b][ha].
+ * Out: dleft [b][xl] (NULL ok), dright [b][l][dr]; ACCUMULATED: dw1 [ha][xl+dr], dw2 [heads][ha]. */
+int gh_concat_att_bwd(const float* left, const float* right, int b, int l, int xl, int dr, int ha, int heads,
+                      const float* w1, const float* w2, const float* t, const float* weights,
+                      const float* g_att, const float* g_w,
+                      float* de, float* dpre, float* du,
+                      float* dleft, float* dright, float* dw1, float* dw2, gh_stream_t stream);
+
+/* ---- plain linear y = x W^T + b (model head, graph_based_semantic_structure.py:69-72) ---- */
+int gh_linear_fwd(const float* x, const float* wt, const float* bias, float* y, int m, int k, int n,
+                  gh_stream_t stream);
+/* dx = g W (NULL ok); dw += g^T x; db += colsum(g) (NULL ok). */
+int gh_linear_bwd(const float* x, const float* w, const float* g, int m, int k, int n,
+                  float* dx, float* dw, float* db, gh_stream_t stream);
+
+/* ---- a8  ragged helpers: Models/FCWithEvidences/basic_fc_model.py:80-121 ----
+ * offsets[b+1] int32 prefix sum of evidence counts (device). */
+int gh_seg_offsets(const int64_t* counts, int b, int32_t* offsets, int32_t* pair2claim, int b1, gh_stream_t stream);
+int gh_seg_broadcast(const float* src, const int32_t* pair2claim, float* dst, int b1, int x, gh_stream_t stream);
+int gh_seg_sum(const float* src, const int32_t* offsets, float* dst, int b, int x, gh_stream_t stream);
+int gh_seg_pad(const float* src, const int32_t* offsets, float* dst, int b, int n_max, int x, int dst_ld,
+               gh_stream_t stream);
+int gh_seg_unpad(const float* src, const int32_t* offsets, float* dst, int b, int n_max, int x, int src_ld,
+                 gh_stream_t stream);
+/* masked mean over claim nodes (graph_based_semantic_structure.py:153): dst[b][h] = sum_l hid*mask / len */
+int gh_masked_mean_fwd(const float* hid, const int32_t* ids, const float* lens, float* dst, int b, int l, int h,
+                       gh_stream_t stream);
+int gh_masked_mean_bwd(const float* g, const int32_t* ids, const float* lens, float* dhid, int b, int l, int h,
+                       gh_stream_t stream);
+
+/* ---- optimiser: torch.optim.Adam(weight_decay) semantics of Fitting/FittingFC/declare_fitter.py:58-61
+ *      on one flat fp32 bucket (the same bucket the RCCL gradient all-reduce uses) ---- */
+int gh_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int step, float grad_scale, gh_stream_t stream);
+
+/* ---- measurement hook (bench.py): HIP events around every kernel launch on its own stream ----
+ * rows of `out` (each {total ms, total algorithmic work, launches}; work = flops for GEMMs, bytes otherwise):
+ * 0 gemm 128x304 NT/NN, 1 gemm 128x304 TN, 2 gemm 32x320 NT/NN, 3 gemm 32x320 TN, 4 spmm, 5 scorer_gsl,
+ * 6 graph_build, 7 att_softmax_fwd, 8 att_softmax_bwd, 9 att_dpre, 10 gate_bwd_pre, 11 colsum, 12 adam */
+#define GH_PROFILE_ROWS 13
+int gh_profile_enable(int on);
+int gh_profile_collect(double* out_host, int rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GET_HIP_H */

@@ -1,0 +1,104 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/get_hip.h declares with the arity the Python binding assumes; the drop-in modules carry the
+reference's state_dict names/shapes; the install() shim resolves the reference's import paths."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "get_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    p = os.path.join(ROOT, "get_amd", "lib", "libget_hip.so")
+    if not os.path.exists(p):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "get_amd", "csrc"), "-j4"])
+    return p
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(gh_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args == "void" else len([a for a in args.split(",") if a.strip()])
+    return out
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    from get_amd import _lib
+    lib = ctypes.CDLL(lib_path)
+    decl = declared_functions()
+    assert len(decl) >= 20
+    for name, nargs in decl.items():
+        assert hasattr(lib, name), f"{name} declared in get_hip.h but not exported"
+        if name in _lib.SIGNATURES:
+            assert len(_lib.SIGNATURES[name]) == nargs, f"{name}: binding has {len(_lib.SIGNATURES[name])} args, header {nargs}"
+    for name in _lib.SIGNATURES:
+        assert name in decl, f"{name} bound in Python but not declared in get_hip.h"
+    lib.gh_abi_version.restype = ctypes.c_int
+    assert lib.gh_abi_version() == 1
+    _lib.load()
+
+
+def test_no_cpu_fallback_ops_refuse_cpu_tensors(lib_path):
+    from get_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.PackedAdj.from_dense(torch.zeros(1, 4, 4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.graph_build(torch.zeros(1, 4, dtype=torch.int32), torch.ones(1, dtype=torch.int32), 3)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "get_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_state_dict_contract_matches_reference(golden_dir):
+    from get_amd import modules
+    from get_amd.synth import make_embeddings
+    from oracle.cases_model import MODEL_CASES
+    cfg, seed = MODEL_CASES["small"]
+    emb, art, clm = make_embeddings(cfg, seed)
+    params = cfg.model_params(emb, art, clm)
+    model = modules.Graph_basedSemantiStructure(params)
+    assert params["embedding_input_dim"] == cfg.vocab and params["embedding_output_dim"] == cfg.emb_dim
+    contract = json.load(open(os.path.join(golden_dir, "state_dict_contract_small.json")))
+    sd = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert sd == contract
+    assert not model.embedding.weight.requires_grad and model.article_source_embs.weight.requires_grad
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/MasterFC"), reason="reference tree only exists in the build container")
+def test_install_shim_resolves_reference_import_paths():
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+from oracle import _refshim
+_refshim.install()
+import get_amd
+M = get_amd.install()
+from Models.FCWithEvidences import graph_based_semantic_structure      # as MasterFC/master_get.py:5 does
+from Models.BiDAF.wrapper import GGNN, GGNN_with_GSL, Linear
+from thirdparty.two_branches_attention import *
+assert graph_based_semantic_structure.Graph_basedSemantiStructure is M.Graph_basedSemantiStructure
+assert GGNN is M.GGNN and ConcatNotEqualSelfAtt is M.ConcatNotEqualSelfAtt
+import setting_keywords                                                  # the reference's own vocabulary
+from get_amd.keywords import KeyWordSettings as K
+for name in [n for n in dir(K) if not n.startswith('_') and isinstance(getattr(K, n), str)]:
+    assert getattr(setting_keywords.KeyWordSettings, name) == getattr(K, name), name
+print('ok')
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]

@@ -1,0 +1,147 @@
+"""GPU parity of the full drop-in model against the golden vectors
+captured from the reference (G7/G8) and against the CPU oracle.  Tolerances: logits 1e-4
+(north_star), attention weights / scorer outputs 1e-5, gradients 1e-3 relative."""
+import numpy as np
+import pytest
+import torch
+
+from get_amd.synth import make_embeddings, make_raw_batch, make_state_dict
+from oracle import get_oracle as O
+from oracle.assemble import assemble_inputs, reference_kargs
+from oracle.cases_model import MODEL_CASES
+from tests.util import check_grad, load
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build_model(cfg, seed):
+    from get_amd import modules
+    emb, art, clm = make_embeddings(cfg, seed)
+    model = modules.Graph_basedSemantiStructure(cfg.model_params(emb, art, clm))
+    full = model.state_dict()
+    full.update({k: torch.from_numpy(v) for k, v in make_state_dict(cfg, seed).items()})
+    model.load_state_dict(full, strict=True)
+    return model.to(DEV).train(False)
+
+
+def to_dev(kargs):
+    out = {}
+    for k, v in kargs.items():
+        if torch.is_tensor(v):
+            out[k] = v.to(DEV)
+        elif isinstance(v, tuple):
+            out[k] = tuple(t.to(DEV) if torch.is_tensor(t) else t for t in v)
+        else:
+            out[k] = v
+    return out
+
+
+def run_case(name, native_graphs=False, int32_inputs=False):
+    cfg, seed = MODEL_CASES[name]
+    model = build_model(cfg, seed)
+    raw = make_raw_batch(cfg, seed)
+    inp = assemble_inputs(raw, cfg, O.convert_text)
+    kargs = to_dev(reference_kargs(inp, torch, output_ranking=True))
+    query = torch.from_numpy(inp["query"]).to(DEV)
+    document = torch.from_numpy(inp["document"]).to(DEV)
+    if native_graphs:
+        from get_amd import ops
+        qa, q_ids, q_n = ops.graph_build(torch.from_numpy(raw["claim_tokens"]).to(DEV),
+                                         torch.from_numpy(raw["claim_len"]).to(DEV), cfg.window)
+        da, d_ids, d_n = ops.graph_build(torch.from_numpy(raw["evd_tokens"]).to(DEV),
+                                         torch.from_numpy(raw["evd_len"]).to(DEV), cfg.window)
+        assert np.array_equal(q_ids.cpu().numpy(), inp["query"]) and np.array_equal(d_ids.cpu().numpy(), inp["doc_ids"])
+        assert np.array_equal(q_n.cpu().numpy(), inp["query_lens"])
+        kargs["query_adj"], kargs["docs_adj"] = qa, da
+    if int32_inputs:       # the evaluation path hands int32 ids/lens (char_man_fitter_query_repr1.py:298-316)
+        query, document = query.int(), document.int()
+        for k in ("query_lens", "doc_content_without_padding_evidences", "doc_sources", "query_sources"):
+            kargs[k] = kargs[k].int()
+    phi, (ww, ew) = model(query, document, **kargs)
+    loss = torch.nn.functional.cross_entropy(phi, torch.from_numpy(inp["labels"]).to(DEV))
+    return cfg, model, inp, phi, ww, ew, loss
+
+
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+@pytest.mark.parametrize("native", [False, True])
+def test_model_vs_golden(name, native):
+    z, meta = load(f"g7_model_{name}.npz")
+    cfg, model, inp, phi, ww, ew, loss = run_case(name, native_graphs=native)
+    assert phi.shape == (cfg.batch, cfg.num_classes)
+    assert np.abs(phi.detach().cpu().numpy() - z["phi"]).max() <= 1e-4
+    assert np.abs(ww.detach().cpu().numpy() - z["word_w"]).max() <= 1e-5
+    assert np.abs(ew.detach().cpu().numpy() - z["evd_w"]).max() <= 1e-5
+    assert np.abs(model.ggnn_with_gsl.last_score.cpu().numpy() - z["score"]).max() <= 1e-5
+    assert abs(loss.item() - float(z["loss"])) <= 1e-5
+    loss.backward()
+    none = set(meta["none_grads"])
+    n_live = 0
+    for k, prm in model.named_parameters():
+        if k in none:
+            assert prm.grad is None, f"{k} must not receive a gradient"
+            continue
+        assert prm.grad is not None, k
+        check_grad(z, f"g::{k}", prm.grad.cpu().numpy(), what=f"{name} native={native} ")
+        n_live += prm.numel()
+    assert n_live == meta["n_live"]
+
+
+def test_model_eval_path_int32_and_predict():
+    z, _ = load("g7_model_small.npz")
+    cfg, model, inp, phi, ww, ew, loss = run_case("small", int32_inputs=True)
+    assert np.abs(phi.detach().cpu().numpy() - z["phi"]).max() <= 1e-4
+    assert np.allclose(ww.detach().sum(1).cpu().numpy(), 1.0, atol=1e-5)
+    # evidence slots beyond a claim's count get exactly zero weight
+    cnt = inp["evd_counts"]
+    e = ew.detach().cpu().numpy()
+    for b, c in enumerate(cnt):
+        assert np.all(e[b, c:] == 0) and abs(e[b, :c].sum(0) - 1).max() <= 1e-5
+
+
+def test_model_adam_step_matches_golden():
+    """G8: one Adam(lr=1e-4, weight_decay=1e-3) step through the flat bucket the DP wrapper uses."""
+    from get_amd.dist import FlatTrainer
+    z, meta = load("g7_model_small.npz")
+    cfg, seed = MODEL_CASES["small"]
+    model = build_model(cfg, seed)
+    trainer = FlatTrainer(model, lr=1e-4, weight_decay=1e-3)
+    raw = make_raw_batch(cfg, seed)
+    inp = assemble_inputs(raw, cfg, O.convert_text)
+    kargs = to_dev(reference_kargs(inp, torch))
+    trainer.zero_grad()
+    phi = model(torch.from_numpy(inp["query"]).to(DEV), torch.from_numpy(inp["document"]).to(DEV), **kargs)
+    torch.nn.functional.cross_entropy(phi, torch.from_numpy(inp["labels"]).to(DEV)).backward()
+    trainer.step()
+    none = set(meta["none_grads"])
+    for k, prm in model.named_parameters():
+        if not prm.requires_grad:
+            continue
+        exp = z[f"adam::{k}"]
+        assert np.abs(prm.detach().cpu().numpy() - exp).max() <= 2e-6, k
+        if k in none:
+            assert k not in trainer.live_names
+
+
+def test_bench_shape_forward_backward_properties():
+    """BASELINE config 2 at full size (B=32, 30 evidences, R=100, H=300): size-independent properties."""
+    from bench import build_workload
+    wl = build_workload(batch=32, n_evd=30, seed=20240229, device=DEV)
+    model = wl["model"].train(False)
+    phi, (ww, ew) = model(wl["query"], wl["document"], **dict(wl["kargs"], output_ranking=True))
+    assert phi.shape == (32, 2) and torch.isfinite(phi).all()
+    assert ww.shape == (960, 100, 5) and ew.shape == (32, 30, 2)
+    assert torch.allclose(ww.sum(1), torch.ones(960, 5, device=DEV), atol=1e-5)
+    assert torch.allclose(ew.sum(1), torch.ones(32, 2, device=DEV), atol=1e-5)
+    # padded evidence-graph nodes get zero word attention
+    pad = wl["kargs"]["doc_content_without_padding_evidences"] < 1
+    assert float(ww[pad].abs().max()) == 0.0
+    loss = torch.nn.functional.cross_entropy(phi, wl["labels"])
+    loss.backward()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), k
+    # a 4-claim slice of the same batch agrees with the oracle on the CPU (logits 1e-4)
+    sub = wl["oracle_slice"](4)
+    phi_o = sub["phi"]
+    assert float((phi[:4].detach().cpu() - phi_o).abs().max()) <= 1e-4

@@ -1,0 +1,347 @@
+"""GPU parity tests of the individual hot-path ops: HIP (through the C-ABI) vs the CPU oracle and
+vs the golden vectors captured from the reference.  Bit-exact for ids/bits/keep-sets, fp32
+tolerances (stated per test) for floating point.  Run with ``-m gpu`` on an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases
+from oracle import get_oracle as O
+from tests.util import check_grad, dense_from_coo, load
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def T(a, grad=False, dev=DEV):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t.requires_grad_(True) if grad else t
+
+
+def bits_to_bool(bits: torch.Tensor, r: int) -> np.ndarray:
+    """(..., W) int64 words -> (..., r) bool."""
+    b = bits.cpu().numpy().view(np.uint64)
+    out = np.zeros(b.shape[:-1] + (r,), dtype=bool)
+    for j in range(r):
+        out[..., j] = (b[..., j // 64] >> np.uint64(j % 64)) & np.uint64(1)
+    return out
+
+
+def maxerr(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+# ---------------------------------------------------------------- a1 graph build
+def test_graph_build_matches_golden_bit_exact():
+    from get_amd import ops
+    z, meta = load("g1_convert_text.npz")
+    by_shape = {}
+    for i, m in enumerate(meta):
+        by_shape.setdefault((m["fixed_length"], m["window"]), []).append(i)
+    for (fl, win), idxs in by_shape.items():
+        toks = np.stack([z[f"c{i}_tokens"] for i in idxs]).astype(np.int32)
+        lens = np.array([meta[i]["length"] for i in idxs], np.int32)
+        adj, node_ids, n_nodes = ops.graph_build(T(toks), T(lens), win)
+        dense = adj.to_dense().cpu().numpy()
+        nbits = bits_to_bool(adj.bits, fl)
+        for k, i in enumerate(idxs):
+            assert int(n_nodes[k]) == meta[i]["n_nodes"], (fl, win, i)
+            assert np.array_equal(node_ids[k].cpu().numpy(), z[f"c{i}_words"]), (fl, win, i)
+            exp = dense_from_coo(z, i, fl)
+            assert np.array_equal(nbits[k], exp != 0), (fl, win, i)
+            assert maxerr(dense[k], exp) <= 2e-7, (fl, win, i)          # fp32 product of two fp32 dinv
+
+
+def test_graph_build_empty_and_full_edge_cases():
+    from get_amd import ops
+    toks = np.zeros((3, 100), np.int32)
+    toks[1, :] = 7                      # one node, full length
+    toks[2, :100] = np.arange(100) + 2  # all distinct
+    lens = np.array([0, 100, 100], np.int32)
+    adj, ids, n = ops.graph_build(T(toks), T(lens), 3)
+    assert n.cpu().tolist() == [0, 1, 100]
+    d = adj.to_dense().cpu().numpy()
+    assert not d[0].any()
+    assert d[1, 0, 0] == 1.0 and d[1].sum() == 1.0
+    for k in range(3):
+        _, exp, _ = O.convert_text(toks[k].tolist(), 100, int(lens[k]), 3)
+        assert maxerr(d[k], exp) <= 2e-7
+
+
+def test_adj_pack_unpack_roundtrip():
+    from get_amd.ops import PackedAdj
+    rng = np.random.default_rng(5)
+    for r in (30, 100, 200):
+        a = rng.standard_normal((3, r, r)) * (rng.random((3, r, r)) < 0.1)
+        for dt in (np.float64, np.float32):
+            p = PackedAdj.from_dense(T(a.astype(dt)))
+            back = p.to_dense().cpu().numpy()
+            assert np.array_equal(back, a.astype(dt).astype(np.float32))
+            assert np.array_equal(bits_to_bool(p.bits, r), a != 0)
+
+
+# ---------------------------------------------------------------- aggregation
+@pytest.mark.parametrize("r,h", [(100, 300), (30, 300), (200, 64), (100, 1), (100, 30), (100, 768)])
+def test_spmm_modes(r, h):
+    from get_amd import ops
+    rng = np.random.default_rng(r * 1000 + h)
+    toks, lens, ids, adj = cases.graphs(rng, 4, r, 3, O.convert_text)
+    x = rng.standard_normal((4, r, h)).astype(np.float32)
+    ref = torch.from_numpy(adj).float() @ torch.from_numpy(x)
+    # normalised mode (native graph build)
+    padj, _, _ = ops.graph_build(T(toks), T(lens), 3)
+    y = ops.spmm(padj, T(x)).cpu()
+    assert maxerr(y, ref) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    # weighted mode (dense hand-over), incl. a non-symmetric adjacency and its transpose in backward
+    a2 = adj * (1.0 + 0.1 * rng.standard_normal(adj.shape))
+    pw = ops.PackedAdj.from_dense(T(a2))
+    xt = T(x, grad=True)
+    y2 = ops.spmm(pw, xt)
+    ref2 = torch.from_numpy(a2).float() @ torch.from_numpy(x)
+    assert maxerr(y2.detach().cpu(), ref2) <= 2e-6 * max(1.0, float(ref2.abs().max()))
+    g = rng.standard_normal((4, r, h)).astype(np.float32)
+    (y2 * T(g)).sum().backward()
+    refg = torch.from_numpy(a2).float().transpose(1, 2) @ torch.from_numpy(g)
+    assert maxerr(xt.grad.cpu(), refg) <= 2e-6 * max(1.0, float(refg.abs().max()))
+    # keep-set refinement == dense mask of wrapper.py:221-225
+    keep = rng.random((4, r)) < 0.5
+    kw = np.zeros((4, (r + 63) // 64), np.uint64)
+    for j in range(r):
+        kw[:, j // 64] |= keep[:, j].astype(np.uint64) << np.uint64(j % 64)
+    pk = padj.with_keep(T(kw.view(np.int64)))
+    y3 = ops.spmm(pk, T(x)).cpu()
+    mask = (keep[:, :, None] | keep[:, None, :])
+    ref3 = (torch.from_numpy(adj * mask).float()) @ torch.from_numpy(x)
+    assert maxerr(y3, ref3) <= 2e-6 * max(1.0, float(ref3.abs().max()))
+    assert maxerr(pk.to_dense().cpu(), (adj * mask).astype(np.float32)) <= 2e-7
+
+
+# ---------------------------------------------------------------- a2 GGNN cell (G2)
+def _load_cell(mod, p, prefix=""):
+    sd = {k[len(prefix):]: torch.from_numpy(v) for k, v in p.items() if k.startswith(prefix)}
+    mod.load_state_dict(sd, strict=True)
+
+
+@pytest.mark.parametrize("ci", range(len(cases.G2_CASES)))
+@pytest.mark.parametrize("mode", ["dense", "native"])
+def test_ggnn_cell_vs_golden_and_oracle(ci, mode):
+    from get_amd import modules, ops
+    z, meta = load("g2_ggnn.npz")
+    n, r, din, dout, window = cases.G2_CASES[ci]
+    c = cases.g2_inputs(ci, O.convert_text)
+    mod = modules.GGNN(din, dout, dropout=0.2)
+    _load_cell(mod, c["p"])
+    mod = mod.to(DEV).train(False)
+    x = T(c["x"], grad=True)
+    if mode == "dense":
+        adj = T(c["adj"])                     # float64 dense, as the reference pipeline hands it over
+    else:
+        adj, _, _ = ops.graph_build(T(c["toks"]), T(c["lens"]), window)
+    out = mod(adj, x)
+    assert out.shape == (n, r, dout)
+    assert maxerr(out.detach().cpu(), z[f"c{ci}_out"]) <= 2e-5
+    (out * T(c["gw"])).sum().backward()
+    check_grad(z, f"c{ci}_dx", x.grad.cpu().numpy(), what=f"{mode} ")
+    for name, prm in mod.named_parameters():
+        check_grad(z, f"c{ci}_g::{name}", prm.grad.cpu().numpy(), what=f"{mode} ")
+    # full-tensor comparison against the oracle's gradients as well
+    p = {k: torch.from_numpy(v).requires_grad_(True) for k, v in c["p"].items()}
+    xo = torch.from_numpy(c["x"]).requires_grad_(True)
+    oo = O.ggnn_cell(torch.from_numpy(c["adj"]).float(), xo, p)
+    (oo * torch.from_numpy(c["gw"])).sum().backward()
+    assert maxerr(x.grad.cpu(), xo.grad) <= 1e-3 * float(xo.grad.abs().max()) + 1e-6
+    for name, prm in mod.named_parameters():
+        go = p[name].grad
+        assert maxerr(prm.grad.cpu(), go) <= 1e-3 * float(go.abs().max()) + 1e-5, name
+
+
+def test_ggnn_cell_fused_embedding_gather():
+    from get_amd import modules, ops
+    rng = np.random.default_rng(77)
+    n, r, d, h = 5, 30, 48, 64
+    toks, lens, ids, adj = cases.graphs(rng, n, r, 3, O.convert_text, vocab=50)
+    emb = rng.standard_normal((50, d)).astype(np.float32)
+    p = cases.cell_params(rng, d, h)
+    mod = modules.GGNN(d, h)
+    _load_cell(mod, p)
+    mod = mod.to(DEV).train(False)
+    e = torch.nn.Embedding.from_pretrained(torch.from_numpy(emb), freeze=False).to(DEV)
+    padj, node_ids, _ = ops.graph_build(T(toks), T(lens), 3)
+    assert np.array_equal(node_ids.cpu().numpy(), ids)
+    out = mod.forward_ids(padj, e, node_ids)
+    po = {k: torch.from_numpy(v) for k, v in p.items()}
+    embo = torch.from_numpy(emb).requires_grad_(True)
+    oo = O.ggnn_cell(torch.from_numpy(adj).float(), embo[torch.from_numpy(ids)], po)
+    assert maxerr(out.detach().cpu(), oo.detach()) <= 2e-5
+    gw = torch.from_numpy(rng.standard_normal((n, r, h)).astype(np.float32))
+    (out * gw.to(DEV)).sum().backward()
+    (oo * gw).sum().backward()
+    assert maxerr(e.weight.grad.cpu(), embo.grad) <= 1e-3 * float(embo.grad.abs().max()) + 1e-6
+
+
+# ---------------------------------------------------------------- a3 GSL (G3)
+def test_gsl_keep_sets_golden():
+    from get_amd import modules
+    z, meta = load("g3_gsl.npz")
+    for ci, m in enumerate(meta):
+        r = m["r"]
+        score = T(z[f"c{ci}_score"])
+        exp_mask = np.unpackbits(z[f"c{ci}_mask"], axis=-1)[..., :r].astype(bool)
+        out = modules.GSL(m["rate"])(torch.ones(m["b"], r, r, device=DEV), score).cpu().numpy()
+        got_mask = out != 0
+        kept = got_mask.all(-1)
+        assert kept.sum(-1).tolist() == [m["k"]] * m["b"], ci
+        # identical to the oracle's convention (ties -> lower index), bit for bit
+        _, keep_o = O.gsl_refine(torch.ones(m["b"], r, r), torch.from_numpy(z[f"c{ci}_score"]), m["rate"])
+        assert np.array_equal(kept, keep_o.numpy()), ci
+        if not m["ties"]:
+            assert np.array_equal(got_mask, exp_mask), ci            # and to the reference where it is defined
+    out = modules.GSL(0.5)(torch.ones(1, 4, 4, device=DEV), torch.tensor([[[.9], [.1], [.8], [.2]]], device=DEV))
+    assert np.array_equal(out.cpu().numpy(), z["known_out"])
+
+
+# ---------------------------------------------------------------- a4 GGNN_with_GSL (G4)
+@pytest.mark.parametrize("ci", range(len(cases.G4_CASES)))
+def test_ggnn_with_gsl_vs_golden(ci):
+    from get_amd import modules
+    z, meta = load("g4_ggnn_gsl.npz")
+    m = meta[ci]
+    n, r, d, h, window, rate = cases.G4_CASES[ci]
+    c = cases.g4_inputs(ci, O.convert_text)
+    mod = modules.GGNN_with_GSL(d, h, h, rate=rate, dropout=0.2)
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in c["p"].items()}, strict=True)
+    mod = mod.to(DEV).train(False)
+    x = T(c["x"], grad=True)
+    out = mod(T(c["adj"]), x)
+    assert maxerr(mod.last_score.cpu(), z[f"c{ci}_score"]) <= 1e-5
+    # keep-set: must reproduce the reference's refined adjacency pattern on real (non-padding) nodes
+    exp_nz = np.unpackbits(z[f"c{ci}_adjr_nz"], axis=-1)[..., :r].astype(bool)
+    keep = bits_to_bool(mod.last_keep, r)
+    nz = (c["adj"] != 0) & (keep[:, :, None] | keep[:, None, :])
+    assert np.array_equal(nz, exp_nz)
+    assert maxerr(out.detach().cpu(), z[f"c{ci}_out"]) <= 2e-5
+    (out * T(c["gw"])).sum().backward()
+    check_grad(z, f"c{ci}_dx", x.grad.cpu().numpy())
+    for name, prm in mod.named_parameters():
+        if name in m["none_grads"]:
+            assert prm.grad is None, name                          # no gradient through GSL (wrapper.py:219)
+        else:
+            check_grad(z, f"c{ci}_g::{name}", prm.grad.cpu().numpy())
+
+
+# ---------------------------------------------------------------- a5/a6 attention (G5, G6)
+@pytest.mark.parametrize("ci", range(len(cases.G5_CASES)))
+def test_concat_att_vs_golden(ci):
+    from get_amd import modules
+    z, meta = load("g5_concat_att.npz")
+    b, l, xl, dr, ha, heads, mkind = cases.G5_CASES[ci]
+    c = cases.g5_inputs(ci)
+    mod = modules.ConcatNotEqualSelfAtt(inp_dim=xl + dr, out_dim=ha, num_heads=heads)
+    mod.load_state_dict({"linear1.weight": torch.from_numpy(c["w1"]), "linear2.weight": torch.from_numpy(c["w2"])})
+    mod = mod.to(DEV)
+    left, right = T(c["left"], True), T(c["right"], True)
+    mask = T(c["mask"]) if mkind == "bool" else T(c["mask"].astype(np.float32))
+    att, w = mod(left, right, mask)
+    assert att.shape == (b, dr, heads) and w.shape == (b, l, heads)
+    assert maxerr(att.detach().cpu(), z[f"c{ci}_att"]) <= 1e-5
+    assert maxerr(w.detach().cpu(), z[f"c{ci}_w"]) <= 1e-6
+    assert np.allclose(w.detach().sum(1).cpu().numpy(), 1.0, atol=1e-5)      # fitter's own self-check (:433,448)
+    ((att * T(c["g_att"])).sum() + (w * T(c["g_w"])).sum()).backward()
+    check_grad(z, f"c{ci}_dleft", left.grad.cpu().numpy())
+    check_grad(z, f"c{ci}_dright", right.grad.cpu().numpy())
+    check_grad(z, f"c{ci}_g::linear1.weight", mod.linear1.weight.grad.cpu().numpy())
+    check_grad(z, f"c{ci}_g::linear2.weight", mod.linear2.weight.grad.cpu().numpy())
+
+
+@pytest.mark.parametrize("ci", range(len(cases.G6_CASES)))
+def test_self_att_extend_vs_golden(ci):
+    from get_amd import modules
+    z, meta = load("g6_self_att.npz")
+    b, l, d, ha, heads = cases.G6_CASES[ci]
+    c = cases.g6_inputs(ci)
+    mod = modules.MultiHeadSelfAttentionICLR2017Extend(inp_dim=d, out_dim=ha, num_heads=heads)
+    mod.load_state_dict({"linear1.weight": torch.from_numpy(c["w1"]), "linear2.weight": torch.from_numpy(c["w2"])})
+    mod = mod.to(DEV)
+    att, w = mod(T(c["tsr"]), T(c["mask"]), return_att_weights=True)
+    assert att.shape == (b, heads, d)
+    assert maxerr(att.detach().cpu(), z[f"c{ci}_att"]) <= 1e-5
+    assert maxerr(w.detach().cpu(), z[f"c{ci}_w"]) <= 1e-6
+
+
+# ---------------------------------------------------------------- linear / ragged helpers / Adam
+@pytest.mark.parametrize("m,k,n", [(32, 3556, 300), (32, 300, 2), (960, 300, 300), (7, 20, 5), (2048, 64, 48)])
+def test_linear_fwd_bwd(m, k, n):
+    from get_amd import ops
+    rng = np.random.default_rng(m + k + n)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal((n,)).astype(np.float32)
+    g = rng.standard_normal((m, n)).astype(np.float32)
+    xt, wt, bt = T(x, True), T(w, True), T(b, True)
+    y = ops.linear(xt, wt, bt)
+    (y * T(g)).sum().backward()
+    xo, wo, bo = (torch.from_numpy(a).double().requires_grad_(True) for a in (x, w, b))
+    yo = xo @ wo.t() + bo
+    (yo * torch.from_numpy(g).double()).sum().backward()
+    assert maxerr(y.detach().cpu(), yo.detach()) <= 2e-5 * max(1.0, float(yo.abs().max()))
+    for got, exp in ((xt.grad, xo.grad), (wt.grad, wo.grad), (bt.grad, bo.grad)):
+        assert maxerr(got.cpu(), exp) <= 1e-4 * float(exp.abs().max()) + 1e-6
+
+
+def test_segment_helpers_and_masked_mean():
+    from get_amd import ops
+    rng = np.random.default_rng(3)
+    counts = [1, 30, 7, 12, 3]
+    b1, x = sum(counts), 44
+    seg = ops.Segments(torch.tensor(counts, device=DEV), b1, 30)
+    assert seg.offsets.cpu().tolist() == np.concatenate([[0], np.cumsum(counts)]).tolist()
+    src = rng.standard_normal((len(counts), x)).astype(np.float32)
+    st = T(src, True)
+    out = ops.seg_broadcast(st, seg)
+    ref = O.pad_left(torch.from_numpy(src), counts)
+    assert np.array_equal(out.detach().cpu().numpy(), ref.numpy())
+    g = rng.standard_normal((b1, x)).astype(np.float32)
+    (out * T(g)).sum().backward()
+    so = torch.from_numpy(src).requires_grad_(True)
+    (O.pad_left(so, counts) * torch.from_numpy(g)).sum().backward()
+    assert maxerr(st.grad.cpu(), so.grad) <= 1e-5
+    pairs = rng.standard_normal((b1, x)).astype(np.float32)
+    pt = T(pairs, True)
+    padded = ops.seg_pad(pt, seg)
+    refp = O.pad_right(torch.from_numpy(pairs), counts, 30)
+    assert np.array_equal(padded.detach().cpu().numpy(), refp.numpy())
+    g2 = rng.standard_normal((len(counts), 30, x)).astype(np.float32)
+    (padded * T(g2)).sum().backward()
+    po = torch.from_numpy(pairs).requires_grad_(True)
+    (O.pad_right(po, counts, 30) * torch.from_numpy(g2)).sum().backward()
+    assert np.array_equal(pt.grad.cpu().numpy(), po.grad.numpy())
+    # masked mean
+    hid = rng.standard_normal((4, 30, 52)).astype(np.float32)
+    ids = (rng.random((4, 30)) < 0.6).astype(np.int64) * 5
+    lens = np.maximum(ids.astype(bool).sum(1), 1)
+    ht = T(hid, True)
+    mm = ops.masked_mean(ht, T(ids), T(lens))
+    ho = torch.from_numpy(hid).requires_grad_(True)
+    mo = (ho * torch.from_numpy(ids > 0).float()[:, :, None]).sum(1) / torch.from_numpy(lens).float()[:, None]
+    assert maxerr(mm.detach().cpu(), mo.detach()) <= 1e-5
+    gm = rng.standard_normal((4, 52)).astype(np.float32)
+    (mm * T(gm)).sum().backward()
+    (mo * torch.from_numpy(gm)).sum().backward()
+    assert maxerr(ht.grad.cpu(), ho.grad) <= 1e-6
+
+
+def test_adam_flat_matches_torch():
+    from get_amd import ops
+    rng = np.random.default_rng(9)
+    n = 10007
+    p0 = rng.standard_normal(n).astype(np.float32)
+    ref = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([ref], lr=1e-4, weight_decay=1e-3)
+    p, m, v = T(p0.copy()), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        g = rng.standard_normal(n).astype(np.float32)
+        ref.grad = torch.from_numpy(g.copy())
+        opt.step()
+        ops.adam_step_flat(p, T(g), m, v, step, lr=1e-4, weight_decay=1e-3)
+        assert maxerr(p.cpu(), ref.detach()) <= 2e-7, step
