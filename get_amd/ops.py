@@ -5,6 +5,7 @@ step runs in libget_hip.so.  All tensors are fp32/contiguous on a ROCm device.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -30,18 +31,22 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
 
 
 def transposed(w: torch.Tensor) -> torch.Tensor:
-    """W[n_out][n_in] -> Wt[n_in][n_out]; cached per (storage, version, epoch)."""
-    w = w.detach()
-    key = (w.data_ptr(), tuple(w.shape), w._version, _WEIGHT_EPOCH)
+    """W[n_out][n_in] -> Wt[n_in][n_out], cached per parameter OBJECT (weak reference), storage
+    address, in-place version and weight epoch -- never by address alone, which the caching
+    allocator recycles."""
+    key = id(w)
     hit = _WT_CACHE.get(key)
     if hit is not None:
-        return hit
-    wc = _f32(w)
+        ref, dptr, ver, epoch, wt = hit
+        if ref() is w and dptr == w.data_ptr() and ver == w._version and epoch == _WEIGHT_EPOCH:
+            return wt
+    wc = _f32(w.detach())
     wt = torch.empty((wc.shape[1], wc.shape[0]), device=w.device, dtype=torch.float32)
     call("gh_transpose", ptr(wc), ptr(wt), wc.shape[0], wc.shape[1], stream())
-    if len(_WT_CACHE) > 256:
-        _WT_CACHE.clear()
-    _WT_CACHE[key] = wt
+    if len(_WT_CACHE) > 512:
+        for k in [k for k, v in _WT_CACHE.items() if v[0]() is None]:
+            del _WT_CACHE[k]
+    _WT_CACHE[key] = (weakref.ref(w), w.data_ptr(), w._version, _WEIGHT_EPOCH, wt)
     return wt
 
 

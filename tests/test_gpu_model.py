@@ -109,18 +109,20 @@ def test_model_adam_step_matches_golden():
     raw = make_raw_batch(cfg, seed)
     inp = assemble_inputs(raw, cfg, O.convert_text)
     kargs = to_dev(reference_kargs(inp, torch))
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
     trainer.zero_grad()
     phi = model(torch.from_numpy(inp["query"]).to(DEV), torch.from_numpy(inp["document"]).to(DEV), **kargs)
     torch.nn.functional.cross_entropy(phi, torch.from_numpy(inp["labels"]).to(DEV)).backward()
     trainer.step()
     none = set(meta["none_grads"])
     for k, prm in model.named_parameters():
-        if not prm.requires_grad:
+        if k in none:
+            # grad-None parameters are skipped by the reference's Adam (no weight decay either);
+            # their values are module-specific random init, so the check is "unchanged"
+            assert k not in trainer.live_names and torch.equal(prm.detach(), before[k]), k
             continue
         exp = z[f"adam::{k}"]
         assert np.abs(prm.detach().cpu().numpy() - exp).max() <= 2e-6, k
-        if k in none:
-            assert k not in trainer.live_names
 
 
 def test_bench_shape_forward_backward_properties():
@@ -135,7 +137,7 @@ def test_bench_shape_forward_backward_properties():
     assert torch.allclose(ew.sum(1), torch.ones(32, 2, device=DEV), atol=1e-5)
     # padded evidence-graph nodes get zero word attention
     pad = wl["kargs"]["doc_content_without_padding_evidences"] < 1
-    assert float(ww[pad].abs().max()) == 0.0
+    assert float(ww.detach()[pad].abs().max()) == 0.0
     loss = torch.nn.functional.cross_entropy(phi, wl["labels"])
     loss.backward()
     for k, p in model.named_parameters():
