@@ -42,6 +42,7 @@ SIGNATURES = {
     "gh_masked_mean_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "gh_masked_mean_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "gh_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
+    "gh_set_workspace": [_P, _L],
     "gh_profile_enable": [_I],
     "gh_profile_collect": [_P, _I],
 }
@@ -85,6 +86,18 @@ def load():
         raise RuntimeError(f"get_amd: ABI version mismatch ({lib.gh_abi_version()} != 1)")
     _lib = lib
     return lib
+
+
+_workspace = None
+
+
+def ensure_workspace(device, nbytes: int = 256 << 20):
+    """Register (once per process) the split-K scratch buffer of the weight-gradient GEMMs."""
+    global _workspace
+    if _workspace is None or _workspace.device != torch.device(device) or _workspace.numel() * 4 < nbytes:
+        _workspace = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+        call("gh_set_workspace", _workspace.data_ptr(), _workspace.numel() * 4)
+    return _workspace
 
 
 def ptr(t):

@@ -49,6 +49,7 @@ struct Problem {
   float* out1;
   const float* in0; const float* in1;   // same leading dimension as C
   const float* u; const float* w2; float* e; int ldu; int R; int heads;
+  long long split_stride;   // TN: element offset of K-chunk `ks`'s partial tile (0 = all chunks hit C, atomically)
 };
 
 #define GH_MAX_PROBLEMS 8
@@ -255,6 +256,7 @@ gemm_kernel(const Launch L_byval) {
   // -------------------------------------------------------------------- epilogue
   const int epi = P.epi;
   const int ldc = P.ldc;
+  float* const Cout = P.C + (TN ? (size_t)ks * (size_t)P.split_stride : (size_t)0);
   if (epi == EPI_ATT) {
     // row-wise head scores need every column of the row: reduce over this lane's tiles, the 16
     // lanes of the row, and (WN > 1) the waves along N through LDS.
@@ -328,23 +330,23 @@ gemm_kernel(const Launch L_byval) {
           const size_t o = (size_t)row * ldc + col;
           const float v = acc[mi][ni][reg] + bias;
           if (epi == EPI_STORE) {
-            P.C[o] = P.accumulate ? P.C[o] + v : v;
+            Cout[o] = P.accumulate ? Cout[o] + v : v;
           } else if (epi == EPI_SIGMOID_Z) {
-            P.C[o] = sigmoidf_(v);
+            Cout[o] = sigmoidf_(v);
           } else if (epi == EPI_SIGMOID_R) {
             const float r = sigmoidf_(v);
-            P.C[o] = r;
+            Cout[o] = r;
             P.out1[o] = r * P.in0[o];
           } else if (epi == EPI_TANH_H) {
             const float h = tanhf_(v), z = P.in0[o], xp = P.in1[o];
-            P.C[o] = h;
+            Cout[o] = h;
             P.out1[o] = h * z + xp * (1.f - z);
           } else if (epi == EPI_BWD_DRX) {
             const float xp = P.in0[o], r = P.in1[o];
-            P.C[o] = v * xp * r * (1.f - r);
+            Cout[o] = v * xp * r * (1.f - r);
             P.out1[o] += v * r;
           } else if (epi == EPI_ATOMIC) {
-            atomicAdd(P.C + o, v);
+            atomicAdd(Cout + o, v);
           }
         }
       }

@@ -1,0 +1,352 @@
+// Fast path of the grouped fp32 MFMA GEMM (same problem descriptors as gemm.hip.h).
+//
+// Preconditions (checked by the host, otherwise the generic kernel in gemm.hip.h runs):
+//   every operand row is 16-byte aligned and its inner extent a multiple of 4 floats (float4
+//   loads/stores everywhere), no row gather on the k-rows of B.
+// What differs from the generic kernel:
+//   * all addressing is hoisted out of the K loop: per-thread 32-bit element offsets, row validity
+//     and (NT mode) the embedding-gather row ids are computed once; a K tile is NA+NB unconditional
+//     global_load_dwordx4 from clamped addresses followed by selects -- no branches, no descriptor
+//     re-loads, no dependent loads inside the loop, so the next tile's loads fly under the MFMAs;
+//   * the MFMA operands are swapped (acc = mfma(b, a)), so a lane owns 4 CONSECUTIVE COLUMNS of one
+//     output row: every epilogue access (bias, gate inputs, outputs) is one 16-byte vector op.
+#pragma once
+#include "gemm.hip.h"
+
+namespace gh {
+
+template <int WM, int WN, int NI, bool TN>
+__global__ void __launch_bounds__(WM * WN * 64, 2)
+gemm_fast_kernel(const Launch L_byval) {
+  (void)L_byval;
+  const GH_KARG Launch& L = *(const GH_KARG Launch*)__builtin_amdgcn_kernarg_segment_ptr();
+  constexpr int NTHR = WM * WN * 64;
+  constexpr int BM = 32 * WM, BN = 16 * NI * WN, BK = 16;
+  constexpr int LDA = BM + 2, LDB = BN + 2;
+  constexpr int A4 = BM * 4, B4 = BK * (BN / 4);
+  constexpr int NA = (A4 + NTHR - 1) / NTHR, NB = (B4 + NTHR - 1) / NTHR;
+  __shared__ float smem[2 * BK * LDA + 2 * BK * LDB];
+  float* As = smem;
+  float* Bs = smem + 2 * BK * LDA;
+
+  const int n_inner = TN ? L.m_tiles * L.nprob : L.nprob;
+  const int n_outer = TN ? L.ksplit : L.m_tiles;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int outer = xcd + 8 * (slot / n_inner);
+  const int inner = slot % n_inner;
+  if (outer >= n_outer) return;
+  const int prob = TN ? inner % L.nprob : inner;
+  const int m_tile = TN ? inner / L.nprob : outer;
+  const GH_KARG Problem& P = L.p[prob];
+  const int M = P.M, N = P.N;
+  const int m0 = m_tile * BM;
+  if (m0 >= M) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int wrow = wm * 32, wcol = wn * 16 * NI;
+  const int l15 = lane & 15, q = lane >> 4;
+
+  // ---- loop-invariant operand description, copied to registers once
+  const int nseg = TN ? 1 : P.nseg;
+  const float* A0 = P.seg[0].A; const float* B0 = P.seg[0].B;
+  const int lda0 = P.seg[0].lda, ldb0 = P.seg[0].ldb, K0 = P.seg[0].K;
+  const float* A1 = nseg > 1 ? P.seg[1].A : A0; const float* B1 = nseg > 1 ? P.seg[1].B : B0;
+  const int lda1 = nseg > 1 ? P.seg[1].lda : lda0, ldb1 = nseg > 1 ? P.seg[1].ldb : ldb0;
+  const int K1 = nseg > 1 ? P.seg[1].K : 0;
+
+  int kbeg = 0, kend = K0;
+  if (TN) {
+    kbeg = (int)outer * L.kchunk;
+    kend = min(K0, kbeg + L.kchunk);
+    if (kbeg >= kend) return;
+  }
+  const int nt0 = TN ? (kend - kbeg + BK - 1) / BK : (K0 + BK - 1) / BK;
+  const int T = nt0 + (nseg > 1 ? (K1 + BK - 1) / BK : 0);
+
+  // per-thread A slots
+  unsigned a_off0[NA], a_off1[NA];
+  bool a_ok[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int idx = tid + j * NTHR;
+    if (!TN) {
+      const int row = idx >> 2, gm = m0 + row;
+      a_ok[j] = (idx < A4) && (gm < M);
+      const int gmc = min(gm, M - 1);
+      int s0 = gmc, s1 = gmc;
+      if (P.seg[0].gatherA) s0 = P.seg[0].gatherA[gmc];          // embedding row id, read once per row
+      if (nseg > 1 && P.seg[1].gatherA) s1 = P.seg[1].gatherA[gmc];
+      a_off0[j] = (unsigned)s0 * (unsigned)lda0;
+      a_off1[j] = (unsigned)s1 * (unsigned)lda1;
+    } else {
+      const int c = m0 + 4 * (idx % (BM / 4));
+      a_ok[j] = (idx < A4) && (c < M);
+      a_off0[j] = (unsigned)min(c, M - 4);      // column offset; the k-row term is added per tile
+      a_off1[j] = 0;
+    }
+  }
+  // per-thread B slots: column offset and validity (row term added per tile)
+  unsigned b_col[NB];
+  bool b_ok[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int idx = tid + j * NTHR;
+    const int c = 4 * (idx % (BN / 4));
+    b_ok[j] = (idx < B4) && (c < N);
+    b_col[j] = (unsigned)min(c, N - 4);
+  }
+
+  f32x4 acc[2][NI];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int mi_cnt = min(2, (M - m0 - wrow + 15) / 16);
+  const int ni_cnt = min(NI, (N - wcol + 15) / 16);
+  const bool full = (mi_cnt == 2) && (ni_cnt == NI);
+
+  float4 ra[NA], rb[NB];
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // Tile addressing shared by the load (issue) and store (mask + LDS write) halves.
+  struct TileAddr { const float* Ab; const float* Bb; int ldb, k0, klim; bool s1; };
+  auto tile_addr = [&](int t) __attribute__((always_inline)) {
+    TileAddr a;
+    a.s1 = (!TN) && (t >= nt0);
+    a.Ab = a.s1 ? A1 : A0;
+    a.Bb = a.s1 ? B1 : B0;
+    a.ldb = a.s1 ? ldb1 : ldb0;
+    a.k0 = TN ? (kbeg + t * BK) : ((a.s1 ? t - nt0 : t) * BK);
+    a.klim = TN ? kend : (a.s1 ? K1 : K0);
+    return a;
+  };
+
+  // issue only: raw 16-byte loads from clamped (always legal) addresses; nothing consumes them here,
+  // so they stay in flight under the MFMAs of the current tile
+  auto load_tile = [&](int t) __attribute__((always_inline)) {
+    const TileAddr a = tile_addr(t);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int idx = tid + j * NTHR;
+      unsigned off;
+      if (!TN) off = (a.s1 ? a_off1[j] : a_off0[j]) + (unsigned)min(a.k0 + 4 * (idx & 3), a.klim - 4);
+      else off = (unsigned)min(a.k0 + idx / (BM / 4), a.klim - 1) * (unsigned)lda0 + a_off0[j];
+      ra[j] = *reinterpret_cast<const float4*>(a.Ab + off);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int idx = tid + j * NTHR;
+      const unsigned off = (unsigned)min(a.k0 + idx / (BN / 4), a.klim - 1) * (unsigned)a.ldb + b_col[j];
+      rb[j] = *reinterpret_cast<const float4*>(a.Bb + off);
+    }
+  };
+
+  // mask out-of-range rows/columns/k (select, no branch) and write the k-major LDS image
+  auto store_tile = [&](int buf, int t) __attribute__((always_inline)) {
+    const TileAddr a = tile_addr(t);
+    float* as = As + buf * BK * LDA;
+    float* bs = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int idx = tid + j * NTHR;
+      if (idx < A4) {
+        if (!TN) {
+          const int row = idx >> 2, kq = idx & 3;
+          const bool ok = a_ok[j] && (a.k0 + 4 * kq < a.klim);
+          const float4 v = ok ? ra[j] : zero4;
+          as[(4 * kq + 0) * LDA + row] = v.x;
+          as[(4 * kq + 1) * LDA + row] = v.y;
+          as[(4 * kq + 2) * LDA + row] = v.z;
+          as[(4 * kq + 3) * LDA + row] = v.w;
+        } else {
+          const int krow = idx / (BM / 4), c = 4 * (idx % (BM / 4));
+          const bool ok = a_ok[j] && (a.k0 + krow < a.klim);
+          const float4 v = ok ? ra[j] : zero4;
+          float2* d = reinterpret_cast<float2*>(as + krow * LDA + c);
+          d[0] = make_float2(v.x, v.y);
+          d[1] = make_float2(v.z, v.w);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int idx = tid + j * NTHR;
+      if (idx < B4) {
+        const int krow = idx / (BN / 4), c = 4 * (idx % (BN / 4));
+        const bool ok = b_ok[j] && (a.k0 + krow < a.klim);
+        const float4 v = ok ? rb[j] : zero4;
+        float2* d = reinterpret_cast<float2*>(bs + krow * LDB + c);
+        d[0] = make_float2(v.x, v.y);
+        d[1] = make_float2(v.z, v.w);
+      }
+    }
+  };
+
+  // swapped operands: acc[mi][ni][r] = C[row = wrow + mi*16 + l15][col = wcol + ni*16 + 4*q + r]
+  auto compute = [&](int buf, auto FULLT) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(FULLT)::value;
+    const float* as = As + buf * BK * LDA + wrow + l15;
+    const float* bs = Bs + buf * BK * LDB + wcol + l15;
+    const int kq = 8 * (q & 1) + 4 * (q >> 1);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int kr = s + kq;
+      float a[2], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[mi] = as[kr * LDA + mi * 16];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) b[ni] = bs[kr * LDB + ni * 16];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        if (FULL || mi < mi_cnt) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            if (FULL || ni < ni_cnt)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  load_tile(0);
+  store_tile(0, 0);
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    if (t + 1 < T) load_tile(t + 1);
+    if (full) compute(t & 1, std::true_type{});
+    else compute(t & 1, std::false_type{});
+    if (t + 1 < T) store_tile((t + 1) & 1, t + 1);
+    __syncthreads();
+  }
+
+  // -------------------------------------------------------------------- epilogue (16-byte vector accesses)
+  const int epi = P.epi;
+  const int ldc = P.ldc;
+  float* const C = P.C + (TN ? (size_t)outer * (size_t)P.split_stride : (size_t)0);
+  if (epi == EPI_ATT) {
+    float* red = smem;   // [WN][BM][8]
+    const int heads = P.heads;
+    const float* U = P.u; const float* W2 = P.w2; float* E = P.e;
+    const int ldu = P.ldu, R = P.R;
+    auto att_rows = [&](auto MI) __attribute__((always_inline)) {
+      constexpr int mi = decltype(MI)::value;
+      const int lrow = wrow + mi * 16 + l15;
+      const int row = m0 + lrow;
+      float pe[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) pe[c] = 0.f;
+      if (mi < mi_cnt && row < M) {
+        const float* urow = U + (size_t)(row / R) * ldu;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int col = wcol + ni * 16 + 4 * q;
+          if (ni < ni_cnt && col < N) {
+            const float4 u4 = *reinterpret_cast<const float4*>(urow + col);
+            float4 t;
+            t.x = tanhf_(acc[mi][ni][0] + u4.x); t.y = tanhf_(acc[mi][ni][1] + u4.y);
+            t.z = tanhf_(acc[mi][ni][2] + u4.z); t.w = tanhf_(acc[mi][ni][3] + u4.w);
+            *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = t;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+              if (c < heads) {
+                const float4 w = *reinterpret_cast<const float4*>(W2 + (size_t)c * N + col);
+                pe[c] += t.x * w.x + t.y * w.y + t.z * w.z + t.w * w.w;
+              }
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float v = pe[c];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        pe[c] = v;
+      }
+      if (WN == 1) {
+        if (q == 0 && row < M && mi < mi_cnt)
+          for (int c = 0; c < heads; ++c) E[(size_t)row * heads + c] = pe[c];
+      } else {
+        if (q == 0)
+          for (int c = 0; c < 8; ++c) red[(wn * BM + lrow) * 8 + c] = pe[c];
+      }
+    };
+    att_rows(std::integral_constant<int, 0>{});
+    att_rows(std::integral_constant<int, 1>{});
+    if (WN > 1) {
+      __syncthreads();
+      for (int i = tid; i < BM * 8; i += NTHR) {
+        const int lrow = i >> 3, c = i & 7, row = m0 + lrow;
+        if (row < M && c < heads) {
+          float v = 0.f;
+          for (int w = 0; w < WN; ++w) v += red[(w * BM + lrow) * 8 + c];
+          E[(size_t)row * heads + c] = v;
+        }
+      }
+    }
+    return;
+  }
+
+  const float* bias = P.bias;
+  float* out1 = P.out1;
+  const float* in0 = P.in0;
+  const float* in1 = P.in1;
+  const int accumulate = P.accumulate;
+  auto epi_rows = [&](auto MI) __attribute__((always_inline)) {
+    constexpr int mi = decltype(MI)::value;
+    const int row = m0 + wrow + mi * 16 + l15;
+    const bool row_ok = (mi < mi_cnt) && (row < M);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = wcol + ni * 16 + 4 * q;
+      if (row_ok && ni < ni_cnt && col < N) {
+        const size_t o = (size_t)row * ldc + col;
+        float4 v = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+        if (bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(bias + col);
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        }
+        if (epi == EPI_STORE) {
+          if (accumulate) {
+            const float4 p = *reinterpret_cast<const float4*>(C + o);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+          }
+          *reinterpret_cast<float4*>(C + o) = v;
+        } else if (epi == EPI_SIGMOID_Z) {
+          *reinterpret_cast<float4*>(C + o) = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+        } else if (epi == EPI_SIGMOID_R) {
+          const float4 r = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+          const float4 x = *reinterpret_cast<const float4*>(in0 + o);
+          *reinterpret_cast<float4*>(C + o) = r;
+          *reinterpret_cast<float4*>(out1 + o) = make_float4(r.x * x.x, r.y * x.y, r.z * x.z, r.w * x.w);
+        } else if (epi == EPI_TANH_H) {
+          const float4 h = make_float4(tanhf_(v.x), tanhf_(v.y), tanhf_(v.z), tanhf_(v.w));
+          const float4 z = *reinterpret_cast<const float4*>(in0 + o);
+          const float4 x = *reinterpret_cast<const float4*>(in1 + o);
+          *reinterpret_cast<float4*>(C + o) = h;
+          *reinterpret_cast<float4*>(out1 + o) =
+              make_float4(h.x * z.x + x.x * (1.f - z.x), h.y * z.y + x.y * (1.f - z.y),
+                          h.z * z.z + x.z * (1.f - z.z), h.w * z.w + x.w * (1.f - z.w));
+        } else if (epi == EPI_BWD_DRX) {
+          const float4 x = *reinterpret_cast<const float4*>(in0 + o);
+          const float4 r = *reinterpret_cast<const float4*>(in1 + o);
+          float4 d = *reinterpret_cast<const float4*>(out1 + o);
+          *reinterpret_cast<float4*>(C + o) =
+              make_float4(v.x * x.x * r.x * (1.f - r.x), v.y * x.y * r.y * (1.f - r.y),
+                          v.z * x.z * r.z * (1.f - r.z), v.w * x.w * r.w * (1.f - r.w));
+          d.x += v.x * r.x; d.y += v.y * r.y; d.z += v.z * r.z; d.w += v.w * r.w;
+          *reinterpret_cast<float4*>(out1 + o) = d;
+        } else if (epi == EPI_ATOMIC) {
+          atomicAdd(C + o + 0, v.x); atomicAdd(C + o + 1, v.y);
+          atomicAdd(C + o + 2, v.z); atomicAdd(C + o + 3, v.w);
+        }
+      }
+    }
+  };
+  epi_rows(std::integral_constant<int, 0>{});
+  epi_rows(std::integral_constant<int, 1>{});
+}
+
+}  // namespace gh

@@ -3,8 +3,31 @@
 #include "../../include/get_hip.h"
 #include "common.h"
 #include "gemm.hip.h"
+#include "gemm_fast.hip.h"
+#include <stdlib.h>
 
 namespace gh {
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// fast-path preconditions of gemm_fast.hip.h
+static bool fast_ok(const Launch& L, bool tn) {
+  for (int i = 0; i < L.nprob; ++i) {
+    const Problem& p = L.p[i];
+    const int ns = tn ? 1 : p.nseg;
+    for (int j = 0; j < ns; ++j) {
+      const Seg& s = p.seg[j];
+      if (!s.vecA || !s.vecB || s.gatherB || s.K < 4) return false;
+      if (tn && s.gatherA) return false;
+    }
+    if (p.N % 4 || p.N < 4 || p.ldc % 4 || !al16(p.C)) return false;
+    if (tn && (p.M % 4 || p.M < 4)) return false;
+    if ((p.bias && !al16(p.bias)) || (p.out1 && !al16(p.out1)) || (p.in0 && !al16(p.in0)) || (p.in1 && !al16(p.in1)))
+      return false;
+    if (p.epi == EPI_ATT && (!al16(p.u) || p.ldu % 4 || !al16(p.w2))) return false;
+  }
+  return true;
+}
 
 template <int WM, int WN, int NI>
 static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
@@ -18,10 +41,52 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
       for (int j = 0; j < L.p[i].nseg; ++j) flops += 2.0 * L.p[i].M * L.p[i].N * (double)L.p[i].seg[j].K;
     prof_begin(s);
   }
-  if (tn) hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, true>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
-  else hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, false>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
-  prof_end((WM == 4 ? PROF_GEMM_BIG : PROF_GEMM_SMALL) + (tn ? 1 : 0), flops, s);
+  if (fast_ok(L, tn)) {
+    if (tn) hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, true>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
+    else hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, false>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
+  } else {
+    if (tn) hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, true>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
+    else hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, false>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
+  }
+  prof_end((WM * WN == 4 && WN != 4 ? PROF_GEMM_BIG : PROF_GEMM_SMALL) + (tn ? 1 : 0), flops, s);
   return hipGetLastError();
+}
+
+// Split-K scratch registered by the caller (gh_set_workspace); partial tiles are written with plain
+// stores and summed by reduce_partials_kernel instead of cross-XCD fp32 atomics.
+static float* g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+
+struct ReduceItem { const float* ws; float* out; int I, J, ldc, ks; long long stride; };
+struct ReduceArgs { ReduceItem it[GH_MAX_PROBLEMS]; int n; };
+
+__global__ void __launch_bounds__(256)
+reduce_partials_kernel(const ReduceArgs R) {
+  const ReduceItem& it = R.it[blockIdx.y];
+  const int J4 = it.J / 4;
+  const size_t total = (size_t)it.I * J4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / J4), j = 4 * (int)(e % J4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* p = it.ws + (size_t)i * it.J + j;
+    for (int k = 0; k < it.ks; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * it.stride);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float* o = it.out + (size_t)i * it.ldc + j;     // += : gradients accumulate into the caller's buffer
+    o[0] += acc.x; o[1] += acc.y; o[2] += acc.z; o[3] += acc.w;
+  }
+}
+
+// Big-M tile configuration: 0 = 128x304 (4x1 waves, 19 col tiles), 1 = 64x320 (2x2 waves, 10 col tiles).
+// GH_GEMM_CFG overrides the default for A/B runs.
+static int big_cfg() {
+  static int cfg = -1;
+  if (cfg < 0) {
+    const char* e = getenv("GH_GEMM_CFG");
+    cfg = e ? atoi(e) : 1;
+  }
+  return cfg;
 }
 
 // Collects problems that share their row space, splits wide outputs into column blocks the tile
@@ -36,8 +101,8 @@ struct Batch {
 
   Batch(bool tn_, int rows_hint, hipStream_t s_) : tn(tn_), s(s_) {
     big = tn_ || rows_hint >= 512;
-    bm = big ? 128 : 32;
-    bn = big ? GH_BN_BIG : GH_BN_SMALL;
+    bm = big ? (big_cfg() == 0 ? 128 : 64) : 32;
+    bn = big ? (big_cfg() == 0 ? GH_BN_BIG : 320) : GH_BN_SMALL;
     reset();
   }
   void reset() { L.nprob = 0; L.m_tiles = 0; L.ksplit = 1; L.kchunk = 0; k_total = 0; }
@@ -68,16 +133,45 @@ struct Batch {
     if (L.nprob == 0 || err != hipSuccess) { reset(); return; }
     if (tn) {
       const int n_inner = L.m_tiles * L.nprob;
-      int ks = (768 + n_inner - 1) / n_inner;
-      const int ks_max = (k_total / 512 > 1) ? k_total / 512 : 1;
+      int ks = (1536 + n_inner - 1) / n_inner;
+      const int ks_max = (k_total / 256 > 1) ? k_total / 256 : 1;
       if (ks > ks_max) ks = ks_max;
       if (ks < 1) ks = 1;
       int chunk = (k_total + ks - 1) / ks;
       chunk = ((chunk + 15) / 16) * 16;
       L.kchunk = chunk;
       L.ksplit = (k_total + chunk - 1) / chunk;
+      // partial tiles -> workspace when it is big enough and every output is float4-shaped
+      size_t need = 0;
+      bool ws_ok = g_ws != nullptr && L.ksplit > 1;
+      for (int i = 0; i < L.nprob && ws_ok; ++i) {
+        if (L.p[i].N % 4) ws_ok = false;
+        need += (size_t)L.ksplit * L.p[i].M * L.p[i].N * sizeof(float);
+      }
+      if (ws_ok && need <= g_ws_bytes) {
+        ReduceArgs R;
+        R.n = L.nprob;
+        float* w = g_ws;
+        int max_elems = 0;
+        for (int i = 0; i < L.nprob; ++i) {
+          Problem& q = L.p[i];
+          R.it[i] = ReduceItem{w, q.C, q.M, q.N, q.ldc, L.ksplit, (long long)q.M * q.N};
+          q.C = w; q.ldc = q.N; q.epi = EPI_STORE; q.accumulate = 0; q.split_stride = (long long)q.M * q.N;
+          w += (size_t)L.ksplit * q.M * q.N;
+          if (q.M * (q.N / 4) > max_elems) max_elems = q.M * (q.N / 4);
+        }
+        hipError_t e = !big ? launch_cfg<1, 4, 5>(L, tn, s)
+                       : (big_cfg() == 0 ? launch_cfg<4, 1, 19>(L, tn, s) : launch_cfg<2, 2, 10>(L, tn, s));
+        if (e != hipSuccess) err = e;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((max_elems + 255) / 256, R.n), dim3(256), 0, s, R);
+        e = hipGetLastError();
+        if (e != hipSuccess) err = e;
+        reset();
+        return;
+      }
     }
-    hipError_t e = big ? launch_cfg<4, 1, 19>(L, tn, s) : launch_cfg<1, 4, 5>(L, tn, s);
+    hipError_t e = !big ? launch_cfg<1, 4, 5>(L, tn, s)
+                   : (big_cfg() == 0 ? launch_cfg<4, 1, 19>(L, tn, s) : launch_cfg<2, 2, 10>(L, tn, s));
     if (e != hipSuccess) err = e;
     reset();
   }
@@ -195,7 +289,13 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
     b.add(tn_problem(h, h, dw_r1, h, drp, h, xp, h, M));
     b.add(tn_problem(h, h, dw_h0, h, dhp, h, a, h, M));
     b.add(tn_problem(h, h, dw_h1, h, dhp, h, rx, h, M));
-    b.add(tn_problem(h, din, dw_p, din, dxp, h, x, din, M, ids));
+    if (ids && din <= h) {
+      // embedding rows materialised once into the (now free) `da` scratch, so the split-K GEMM streams them
+      if (int e = launch_gather_rows(x, ids, da, M, din, s)) return e;
+      b.add(tn_problem(h, din, dw_p, din, dxp, h, da, din, M));
+    } else {
+      b.add(tn_problem(h, din, dw_p, din, dxp, h, x, din, M, ids));
+    }
     b.flush();
     GH_CHECK_HIP(b.err);
   }
@@ -210,7 +310,7 @@ extern "C" int gh_concat_att_fwd(const float* left, const float* right, const fl
   GH_REQUIRE(heads >= 1 && heads <= 8, "concat_att: heads=%d not in [1,8]", heads);
   GH_REQUIRE(b > 0 && l > 0 && dr > 0 && ha > 0, "concat_att_fwd: bad sizes");
   const int M = b * l;
-  GH_REQUIRE(ha <= ((M >= 512) ? GH_BN_BIG : GH_BN_SMALL), "concat_att_fwd: attention hidden %d exceeds one column block", ha);
+  GH_REQUIRE(ha <= ((M >= 512 && big_cfg() == 0) ? GH_BN_BIG : GH_BN_SMALL), "concat_att_fwd: attention hidden %d exceeds one column block", ha);
   if (left && xl > 0) {  // u = W1[:, :xl] . left -- once per pair, not per token (two_branches_attention.py:137-140)
     Batch bt(false, b, s);
     bt.add(gemm_problem(b, ha, EPI_STORE, u, ha, left, xl, w1t, ha, xl));
@@ -269,6 +369,12 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, int b, i
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }
+  return 0;
+}
+
+extern "C" int gh_set_workspace(void* ptr, int64_t bytes) {
+  g_ws = (float*)ptr;
+  g_ws_bytes = ptr ? (size_t)bytes : 0;
   return 0;
 }
 

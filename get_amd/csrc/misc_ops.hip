@@ -142,6 +142,28 @@ int launch_colsum(const float* a, float* oa, int m, int h, hipStream_t s) {
   return launch_colsum3(a, nullptr, nullptr, oa, nullptr, nullptr, m, h, s);
 }
 
+// ---------------------------------------------------------------------------- row gather (embedding rows for the dW_proj GEMM)
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids, float* __restrict__ dst, int m,
+                   int d) {
+  const int per = (d + 3) / 4;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < (size_t)m * per; it += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(it / per), c = 4 * (int)(it % per);
+    const float* s = table + (size_t)ids[r] * d + c;
+    float* o = dst + (size_t)r * d + c;
+    if (d % 4 == 0) *reinterpret_cast<float4*>(o) = *reinterpret_cast<const float4*>(s);
+    else for (int k = 0; k < 4 && c + k < d; ++k) o[k] = s[k];
+  }
+}
+int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m, int d, hipStream_t s) {
+  if (m <= 0) return 0;
+  const size_t n = (size_t)m * ((d + 3) / 4);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s,
+                     table, ids, dst, m, d);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------- concat attention: masked softmax + weighted reduce
 // e [b][l][C] -> weights = softmax over l (two_branches_attention.py:142-146), attended[b][d][c] = sum_l right[b][l][d] w[l][c] (:147)
 __global__ void __launch_bounds__(256)

@@ -186,6 +186,7 @@ class _GGNNCell(torch.autograd.Function):
         m = n * r
         dev = g.device
         g = _f32(g).reshape(m, h)
+        _lib.ensure_workspace(dev)
         scratch = torch.empty((5, m, h), device=dev, dtype=torch.float32)
         dhp, dzp, drp, dxp, da = scratch.unbind(0)
         ids = ctx.ids
@@ -279,6 +280,7 @@ class _ConcatAtt(torch.autograd.Function):
         dev = right.device
         if not ctx.has_left:
             left = None
+        _lib.ensure_workspace(dev)
         g_att = _f32(g_att) if g_att is not None else torch.zeros((b, dr, heads), device=dev)
         g_w = _f32(g_w) if g_w is not None else None
         de = torch.empty((b * l, heads), device=dev, dtype=torch.float32)
@@ -320,6 +322,7 @@ class _Linear(torch.autograd.Function):
         m, k = x2.shape
         n = w.shape[0]
         g2 = _f32(g).reshape(m, n)
+        _lib.ensure_workspace(g.device)
         dx = torch.empty((m, k), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         dw = torch.zeros((n, k), device=g.device, dtype=torch.float32)
         db = torch.zeros((n,), device=g.device, dtype=torch.float32) if ctx.has_bias else None

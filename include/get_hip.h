@@ -126,6 +126,13 @@ int gh_concat_att_bwd(const float* left, const float* right, int b, int l, int x
                       float* de, float* dpre, float* du,
                       float* dleft, float* dright, float* dw1, float* dw2, gh_stream_t stream);
 
+/* ---- split-K scratch for the weight-gradient GEMMs ----
+ * Caller-owned device buffer (stays registered until replaced; NULL unregisters).  With it the
+ * K-chunk partial tiles are written with plain stores and reduced by a second kernel; without it
+ * (or when it is too small) the chunks add into the output with fp32 atomics.  All work that uses
+ * it is ordered on the stream of the call, so one buffer serves one stream at a time. */
+int gh_set_workspace(void* ptr, int64_t bytes);
+
 /* ---- plain linear y = x W^T + b (model head, graph_based_semantic_structure.py:69-72) ---- */
 int gh_linear_fwd(const float* x, const float* wt, const float* bias, float* y, int m, int k, int n,
                   gh_stream_t stream);
