@@ -47,7 +47,7 @@ SIGNATURES = {
     "gh_profile_collect": [_P, _I],
 }
 
-PROFILE_ROWS = ["gemm_128x304", "gemm_128x304_tn", "gemm_32x320", "gemm_32x320_tn", "spmm", "scorer_gsl",
+PROFILE_ROWS = ["gemm_big", "gemm_big_tn", "gemm_small", "gemm_small_tn", "spmm", "scorer_gsl",
                 "graph_build", "att_softmax_fwd", "att_softmax_bwd", "att_dpre", "gate_bwd_pre", "colsum", "adam"]
 
 

@@ -50,6 +50,7 @@ int launch_gate_bwd_pre(const float* g, const float* z, const float* hh, const f
 int launch_colsum3(const float* a, const float* b, const float* c, float* oa, float* ob, float* oc, int m, int h,
                    hipStream_t s);
 int launch_colsum(const float* a, float* oa, int m, int h, hipStream_t s);
+void set_colsum_workspace(float* p, size_t bytes);
 int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m, int d, hipStream_t s);
 int launch_att_softmax_fwd(const float* e, const float* mask, const float* right, int b, int l, int dr, int heads,
                            float* weights, float* attended, hipStream_t s);

@@ -22,22 +22,28 @@ gemm_fast_kernel(const Launch L_byval) {
   const GH_KARG Launch& L = *(const GH_KARG Launch*)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int NTHR = WM * WN * 64;
   constexpr int BM = 32 * WM, BN = 16 * NI * WN, BK = 16;
-  constexpr int LDA = BM + 2, LDB = BN + 2;
+  // LDS pitches == 4 (mod 32) dwords: with the k-rows of one MFMA step taken as {s, s+4, s+8, s+12}
+  // the two 16-lane halves of a ds_read_b32 group sit 16 banks apart (conflict-free fragment reads),
+  // and rows stay 16-byte aligned so the B tile is written with ds_write_b128.
+  constexpr int LDA = BM + 4, LDB = BN + 4;
   constexpr int A4 = BM * 4, B4 = BK * (BN / 4);
   constexpr int NA = (A4 + NTHR - 1) / NTHR, NB = (B4 + NTHR - 1) / NTHR;
   __shared__ float smem[2 * BK * LDA + 2 * BK * LDB];
   float* As = smem;
   float* Bs = smem + 2 * BK * LDA;
 
-  const int n_inner = TN ? L.m_tiles * L.nprob : L.nprob;
+  // NT launches may also be split over K (few-row GEMMs): inner = (k-chunk, problem)
+  const int n_inner = TN ? L.m_tiles * L.nprob : L.nprob * L.ksplit;
   const int n_outer = TN ? L.ksplit : L.m_tiles;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
   const int outer = xcd + 8 * (slot / n_inner);
   const int inner = slot % n_inner;
   if (outer >= n_outer) return;
-  const int prob = TN ? inner % L.nprob : inner;
+  const int prob = inner % L.nprob;
   const int m_tile = TN ? inner / L.nprob : outer;
+  const int ks = TN ? outer : inner / L.nprob;
+  const bool split = TN || L.ksplit > 1;
   const GH_KARG Problem& P = L.p[prob];
   const int M = P.M, N = P.N;
   const int m0 = m_tile * BM;
@@ -57,12 +63,12 @@ gemm_fast_kernel(const Launch L_byval) {
   const int K1 = nseg > 1 ? P.seg[1].K : 0;
 
   int kbeg = 0, kend = K0;
-  if (TN) {
-    kbeg = (int)outer * L.kchunk;
+  if (split) {
+    kbeg = ks * L.kchunk;
     kend = min(K0, kbeg + L.kchunk);
     if (kbeg >= kend) return;
   }
-  const int nt0 = TN ? (kend - kbeg + BK - 1) / BK : (K0 + BK - 1) / BK;
+  const int nt0 = (kend - kbeg + BK - 1) / BK;
   const int T = nt0 + (nseg > 1 ? (K1 + BK - 1) / BK : 0);
 
   // per-thread A slots
@@ -106,7 +112,6 @@ gemm_fast_kernel(const Launch L_byval) {
 
   const int mi_cnt = min(2, (M - m0 - wrow + 15) / 16);
   const int ni_cnt = min(NI, (N - wcol + 15) / 16);
-  const bool full = (mi_cnt == 2) && (ni_cnt == NI);
 
   float4 ra[NA], rb[NB];
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -119,8 +124,8 @@ gemm_fast_kernel(const Launch L_byval) {
     a.Ab = a.s1 ? A1 : A0;
     a.Bb = a.s1 ? B1 : B0;
     a.ldb = a.s1 ? ldb1 : ldb0;
-    a.k0 = TN ? (kbeg + t * BK) : ((a.s1 ? t - nt0 : t) * BK);
-    a.klim = TN ? kend : (a.s1 ? K1 : K0);
+    a.k0 = a.s1 ? (t - nt0) * BK : kbeg + t * BK;
+    a.klim = a.s1 ? K1 : kend;
     return a;
   };
 
@@ -165,9 +170,7 @@ gemm_fast_kernel(const Launch L_byval) {
           const int krow = idx / (BM / 4), c = 4 * (idx % (BM / 4));
           const bool ok = a_ok[j] && (a.k0 + krow < a.klim);
           const float4 v = ok ? ra[j] : zero4;
-          float2* d = reinterpret_cast<float2*>(as + krow * LDA + c);
-          d[0] = make_float2(v.x, v.y);
-          d[1] = make_float2(v.z, v.w);
+          *reinterpret_cast<float4*>(as + krow * LDA + c) = v;
         }
       }
     }
@@ -178,19 +181,19 @@ gemm_fast_kernel(const Launch L_byval) {
         const int krow = idx / (BN / 4), c = 4 * (idx % (BN / 4));
         const bool ok = b_ok[j] && (a.k0 + krow < a.klim);
         const float4 v = ok ? rb[j] : zero4;
-        float2* d = reinterpret_cast<float2*>(bs + krow * LDB + c);
-        d[0] = make_float2(v.x, v.y);
-        d[1] = make_float2(v.z, v.w);
+        *reinterpret_cast<float4*>(bs + krow * LDB + c) = v;
       }
     }
   };
 
   // swapped operands: acc[mi][ni][r] = C[row = wrow + mi*16 + l15][col = wcol + ni*16 + 4*q + r]
-  auto compute = [&](int buf, auto FULLT) __attribute__((always_inline)) {
-    constexpr bool FULL = decltype(FULLT)::value;
+  // NV = number of valid 16-wide column tiles of this wave when known at compile time (NI or NI-1:
+  // N = 300 leaves the last wave one tile short), -1 = guarded per tile (ragged M / N tails).
+  auto compute = [&](int buf, auto NVT) __attribute__((always_inline)) {
+    constexpr int NV = decltype(NVT)::value;
     const float* as = As + buf * BK * LDA + wrow + l15;
     const float* bs = Bs + buf * BK * LDB + wcol + l15;
-    const int kq = 8 * (q & 1) + 4 * (q >> 1);
+    const int kq = 4 * q;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int kr = s + kq;
@@ -198,26 +201,41 @@ gemm_fast_kernel(const Launch L_byval) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) a[mi] = as[kr * LDA + mi * 16];
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) b[ni] = bs[kr * LDB + ni * 16];
+      for (int ni = 0; ni < NI; ++ni)
+        if (NV < 0 || ni < NV) b[ni] = bs[kr * LDB + ni * 16];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
-        if (FULL || mi < mi_cnt) {
+        if (NV >= 0 || mi < mi_cnt) {
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            if (FULL || ni < ni_cnt)
+            if ((NV >= 0 && ni < NV) || (NV < 0 && ni < ni_cnt))
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ni], a[mi], acc[mi][ni], 0, 0, 0);
         }
       }
     }
   };
+  const int path = (mi_cnt == 2 && ni_cnt == NI) ? 0 : ((mi_cnt == 2 && ni_cnt == NI - 1) ? 1 : 2);
 
+  // Workgroups that start together on one CU would otherwise run their load / MFMA / barrier phases in
+  // lock-step and leave the matrix pipe idle in every barrier; shift the first round apart in time.
+  if (L.stagger) {
+    int ph = 0;
+    if (L.stagger == 1) ph = (bid >> 8) % 3;
+    else if (L.stagger == 2) ph = (bid >> 3) % 3;
+    else if (L.stagger == 3) ph = (int)((bid * 2654435761u) >> 30) % 3;
+    if (bid < 768 * 2) {
+      if (ph == 1) __builtin_amdgcn_s_sleep(40);
+      else if (ph == 2) { __builtin_amdgcn_s_sleep(40); __builtin_amdgcn_s_sleep(40); }
+    }
+  }
   load_tile(0);
   store_tile(0, 0);
   __syncthreads();
   for (int t = 0; t < T; ++t) {
     if (t + 1 < T) load_tile(t + 1);
-    if (full) compute(t & 1, std::true_type{});
-    else compute(t & 1, std::false_type{});
+    if (path == 0) compute(t & 1, std::integral_constant<int, NI>{});
+    else if (path == 1) compute(t & 1, std::integral_constant<int, NI - 1>{});
+    else compute(t & 1, std::integral_constant<int, -1>{});
     if (t + 1 < T) store_tile((t + 1) & 1, t + 1);
     __syncthreads();
   }
@@ -225,7 +243,7 @@ gemm_fast_kernel(const Launch L_byval) {
   // -------------------------------------------------------------------- epilogue (16-byte vector accesses)
   const int epi = P.epi;
   const int ldc = P.ldc;
-  float* const C = P.C + (TN ? (size_t)outer * (size_t)P.split_stride : (size_t)0);
+  float* const C = P.C + (split ? (size_t)ks * (size_t)P.split_stride : (size_t)0);
   if (epi == EPI_ATT) {
     float* red = smem;   // [WN][BM][8]
     const int heads = P.heads;

@@ -32,7 +32,7 @@ static bool fast_ok(const Launch& L, bool tn) {
 template <int WM, int WN, int NI>
 static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
   const int n_outer = tn ? L.ksplit : L.m_tiles;
-  const int n_inner = tn ? L.m_tiles * L.nprob : L.nprob;
+  const int n_inner = tn ? L.m_tiles * L.nprob : L.nprob * L.ksplit;
   const int grid = 8 * ((n_outer + 7) / 8) * n_inner;
   if (grid <= 0) return hipSuccess;
   double flops = 0.0;
@@ -78,6 +78,65 @@ reduce_partials_kernel(const ReduceArgs R) {
   }
 }
 
+// Second half of an NT GEMM that was split over K: sum the partial tiles, then apply the real epilogue
+// (bias / accumulate, or the attention tanh + head scores).  One wave per output row.
+struct FinishItem {
+  const float* ws; long long stride; int ks; int M, N, epi, accumulate, ldc;
+  float* C; const float* bias; const float* u; const float* w2; float* e; int ldu, R, heads;
+};
+struct FinishArgs { FinishItem it[GH_MAX_PROBLEMS]; int n; };
+
+__global__ void __launch_bounds__(256)
+nt_finish_kernel(const FinishArgs F) {
+  const FinishItem& it = F.it[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= it.M) return;
+  const int N4 = it.N / 4;
+  float pe[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) pe[c] = 0.f;
+  for (int c4 = lane; c4 < N4; c4 += 64) {
+    const int col = 4 * c4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* p = it.ws + (size_t)row * it.N + col;
+    for (int k = 0; k < it.ks; ++k) {
+      const float4 x = *reinterpret_cast<const float4*>(p + (size_t)k * it.stride);
+      v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+    }
+    float* o = it.C + (size_t)row * it.ldc + col;
+    if (it.epi == EPI_ATT) {
+      const float4 u4 = *reinterpret_cast<const float4*>(it.u + (size_t)(row / it.R) * it.ldu + col);
+      const float4 t = make_float4(tanhf_(v.x + u4.x), tanhf_(v.y + u4.y), tanhf_(v.z + u4.z), tanhf_(v.w + u4.w));
+      *reinterpret_cast<float4*>(o) = t;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < it.heads) {
+          const float4 w = *reinterpret_cast<const float4*>(it.w2 + (size_t)c * it.N + col);
+          pe[c] += t.x * w.x + t.y * w.y + t.z * w.z + t.w * w.w;
+        }
+    } else {
+      if (it.bias) {
+        const float4 b4 = *reinterpret_cast<const float4*>(it.bias + col);
+        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+      }
+      if (it.accumulate) {
+        const float4 c4v = *reinterpret_cast<const float4*>(o);
+        v.x += c4v.x; v.y += c4v.y; v.z += c4v.z; v.w += c4v.w;
+      }
+      *reinterpret_cast<float4*>(o) = v;
+    }
+  }
+  if (it.epi == EPI_ATT) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float v = pe[c];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0 && c < it.heads) it.e[(size_t)row * it.heads + c] = v;
+    }
+  }
+}
+
 // Big-M tile configuration: 0 = 128x304 (4x1 waves, 19 col tiles), 1 = 64x320 (2x2 waves, 10 col tiles).
 // GH_GEMM_CFG overrides the default for A/B runs.
 static int big_cfg() {
@@ -100,12 +159,16 @@ struct Batch {
   int k_total = 0;
 
   Batch(bool tn_, int rows_hint, hipStream_t s_) : tn(tn_), s(s_) {
-    big = tn_ || rows_hint >= 512;
+    big = tn_ || rows_hint >= 8192;
     bm = big ? (big_cfg() == 0 ? 128 : 64) : 32;
     bn = big ? (big_cfg() == 0 ? GH_BN_BIG : 320) : GH_BN_SMALL;
     reset();
   }
-  void reset() { L.nprob = 0; L.m_tiles = 0; L.ksplit = 1; L.kchunk = 0; k_total = 0; }
+  void reset() {
+    static int stagger = -1;
+    if (stagger < 0) { const char* e = getenv("GH_GEMM_STAGGER"); stagger = e ? atoi(e) : 0; }
+    L.nprob = 0; L.m_tiles = 0; L.ksplit = 1; L.kchunk = 0; k_total = 0; L.stagger = stagger;
+  }
 
   void add(const Problem& p) {
     if (p.epi == EPI_ATT && p.N > bn) { err = hipErrorInvalidValue; return; }
@@ -160,8 +223,7 @@ struct Batch {
           w += (size_t)L.ksplit * q.M * q.N;
           if (q.M * (q.N / 4) > max_elems) max_elems = q.M * (q.N / 4);
         }
-        hipError_t e = !big ? launch_cfg<1, 4, 5>(L, tn, s)
-                       : (big_cfg() == 0 ? launch_cfg<4, 1, 19>(L, tn, s) : launch_cfg<2, 2, 10>(L, tn, s));
+        hipError_t e = launch_any();
         if (e != hipSuccess) err = e;
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((max_elems + 255) / 256, R.n), dim3(256), 0, s, R);
         e = hipGetLastError();
@@ -170,10 +232,61 @@ struct Batch {
         return;
       }
     }
-    hipError_t e = !big ? launch_cfg<1, 4, 5>(L, tn, s)
-                   : (big_cfg() == 0 ? launch_cfg<4, 1, 19>(L, tn, s) : launch_cfg<2, 2, 10>(L, tn, s));
+    if (!tn && nt_split_plan()) return;
+    hipError_t e = launch_any();
     if (e != hipSuccess) err = e;
     reset();
+  }
+
+  hipError_t launch_any() {
+    return !big ? launch_cfg<1, 4, 5>(L, tn, s)
+                : (big_cfg() == 0 ? launch_cfg<4, 1, 19>(L, tn, s) : launch_cfg<2, 2, 10>(L, tn, s));
+  }
+
+  // Few-row NT GEMMs (evidence level, head): too few row tiles to fill 256 CUs, so split K across
+  // workgroups, keep the partial tiles in the workspace and finish with nt_finish_kernel.
+  bool nt_split_plan() {
+    const int blocks = L.m_tiles * L.nprob;
+    if (g_ws == nullptr || blocks >= 96 || !fast_ok(L, false)) return false;
+    int kmax = 0;
+    for (int i = 0; i < L.nprob; ++i) {
+      const Problem& q = L.p[i];
+      if (q.nseg != 1 || (q.epi != EPI_STORE && q.epi != EPI_ATT)) return false;
+      if (q.seg[0].K > kmax) kmax = q.seg[0].K;
+    }
+    int ks = kmax / 64;
+    const int want = (256 + blocks - 1) / blocks;
+    if (ks > want) ks = want;
+    if (ks < 2) return false;
+    int chunk = (kmax + ks - 1) / ks;
+    chunk = ((chunk + 15) / 16) * 16;
+    ks = (kmax + chunk - 1) / chunk;
+    if (ks < 2) return false;
+    size_t need = 0;
+    for (int i = 0; i < L.nprob; ++i) need += (size_t)ks * L.p[i].M * L.p[i].N * sizeof(float);
+    if (need > g_ws_bytes) return false;
+    FinishArgs F;
+    F.n = L.nprob;
+    float* w = g_ws;
+    int max_m = 0;
+    for (int i = 0; i < L.nprob; ++i) {
+      Problem& q = L.p[i];
+      F.it[i] = FinishItem{w, (long long)q.M * q.N, ks, q.M, q.N, q.epi, q.accumulate, q.ldc,
+                           q.C, q.bias, q.u, q.w2, q.e, q.ldu, q.R, q.heads};
+      q.C = w; q.ldc = q.N; q.epi = EPI_STORE; q.accumulate = 0; q.bias = nullptr;
+      q.split_stride = (long long)q.M * q.N;
+      w += (size_t)ks * q.M * q.N;
+      if (q.M > max_m) max_m = q.M;
+    }
+    L.ksplit = ks;
+    L.kchunk = chunk;
+    hipError_t e = launch_any();
+    if (e != hipSuccess) err = e;
+    hipLaunchKernelGGL(nt_finish_kernel, dim3((max_m + 3) / 4, F.n), dim3(256), 0, s, F);
+    e = hipGetLastError();
+    if (e != hipSuccess) err = e;
+    reset();
+    return true;
   }
 };
 
@@ -310,7 +423,7 @@ extern "C" int gh_concat_att_fwd(const float* left, const float* right, const fl
   GH_REQUIRE(heads >= 1 && heads <= 8, "concat_att: heads=%d not in [1,8]", heads);
   GH_REQUIRE(b > 0 && l > 0 && dr > 0 && ha > 0, "concat_att_fwd: bad sizes");
   const int M = b * l;
-  GH_REQUIRE(ha <= ((M >= 512 && big_cfg() == 0) ? GH_BN_BIG : GH_BN_SMALL), "concat_att_fwd: attention hidden %d exceeds one column block", ha);
+  GH_REQUIRE(ha <= ((M >= 8192 && big_cfg() == 0) ? GH_BN_BIG : GH_BN_SMALL), "concat_att_fwd: attention hidden %d exceeds one column block", ha);
   if (left && xl > 0) {  // u = W1[:, :xl] . left -- once per pair, not per token (two_branches_attention.py:137-140)
     Batch bt(false, b, s);
     bt.add(gemm_problem(b, ha, EPI_STORE, u, ha, left, xl, w1t, ha, xl));
@@ -359,6 +472,11 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, int b, i
   {
     Batch bt(true, M, s);
     bt.add(tn_problem(ha, dr, dw1 + xl, ldw, dpre, ha, right, dr, M));
+    bt.flush();
+    GH_CHECK_HIP(bt.err);
+  }
+  {  // own launch: `heads` rows are not float4-shaped, so this one takes the generic kernel
+    Batch bt(true, M, s);
     bt.add(tn_problem(heads, ha, dw2, ha, de, heads, t, ha, M));
     bt.flush();
     GH_CHECK_HIP(bt.err);
@@ -373,8 +491,17 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, int b, i
 }
 
 extern "C" int gh_set_workspace(void* ptr, int64_t bytes) {
+  // the last 1/16 of the buffer (16-byte aligned) serves the column-sum partials, the rest split-K tiles
+  if (!ptr || bytes < (1 << 20)) {
+    g_ws = nullptr; g_ws_bytes = 0;
+    set_colsum_workspace(nullptr, 0);
+    return 0;
+  }
+  const size_t tail = ((size_t)bytes / 16) & ~(size_t)15;
   g_ws = (float*)ptr;
-  g_ws_bytes = ptr ? (size_t)bytes : 0;
+  g_ws_bytes = (size_t)bytes - tail;
+  g_ws_bytes &= ~(size_t)15;
+  set_colsum_workspace((float*)((char*)ptr + g_ws_bytes), tail);
   return 0;
 }
 

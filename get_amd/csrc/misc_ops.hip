@@ -129,12 +129,87 @@ colsum_kernel(const float* __restrict__ a, const float* __restrict__ b, const fl
     if (c) atomicAdd(oc + col, sc);
   }
 }
+// workspace variant: float4 columns x RL row lanes per block, partial sums to scratch, one final pass.
+constexpr int CS2_ROWS = 128;
+__global__ void colsum_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                      float* __restrict__ ws, int m, int h, int RL) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  float4* red = reinterpret_cast<float4*>(dsm);          // [3][RL][h/4]
+  const int n4 = h / 4;
+  const int c4 = threadIdx.x % n4, rl = threadIdx.x / n4;
+  const int r0 = blockIdx.x * CS2_ROWS, r1 = min(m, r0 + CS2_ROWS);
+  float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa, sc = sa;
+  if (rl < RL) {
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += RL) {
+      const size_t o = (size_t)r * n4 + c4;
+      const float4 va = reinterpret_cast<const float4*>(a)[o];
+      sa.x += va.x; sa.y += va.y; sa.z += va.z; sa.w += va.w;
+      if (b) { const float4 v = reinterpret_cast<const float4*>(b)[o]; sb.x += v.x; sb.y += v.y; sb.z += v.z; sb.w += v.w; }
+      if (c) { const float4 v = reinterpret_cast<const float4*>(c)[o]; sc.x += v.x; sc.y += v.y; sc.z += v.z; sc.w += v.w; }
+    }
+    red[(0 * RL + rl) * n4 + c4] = sa;
+    red[(1 * RL + rl) * n4 + c4] = sb;
+    red[(2 * RL + rl) * n4 + c4] = sc;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * n4; i += blockDim.x) {
+    const int arr = i / n4, cc = i % n4;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < RL; ++k) {
+      const float4 v = red[(arr * RL + k) * n4 + cc];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    reinterpret_cast<float4*>(ws)[((size_t)blockIdx.x * 3 + arr) * n4 + cc] = t;
+  }
+}
+// 64 columns x 4 partial-row lanes per block; LDS tree over the lanes
+__global__ void __launch_bounds__(256)
+colsum_final_kernel(const float* __restrict__ ws, int nblk, int h, float* __restrict__ oa, float* __restrict__ ob,
+                    float* __restrict__ oc) {
+  __shared__ float red[4][64];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), kl = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (i < 3 * h) {
+    const int arr = i / h, col = i % h;
+#pragma unroll 4
+    for (int k = kl; k < nblk; k += 4) acc += ws[((size_t)k * 3 + arr) * h + col];
+  }
+  red[kl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (kl == 0 && i < 3 * h) {
+    const int arr = i / h, col = i % h;
+    float* out = arr == 0 ? oa : (arr == 1 ? ob : oc);
+    if (out) out[col] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  }
+}
+
+static float* g_cs_ws = nullptr;
+static size_t g_cs_ws_bytes = 0;
+void set_colsum_workspace(float* p, size_t bytes) { g_cs_ws = p; g_cs_ws_bytes = bytes; }
+
 int launch_colsum3(const float* a, const float* b, const float* c, float* oa, float* ob, float* oc, int m, int h,
                    hipStream_t s) {
   if (m <= 0) return 0;
+  const uintptr_t al = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c;
+  const int nblk = (m + CS2_ROWS - 1) / CS2_ROWS;
+  const size_t need = (size_t)nblk * 3 * h * sizeof(float);
+  const double bytes = 4.0 * (double)m * h * (1 + (b != nullptr) + (c != nullptr));
+  if (g_cs_ws && need <= g_cs_ws_bytes && h % 4 == 0 && h / 4 <= 256 && (al & 15) == 0) {
+    const int n4 = h / 4;
+    const int RL = (256 / n4) > 0 ? (256 / n4) : 1;
+    const int threads = ((n4 * RL + 63) / 64) * 64;
+    prof_begin(s);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(threads), (size_t)3 * RL * h * sizeof(float), s, a, b, c,
+                       g_cs_ws, m, h, RL);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((3 * h + 63) / 64), dim3(256), 0, s, g_cs_ws, nblk, h, oa, ob, oc);
+    prof_end(PROF_COLSUM, bytes, s);
+    GH_LAUNCH_CHECK();
+    return 0;
+  }
   prof_begin(s);
   hipLaunchKernelGGL(colsum_kernel, dim3((m + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, s, a, b, c, oa, ob, oc, m, h);
-  prof_end(PROF_COLSUM, 4.0 * (double)m * h * (1 + (b != nullptr) + (c != nullptr)), s);
+  prof_end(PROF_COLSUM, bytes, s);
   GH_LAUNCH_CHECK();
   return 0;
 }

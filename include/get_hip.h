@@ -162,7 +162,7 @@ int gh_adam_step(float* p, const float* g, float* m, float* v, int64_t count, fl
 
 /* ---- measurement hook (bench.py): HIP events around every kernel launch on its own stream ----
  * rows of `out` (each {total ms, total algorithmic work, launches}; work = flops for GEMMs, bytes otherwise):
- * 0 gemm 128x304 NT/NN, 1 gemm 128x304 TN, 2 gemm 32x320 NT/NN, 3 gemm 32x320 TN, 4 spmm, 5 scorer_gsl,
+ * 0 gemm big-M tile (64x320) NT/NN, 1 same TN, 2 gemm few-row tile (32x320) NT/NN, 3 same TN, 4 spmm, 5 scorer_gsl,
  * 6 graph_build, 7 att_softmax_fwd, 8 att_softmax_bwd, 9 att_dpre, 10 gate_bwd_pre, 11 colsum, 12 adam */
 #define GH_PROFILE_ROWS 13
 int gh_profile_enable(int on);

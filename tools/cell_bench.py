@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""GGNN cell forward+backward at the bench shape (960 graphs x 100 nodes, 300->300), per-kernel HIP-event
+times from the library's profiling hook.  python tools/cell_bench.py [reps]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from get_amd import _lib, modules, ops  # noqa: E402
+from get_amd.synth import make_tokens  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+dev = "cuda:0"
+rng = np.random.default_rng(0)
+toks, lens = make_tokens(rng, 960, 100, 20000, 100, 100)
+adj, ids, _ = ops.graph_build(torch.from_numpy(toks).to(dev), torch.from_numpy(lens).to(dev), 3)
+cell = modules.GGNN(300, 300, dropout=0.0).to(dev)
+x = torch.randn(960, 100, 300, device=dev, requires_grad=True)
+g = torch.randn(960, 100, 300, device=dev)
+for _ in range(2):
+    cell(adj, x).backward(g)
+torch.cuda.synchronize()
+_lib.profile_enable(True)
+_lib.profile_collect()
+for _ in range(reps):
+    cell(adj, x).backward(g)
+torch.cuda.synchronize()
+prof = _lib.profile_collect()
+for k, v in prof.items():
+    if v["launches"]:
+        rate = v["work"] / (v["ms"] * 1e-3)
+        unit = "TFLOP/s" if k.startswith("gemm") else "GB/s"
+        print(f"{k:16s} {v['ms']/reps:8.3f} ms/iter  {v['launches']//reps:3d} launches  {rate/(1e12 if k.startswith('gemm') else 1e9):9.2f} {unit}")
