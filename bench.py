@@ -125,6 +125,7 @@ def cpu_baseline(wl, budget_s=15.0, claims=2):
                                     T(inp["doc_sources"]), T(inp["query_sources"]))
         O.cross_entropy(phi, T(inp["labels"])).backward()
 
+    torch.set_num_threads(min(8, cores))
     # torch's intra-op pool thrashes when handed every hardware thread of a 2-socket host for
     # matrices this small: probe a few pool sizes once, then spend the budget at the best one
     one()

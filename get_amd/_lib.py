@@ -25,8 +25,9 @@ SIGNATURES = {
     "gh_adj_pack_f32": [_P, _I, _I, _P, _P, _P],
     "gh_spmm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gh_transpose": [_P, _P, _I, _I, _P],
+    "gh_transpose_batch": [_I, _P, _P, _P, _P, _P],
     "gh_ggnn_cell_fwd": [_P] * 6 + [_I] * 4 + [_P] * 10 + [_P] * 7 + [_P],
-    "gh_ggnn_cell_bwd": [_P] * 6 + [_I] * 4 + [_P] * 7 + [_P] * 7 + [_P] * 5 + [_P] * 11 + [_P],
+    "gh_ggnn_cell_bwd": [_P] * 6 + [_I] * 4 + [_P] * 7 + [_P] * 7 + [_P] * 5 + [_P] * 14 + [_P],
     "gh_scorer_gsl": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "gh_gsl_topk": [_P, _I, _I, _I, _P, _P],
     "gh_adj_unpack": [_P, _P, _P, _P, _I, _I, _P, _P],

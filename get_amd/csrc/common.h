@@ -48,7 +48,7 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
 int launch_gate_bwd_pre(const float* g, const float* z, const float* hh, const float* xp, float* dhp, float* dzp,
                         float* dxp, size_t count, hipStream_t s);
 int launch_colsum3(const float* a, const float* b, const float* c, float* oa, float* ob, float* oc, int m, int h,
-                   hipStream_t s);
+                   hipStream_t s, float* oa2 = nullptr, float* ob2 = nullptr, float* oc2 = nullptr);
 int launch_colsum(const float* a, float* oa, int m, int h, hipStream_t s);
 void set_colsum_workspace(float* p, size_t bytes);
 int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m, int d, hipStream_t s);

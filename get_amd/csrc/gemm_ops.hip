@@ -196,7 +196,7 @@ struct Batch {
     if (L.nprob == 0 || err != hipSuccess) { reset(); return; }
     if (tn) {
       const int n_inner = L.m_tiles * L.nprob;
-      int ks = (1536 + n_inner - 1) / n_inner;
+      int ks = (1536 + n_inner - 1) / n_inner;   // two resident rounds of 256 CUs x 3 workgroups (one round measured 20 % slower)
       const int ks_max = (k_total / 256 > 1) ? k_total / 256 : 1;
       if (ks > ks_max) ks = ks_max;
       if (ks < 1) ks = 1;
@@ -360,7 +360,7 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
                                 float* dhp, float* dzp, float* drp, float* dxp, float* da,
                                 float* dx, float* dw_p, float* dw_z0, float* dw_z1, float* dw_r0, float* dw_r1,
                                 float* dw_h0, float* dw_h1, float* db_z, float* db_r, float* db_h,
-                                gh_stream_t stream) {
+                                float* db_z1, float* db_r1, float* db_h1, gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const int M = n * r;
   GH_REQUIRE(n > 0 && r > 0 && din > 0 && h > 0, "ggnn_cell_bwd: bad sizes");
@@ -412,7 +412,7 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
     b.flush();
     GH_CHECK_HIP(b.err);
   }
-  return launch_colsum3(dzp, drp, dhp, db_z, db_r, db_h, M, h, s);
+  return launch_colsum3(dzp, drp, dhp, db_z, db_r, db_h, M, h, s, db_z1, db_r1, db_h1);
 }
 
 extern "C" int gh_concat_att_fwd(const float* left, const float* right, const float* mask, int b, int l, int xl,

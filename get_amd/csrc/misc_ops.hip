@@ -62,6 +62,29 @@ transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int rows, 
   }
 }
 
+struct TransposeBatch { const float* src[32]; float* dst[32]; int rows[32]; int cols[32]; int tile0[33]; int n; };
+__global__ void __launch_bounds__(256)
+transpose_batch_kernel(const TransposeBatch B) {
+  __shared__ float tile[32][33];
+  int m = 0;
+  while (m + 1 < B.n && (int)blockIdx.x >= B.tile0[m + 1]) ++m;
+  const int rows = B.rows[m], cols = B.cols[m];
+  const int t = blockIdx.x - B.tile0[m], tx_n = (cols + 31) / 32;
+  const int bx = (t % tx_n) * 32, by = (t / tx_n) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* w = B.src[m];
+  float* wt = B.dst[m];
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    if (r < rows && c < cols) tile[j][tx] = w[(size_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;
+    if (r < rows && c < cols) wt[(size_t)c * rows + r] = tile[tx][j];
+  }
+}
+
 // ---------------------------------------------------------------------------- GGNN gate backward (elementwise part)
 // out = h z + xp (1 - z)  (wrapper.py:206):  dhp = g z (1-h^2) ; dzp = g (h-xp) z (1-z) ; dxp = g (1-z)
 __global__ void __launch_bounds__(256)
@@ -115,7 +138,8 @@ int launch_gate_bwd_pre(const float* g, const float* z, const float* hh, const f
 constexpr int CS_ROWS = 256;
 __global__ void __launch_bounds__(256)
 colsum_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
-              float* __restrict__ oa, float* __restrict__ ob, float* __restrict__ oc, int m, int h) {
+              float* __restrict__ oa, float* __restrict__ ob, float* __restrict__ oc, float* __restrict__ oa2,
+              float* __restrict__ ob2, float* __restrict__ oc2, int m, int h) {
   const int r0 = blockIdx.x * CS_ROWS, r1 = min(m, r0 + CS_ROWS);
   for (int col = threadIdx.x; col < h; col += 256) {
     float sa = 0.f, sb = 0.f, sc = 0.f;
@@ -127,6 +151,9 @@ colsum_kernel(const float* __restrict__ a, const float* __restrict__ b, const fl
     atomicAdd(oa + col, sa);
     if (b) atomicAdd(ob + col, sb);
     if (c) atomicAdd(oc + col, sc);
+    if (oa2) atomicAdd(oa2 + col, sa);
+    if (b && ob2) atomicAdd(ob2 + col, sb);
+    if (c && oc2) atomicAdd(oc2 + col, sc);
   }
 }
 // workspace variant: float4 columns x RL row lanes per block, partial sums to scratch, one final pass.
@@ -166,7 +193,7 @@ __global__ void colsum_partial_kernel(const float* __restrict__ a, const float* 
 // 64 columns x 4 partial-row lanes per block; LDS tree over the lanes
 __global__ void __launch_bounds__(256)
 colsum_final_kernel(const float* __restrict__ ws, int nblk, int h, float* __restrict__ oa, float* __restrict__ ob,
-                    float* __restrict__ oc) {
+                    float* __restrict__ oc, float* __restrict__ oa2, float* __restrict__ ob2, float* __restrict__ oc2) {
   __shared__ float red[4][64];
   const int i = blockIdx.x * 64 + (threadIdx.x & 63), kl = threadIdx.x >> 6;
   float acc = 0.f;
@@ -180,7 +207,10 @@ colsum_final_kernel(const float* __restrict__ ws, int nblk, int h, float* __rest
   if (kl == 0 && i < 3 * h) {
     const int arr = i / h, col = i % h;
     float* out = arr == 0 ? oa : (arr == 1 ? ob : oc);
-    if (out) out[col] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    float* out2 = arr == 0 ? oa2 : (arr == 1 ? ob2 : oc2);
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (out) out[col] += v;
+    if (out2) out2[col] += v;     // the same sum feeds a second bias (b?0 and b?1 share their gradient)
   }
 }
 
@@ -189,7 +219,7 @@ static size_t g_cs_ws_bytes = 0;
 void set_colsum_workspace(float* p, size_t bytes) { g_cs_ws = p; g_cs_ws_bytes = bytes; }
 
 int launch_colsum3(const float* a, const float* b, const float* c, float* oa, float* ob, float* oc, int m, int h,
-                   hipStream_t s) {
+                   hipStream_t s, float* oa2, float* ob2, float* oc2) {
   if (m <= 0) return 0;
   const uintptr_t al = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c;
   const int nblk = (m + CS2_ROWS - 1) / CS2_ROWS;
@@ -202,19 +232,19 @@ int launch_colsum3(const float* a, const float* b, const float* c, float* oa, fl
     prof_begin(s);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(threads), (size_t)3 * RL * h * sizeof(float), s, a, b, c,
                        g_cs_ws, m, h, RL);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((3 * h + 63) / 64), dim3(256), 0, s, g_cs_ws, nblk, h, oa, ob, oc);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((3 * h + 63) / 64), dim3(256), 0, s, g_cs_ws, nblk, h, oa, ob, oc, oa2, ob2, oc2);
     prof_end(PROF_COLSUM, bytes, s);
     GH_LAUNCH_CHECK();
     return 0;
   }
   prof_begin(s);
-  hipLaunchKernelGGL(colsum_kernel, dim3((m + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, s, a, b, c, oa, ob, oc, m, h);
+  hipLaunchKernelGGL(colsum_kernel, dim3((m + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, s, a, b, c, oa, ob, oc, oa2, ob2, oc2, m, h);
   prof_end(PROF_COLSUM, bytes, s);
   GH_LAUNCH_CHECK();
   return 0;
 }
 int launch_colsum(const float* a, float* oa, int m, int h, hipStream_t s) {
-  return launch_colsum3(a, nullptr, nullptr, oa, nullptr, nullptr, m, h, s);
+  return launch_colsum3(a, nullptr, nullptr, oa, nullptr, nullptr, m, h, s, nullptr, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------- row gather (embedding rows for the dW_proj GEMM)
@@ -530,6 +560,26 @@ extern "C" int gh_transpose(const float* w, float* wt, int rows, int cols, gh_st
   hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream, w,
                      wt, rows, cols);
   GH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gh_transpose_batch(int n, const void* const* src, void* const* dst, const int* rows, const int* cols,
+                                  gh_stream_t stream) {
+  for (int i0 = 0; i0 < n; i0 += 32) {
+    TransposeBatch B;
+    B.n = (n - i0 < 32) ? n - i0 : 32;
+    int tiles = 0;
+    for (int i = 0; i < B.n; ++i) {
+      GH_REQUIRE(rows[i0 + i] > 0 && cols[i0 + i] > 0, "transpose_batch: bad size at %d", i0 + i);
+      B.src[i] = (const float*)src[i0 + i]; B.dst[i] = (float*)dst[i0 + i];
+      B.rows[i] = rows[i0 + i]; B.cols[i] = cols[i0 + i];
+      B.tile0[i] = tiles;
+      tiles += ((rows[i0 + i] + 31) / 32) * ((cols[i0 + i] + 31) / 32);
+    }
+    B.tile0[B.n] = tiles;
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, B);
+    GH_LAUNCH_CHECK();
+  }
   return 0;
 }
 

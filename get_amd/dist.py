@@ -56,10 +56,14 @@ class FlatTrainer:
             p.data = self.flat_p[off:off + n].view_as(p)
             gv = self.flat_g[off:off + n].view_as(p)
             p.grad = gv
+            p._gh_direct_grad = True          # kernels may accumulate straight into this view (ops._direct)
             self._views.append(gv)
             off += n
         self.numel = total
         self.t = 0
+        # matrices whose transposed copy the forward GEMMs consume (everything but embedding tables)
+        emb_ids = {id(m.weight) for m in model.modules() if isinstance(m, torch.nn.Embedding)}
+        self._matrices = [p for p in self.params if p.dim() == 2 and id(p) not in emb_ids and min(p.shape) > 1]
 
     @property
     def world(self) -> int:
@@ -83,3 +87,4 @@ class FlatTrainer:
         self.t += 1
         ops.adam_step_flat(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.t, lr=self.lr, betas=self.betas,
                            eps=self.eps, weight_decay=self.weight_decay, grad_scale=1.0 / self.world)
+        ops.refresh_transposes(self._matrices)     # k-major copies for the next forward, one launch

@@ -24,6 +24,15 @@ def bump_weight_epoch():
     _WT_CACHE.clear()
 
 
+def _direct(p) -> bool:
+    """True when gradients of `p` may be accumulated by the kernels straight into `p.grad` (a live view of
+    the trainer's flat bucket, see dist.FlatTrainer) instead of being returned to autograd, which
+    would add them there with one extra elementwise kernel per parameter."""
+    g = getattr(p, "grad", None)
+    return (getattr(p, "_gh_direct_grad", False) and g is not None and g.dtype == torch.float32
+            and g.is_contiguous() and g.shape == p.shape)
+
+
 def _f32(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         t = t.float()
@@ -48,6 +57,25 @@ def transposed(w: torch.Tensor) -> torch.Tensor:
             del _WT_CACHE[k]
     _WT_CACHE[key] = (weakref.ref(w), w.data_ptr(), w._version, _WEIGHT_EPOCH, wt)
     return wt
+
+
+def refresh_transposes(weights):
+    """Transpose many weight matrices in ONE launch and prime the cache (called by the trainer right
+    after the optimiser step, so the next forward finds every k-major operand ready)."""
+    import ctypes
+    ws = [w for w in weights if w.dim() == 2]
+    if not ws:
+        return
+    n = len(ws)
+    wts = [torch.empty((w.shape[1], w.shape[0]), device=w.device, dtype=torch.float32) for w in ws]
+    src = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+    dst = (ctypes.c_void_p * n)(*[t.data_ptr() for t in wts])
+    rows = (ctypes.c_int * n)(*[w.shape[0] for w in ws])
+    cols = (ctypes.c_int * n)(*[w.shape[1] for w in ws])
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    call("gh_transpose_batch", n, cast(src), cast(dst), cast(rows), cast(cols), stream())
+    for w, wt in zip(ws, wts):
+        _WT_CACHE[id(w)] = (weakref.ref(w), w.data_ptr(), w._version, _WEIGHT_EPOCH, wt)
 
 
 # --------------------------------------------------------------------------- packed adjacency
@@ -174,6 +202,7 @@ class _GGNNCell(torch.autograd.Function):
              *[ptr(t) for t in wts], ptr(b_z), ptr(b_r), ptr(b_h),
              ptr(xp), ptr(a), ptr(z), ptr(rr), ptr(rx), ptr(hh), ptr(out), stream())
         ctx.adj, ctx.ids, ctx.dims = adj, ids, (n, r, din, h)
+        ctx.params = (w_p, w_z0, b_z0, w_z1, b_z1, w_r0, b_r0, w_r1, b_r1, w_h0, b_h0, w_h1, b_h1)
         ctx.save_for_backward(x, buf, *ws)
         ctx.x_needs_grad = ctx.needs_input_grad[0]
         return out.view(n, r, h)
@@ -192,14 +221,23 @@ class _GGNNCell(torch.autograd.Function):
         ids = ctx.ids
         want_dx = ctx.x_needs_grad
         dx = torch.empty((m, din), device=dev, dtype=torch.float32) if want_dx else None
-        dw_p = torch.zeros((h, din), device=dev, dtype=torch.float32)
-        dws = torch.zeros((6, h, h), device=dev, dtype=torch.float32)
-        dbs = torch.zeros((3, h), device=dev, dtype=torch.float32)
+        P = ctx.params
+        direct = all(_direct(p) for p in P)
+        if direct:     # weight/bias gradients land in the parameters' own .grad (flat bucket) -- no adds, no fills
+            pw_p, pz0, bz0, pz1, bz1, pr0, br0, pr1, br1, ph0, bh0, ph1, bh1 = (p.grad for p in P)
+            gw = [pw_p, pz0, pz1, pr0, pr1, ph0, ph1]
+            gb = [bz0, br0, bh0, bz1, br1, bh1]
+        else:
+            dw_p = torch.zeros((h, din), device=dev, dtype=torch.float32)
+            dws = torch.zeros((6, h, h), device=dev, dtype=torch.float32)
+            dbs = torch.zeros((3, h), device=dev, dtype=torch.float32)
+            gw = [dw_p] + [dws[i] for i in range(6)]
+            gb = [dbs[0], dbs[1], dbs[2], None, None, None]
         call("gh_ggnn_cell_bwd", *ctx.adj._args(), ptr(x), ptr(ids), n, r, din, h,
              ptr(w_p), ptr(w_z0), ptr(w_z1), ptr(w_r0), ptr(w_r1), ptr(w_h0), ptr(w_h1),
              ptr(xp), ptr(a), ptr(z), ptr(rr), ptr(rx), ptr(hh), ptr(g),
              ptr(dhp), ptr(dzp), ptr(drp), ptr(dxp), ptr(da),
-             ptr(dx), ptr(dw_p), *[ptr(dws[i]) for i in range(6)], ptr(dbs[0]), ptr(dbs[1]), ptr(dbs[2]), stream())
+             ptr(dx), *[ptr(t) for t in gw], *[ptr(t) for t in gb], stream())
         if want_dx:
             if ids is not None:      # trainable embedding table: scatter the row gradients
                 demb = torch.zeros_like(x)
@@ -207,6 +245,8 @@ class _GGNNCell(torch.autograd.Function):
                 dx = demb
             else:
                 dx = dx.view(x.shape)
+        if direct:
+            return (dx, None, None) + (None,) * 13
         dz0, dz1, dr0, dr1, dh0, dh1 = dws.unbind(0)
         bz, br, bh = dbs.unbind(0)
         return (dx, None, None, dw_p, dz0, bz, dz1, bz, dr0, br, dr1, br, dh0, bh, dh1, bh)
@@ -269,6 +309,7 @@ class _ConcatAtt(torch.autograd.Function):
         call("gh_concat_att_fwd", ptr(left), ptr(right), ptr(maskf), b, l, xl, dr, ha, heads, ptr(w1t), ptr(w2c),
              ptr(u), ptr(t), ptr(e), ptr(weights), ptr(attended), stream())
         ctx.dims = (b, l, xl, dr, ha, heads)
+        ctx.params = (w1, w2)
         ctx.has_left = left is not None
         ctx.save_for_backward(left if left is not None else right.new_empty(0), right, w1c, w2c, t, weights)
         return attended, weights
@@ -288,11 +329,17 @@ class _ConcatAtt(torch.autograd.Function):
         du = torch.empty((b, ha), device=dev, dtype=torch.float32)
         dleft = torch.empty((b, xl), device=dev, dtype=torch.float32) if left is not None else None
         dright = torch.empty((b, l, dr), device=dev, dtype=torch.float32)
-        dw1 = torch.zeros((ha, xl + dr), device=dev, dtype=torch.float32)
-        dw2 = torch.zeros((heads, ha), device=dev, dtype=torch.float32)
+        direct = all(_direct(p) for p in ctx.params)
+        if direct:
+            dw1, dw2 = ctx.params[0].grad, ctx.params[1].grad
+        else:
+            dw1 = torch.zeros((ha, xl + dr), device=dev, dtype=torch.float32)
+            dw2 = torch.zeros((heads, ha), device=dev, dtype=torch.float32)
         call("gh_concat_att_bwd", ptr(left), ptr(right), b, l, xl, dr, ha, heads, ptr(w1), ptr(w2), ptr(t),
              ptr(weights), ptr(g_att), ptr(g_w), ptr(de), ptr(dpre), ptr(du), ptr(dleft), ptr(dright), ptr(dw1),
              ptr(dw2), stream())
+        if direct:
+            return dleft, dright, None, None, None
         return dleft, dright, None, dw1, dw2
 
 
@@ -312,6 +359,7 @@ class _Linear(torch.autograd.Function):
         bc = _f32(b.detach()) if b is not None else None
         call("gh_linear_fwd", ptr(x2), ptr(transposed(w)), ptr(bc), ptr(y), m, k, n, stream())
         ctx.save_for_backward(x2, wc)
+        ctx.params = (w, b)
         ctx.has_bias = b is not None
         ctx.xshape = x.shape
         return y.view(*x.shape[:-1], n)
@@ -324,10 +372,18 @@ class _Linear(torch.autograd.Function):
         g2 = _f32(g).reshape(m, n)
         _lib.ensure_workspace(g.device)
         dx = torch.empty((m, k), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
-        dw = torch.zeros((n, k), device=g.device, dtype=torch.float32)
-        db = torch.zeros((n,), device=g.device, dtype=torch.float32) if ctx.has_bias else None
+        pw, pb = ctx.params
+        direct = _direct(pw) and (pb is None or _direct(pb))
+        if direct:
+            dw, db = pw.grad, (pb.grad if pb is not None else None)
+        else:
+            dw = torch.zeros((n, k), device=g.device, dtype=torch.float32)
+            db = torch.zeros((n,), device=g.device, dtype=torch.float32) if ctx.has_bias else None
         call("gh_linear_bwd", ptr(x2), ptr(w), ptr(g2), m, k, n, ptr(dx), ptr(dw), ptr(db), stream())
-        return (dx.view(ctx.xshape) if dx is not None else None), dw, db
+        dxo = dx.view(ctx.xshape) if dx is not None else None
+        if direct:
+            return dxo, None, None
+        return dxo, dw, db
 
 
 def linear(x, w, b=None):

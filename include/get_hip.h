@@ -64,6 +64,9 @@ int gh_spmm(const uint64_t* bits, const float* dinv, const float* vals, const ui
 
 /* ---- weight packing: W[n_out][n_in] -> Wt[n_in][n_out] (k-major operand of the MFMA GEMMs) ---- */
 int gh_transpose(const float* w, float* wt, int rows, int cols, gh_stream_t stream);
+/* All weights of a model in one launch: n matrices, HOST arrays of device pointers and sizes. */
+int gh_transpose_batch(int n, const void* const* src_host, void* const* dst_host, const int* rows_host,
+                       const int* cols_host, gh_stream_t stream);
 
 /* ---- a2  GGNN cell: Models/BiDAF/wrapper.py:188-208 GGNN.forward ----
  * Input rows are x[m][din] (m = n*r), or emb[ids[m]][din] when ids != NULL (fused
@@ -83,7 +86,9 @@ int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const float* vals,
 /* Backward of the cell.  w_*: the reference's UNtransposed weights [h][h] / w_p[h][din].
  * g [m][h] = dL/dout.  Scratch (all [m][h]): dhp, dzp, drp, dxp, da.
  * Outputs: dx [m][din] (may be NULL: frozen embedding), and ACCUMULATED (+=) into
- * dw_p[h][din], dw_z0..dw_h1 [h][h], db_z[h], db_r[h], db_h[h]  (caller zeroes them). */
+ * dw_p[h][din], dw_z0..dw_h1 [h][h], db_z[h], db_r[h], db_h[h]  (caller zeroes them, or hands the
+ * parameters' own .grad buffers).  b?0 and b?1 share one gradient: db_z1/db_r1/db_h1 (NULL ok) receive
+ * the same column sums, so both biases' .grad can be fed without a copy. */
 int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
                      const float* x, const int32_t* ids, int n, int r, int din, int h,
                      const float* w_p, const float* w_z0, const float* w_z1, const float* w_r0,
@@ -93,7 +98,7 @@ int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const float* vals,
                      float* dhp, float* dzp, float* drp, float* dxp, float* da,
                      float* dx, float* dw_p, float* dw_z0, float* dw_z1, float* dw_r0, float* dw_r1,
                      float* dw_h0, float* dw_h1, float* db_z, float* db_r, float* db_h,
-                     gh_stream_t stream);
+                     float* db_z1, float* db_r1, float* db_h1, gh_stream_t stream);
 
 /* ---- a2(300->1) + a3  word scorer + GSL top-k: wrapper.py:167-168, GSL.forward :215-227 ----
  * feat [n][r][h]; w_p[h] = scorer proj.linear.weight; gate[12] = {wz0,bz0,wz1,bz1,wr0,br0,wr1,br1,
