@@ -59,7 +59,6 @@ struct Launch {
   int m_tiles;   // max over problems of ceil(M / BM)
   int ksplit;    // TN: number of K chunks (1 otherwise)
   int kchunk;    // TN: rows per chunk, multiple of 16
-  int stagger;   // experiment knob: phase-shift the first round of workgroups (0 = off)
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }

@@ -189,13 +189,14 @@ gemm_fast_kernel(const Launch L_byval) {
   // swapped operands: acc[mi][ni][r] = C[row = wrow + mi*16 + l15][col = wcol + ni*16 + 4*q + r]
   // NV = number of valid 16-wide column tiles of this wave when known at compile time (NI or NI-1:
   // N = 300 leaves the last wave one tile short), -1 = guarded per tile (ragged M / N tails).
-  auto compute = [&](int buf, auto NVT) __attribute__((always_inline)) {
+  auto compute = [&](int buf, auto NVT, auto HALFT) __attribute__((always_inline)) {
     constexpr int NV = decltype(NVT)::value;
+    constexpr int S0 = decltype(HALFT)::value * 2;      // k-steps {0,1} or {2,3} of the tile
     const float* as = As + buf * BK * LDA + wrow + l15;
     const float* bs = Bs + buf * BK * LDB + wcol + l15;
     const int kq = 4 * q;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = S0; s < S0 + 2; ++s) {
       const int kr = s + kq;
       float a[2], b[NI];
 #pragma unroll
@@ -216,27 +217,23 @@ gemm_fast_kernel(const Launch L_byval) {
   };
   const int path = (mi_cnt == 2 && ni_cnt == NI) ? 0 : ((mi_cnt == 2 && ni_cnt == NI - 1) ? 1 : 2);
 
-  // Workgroups that start together on one CU would otherwise run their load / MFMA / barrier phases in
-  // lock-step and leave the matrix pipe idle in every barrier; shift the first round apart in time.
-  if (L.stagger) {
-    int ph = 0;
-    if (L.stagger == 1) ph = (bid >> 8) % 3;
-    else if (L.stagger == 2) ph = (bid >> 3) % 3;
-    else if (L.stagger == 3) ph = (int)((bid * 2654435761u) >> 30) % 3;
-    if (bid < 768 * 2) {
-      if (ph == 1) __builtin_amdgcn_s_sleep(40);
-      else if (ph == 2) { __builtin_amdgcn_s_sleep(40); __builtin_amdgcn_s_sleep(40); }
-    }
-  }
+  // Software pipeline, one barrier per K tile:
+  //   registers hold tile t+1 (loaded one iteration ago, so HBM/L2 latency has a whole tile to hide);
+  //   halfway through the MFMAs of tile t they are written to the other LDS buffer and the loads of
+  //   tile t+2 are issued, so the only thing left at the end of the tile is the barrier.
   load_tile(0);
   store_tile(0, 0);
+  if (T > 1) load_tile(1);
   __syncthreads();
   for (int t = 0; t < T; ++t) {
-    if (t + 1 < T) load_tile(t + 1);
-    if (path == 0) compute(t & 1, std::integral_constant<int, NI>{});
-    else if (path == 1) compute(t & 1, std::integral_constant<int, NI - 1>{});
-    else compute(t & 1, std::integral_constant<int, -1>{});
+    if (path == 0) compute(t & 1, std::integral_constant<int, NI>{}, std::integral_constant<int, 0>{});
+    else if (path == 1) compute(t & 1, std::integral_constant<int, NI - 1>{}, std::integral_constant<int, 0>{});
+    else compute(t & 1, std::integral_constant<int, -1>{}, std::integral_constant<int, 0>{});
     if (t + 1 < T) store_tile((t + 1) & 1, t + 1);
+    if (t + 2 < T) load_tile(t + 2);
+    if (path == 0) compute(t & 1, std::integral_constant<int, NI>{}, std::integral_constant<int, 1>{});
+    else if (path == 1) compute(t & 1, std::integral_constant<int, NI - 1>{}, std::integral_constant<int, 1>{});
+    else compute(t & 1, std::integral_constant<int, -1>{}, std::integral_constant<int, 1>{});
     __syncthreads();
   }
 

@@ -164,11 +164,7 @@ struct Batch {
     bn = big ? (big_cfg() == 0 ? GH_BN_BIG : 320) : GH_BN_SMALL;
     reset();
   }
-  void reset() {
-    static int stagger = -1;
-    if (stagger < 0) { const char* e = getenv("GH_GEMM_STAGGER"); stagger = e ? atoi(e) : 0; }
-    L.nprob = 0; L.m_tiles = 0; L.ksplit = 1; L.kchunk = 0; k_total = 0; L.stagger = stagger;
-  }
+  void reset() { L.nprob = 0; L.m_tiles = 0; L.ksplit = 1; L.kchunk = 0; k_total = 0; }
 
   void add(const Problem& p) {
     if (p.epi == EPI_ATT && p.N > bn) { err = hipErrorInvalidValue; return; }
