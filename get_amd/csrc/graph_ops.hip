@@ -3,6 +3,7 @@
 // no MFMA here by design.
 #include "../../include/get_hip.h"
 #include "common.h"
+#include <stdlib.h>
 
 namespace gh {
 
@@ -190,6 +191,132 @@ spmm_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, c
   }
 }
 
+// LDS-free variant for float4-shaped rows: every thread owns output float4s (row i, column c) of one
+// graph and gathers its neighbours' float4s straight from L1/L2 (neighbours of node i are almost always
+// the adjacent nodes, so the gathers hit lines its wave neighbours just touched).  No staging phase and
+// no barrier: ~8 independent 16-byte loads in flight per thread, 8 waves per SIMD.
+__global__ void __launch_bounds__(256)
+spmm_gather_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
+                   const uint64_t* __restrict__ keep, const float* __restrict__ x, float* __restrict__ y, int R, int H,
+                   int transpose, int accumulate, int blocks_per_graph) {
+  const int g = blockIdx.x / blocks_per_graph, part = blockIdx.x % blocks_per_graph;
+  const int W = (R + 63) / 64, H4 = H / 4;
+  const float4* xg = reinterpret_cast<const float4*>(x + (size_t)g * R * H);
+  float4* yg = reinterpret_cast<float4*>(y + (size_t)g * R * H);
+  const uint64_t* bg = bits + (size_t)g * R * W;
+  const uint64_t* kg = keep ? keep + (size_t)g * W : nullptr;
+  const float* dg = dinv ? dinv + (size_t)g * R : nullptr;
+  const float* vg = vals ? vals + (size_t)g * R * R : nullptr;
+  const int total = R * H4;
+  for (int it = part * 256 + threadIdx.x; it < total; it += blocks_per_graph * 256) {
+    const int i = it / H4, c = it % H4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float di = dg ? dg[i] : 0.f;
+    bool ki = true;
+    if (kg) ki = (kg[i >> 6] >> (i & 63)) & 1ull;
+    for (int w = 0; w < W; ++w) {
+      unsigned long long m = bg[(size_t)i * W + w];
+      if (kg && !ki) m &= kg[w];
+      // neighbours in batches of 8: collect the indices first (pure bit work), then issue all 16-byte
+      // gathers back to back so their latencies overlap instead of chaining
+      while (m) {
+        int nb[8];
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const bool on = m != 0ull;
+          nb[q] = on ? (w << 6) + __builtin_ctzll(m) : 0;
+          cnt += on;
+          m &= m - 1;                       // m == 0 stays 0
+        }
+        float4 xv[8];
+        float wt[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (q < cnt) {
+            xv[q] = xg[(size_t)nb[q] * H4 + c];
+            wt[q] = vg ? (transpose ? vg[(size_t)nb[q] * R + i] : vg[(size_t)i * R + nb[q]]) : di * dg[nb[q]];
+          }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (q < cnt) {
+            acc.x += wt[q] * xv[q].x; acc.y += wt[q] * xv[q].y; acc.z += wt[q] * xv[q].z; acc.w += wt[q] * xv[q].w;
+          }
+      }
+    }
+    float4* o = yg + (size_t)i * H4 + c;
+    if (accumulate) { const float4 p = *o; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+    *o = acc;
+  }
+}
+
+// Wave-per-row variant: the neighbour bit rows are wave-uniform (scalar registers, SALU bit walk), every
+// lane owns one or two float4 columns of the output row, neighbours are consumed four at a time so that
+// up to eight 16-byte gathers are in flight per lane with no divergence at all.
+template <int RPW>
+__global__ void __launch_bounds__(256)
+spmm_wave_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
+                 const uint64_t* __restrict__ keep, const float* __restrict__ x, float* __restrict__ y, int R, int H,
+                 int transpose, int accumulate, int waves_per_graph) {
+  const int lane = threadIdx.x & 63;
+  const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int g = gw / waves_per_graph, r0 = (gw % waves_per_graph) * RPW;
+  const int W = (R + 63) / 64, H4 = H / 4;
+  const float4* xg = reinterpret_cast<const float4*>(x + (size_t)g * R * H);
+  float4* yg = reinterpret_cast<float4*>(y + (size_t)g * R * H);
+  const uint64_t* bg = bits + (size_t)g * R * W;
+  const uint64_t* kg = keep ? keep + (size_t)g * W : nullptr;
+  const float* dg = dinv ? dinv + (size_t)g * R : nullptr;
+  const float* vg = vals ? vals + (size_t)g * R * R : nullptr;
+  const bool two = lane + 64 < H4;
+  for (int i = r0; i < min(R, r0 + RPW); ++i) {
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    const float di = dg ? dg[i] : 0.f;
+    bool ki = true;
+    if (kg) ki = (kg[i >> 6] >> (i & 63)) & 1ull;
+    for (int w = 0; w < W; ++w) {
+      unsigned long long m = bg[(size_t)i * W + w];
+      if (kg && !ki) m &= kg[w];
+      while (m) {
+        int nb[4];
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool on = m != 0ull;
+          nb[q] = on ? (w << 6) + __builtin_ctzll(m) : 0;
+          cnt += on;
+          m &= m - 1;
+        }
+        float4 v0[4], v1[4];
+        float wt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < cnt) {
+            if (lane < H4) v0[q] = xg[(size_t)nb[q] * H4 + lane];
+            if (two) v1[q] = xg[(size_t)nb[q] * H4 + lane + 64];
+            wt[q] = vg ? (transpose ? vg[(size_t)nb[q] * R + i] : vg[(size_t)i * R + nb[q]]) : di * dg[nb[q]];
+          }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q < cnt) {
+            a0.x += wt[q] * v0[q].x; a0.y += wt[q] * v0[q].y; a0.z += wt[q] * v0[q].z; a0.w += wt[q] * v0[q].w;
+            a1.x += wt[q] * v1[q].x; a1.y += wt[q] * v1[q].y; a1.z += wt[q] * v1[q].z; a1.w += wt[q] * v1[q].w;
+          }
+      }
+    }
+    if (lane < H4) {
+      float4* o = yg + (size_t)i * H4 + lane;
+      if (accumulate) { const float4 p = *o; a0.x += p.x; a0.y += p.y; a0.z += p.z; a0.w += p.w; }
+      *o = a0;
+    }
+    if (two) {
+      float4* o = yg + (size_t)i * H4 + lane + 64;
+      if (accumulate) { const float4 p = *o; a1.x += p.x; a1.y += p.y; a1.z += p.z; a1.w += p.w; }
+      *o = a1;
+    }
+  }
+}
+
 int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const float* x,
                 float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s) {
   GH_REQUIRE(r <= MAX_R, "spmm: padded graph size %d > %d", r, MAX_R);
@@ -207,8 +334,22 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   // algorithmic bytes: x in + y out (+ y in when accumulating) + bit rows + dinv (or the touched dense values)
   const double alg_bytes = (double)n * ((2.0 + (accumulate ? 1.0 : 0.0)) * r * h * 4.0 + (double)r * W * 8.0 +
                                         (vals ? (double)r * r * 4.0 : (double)r * 4.0));
+  // 0 (default): LDS-staged slab kernel -- every feature row leaves HBM exactly once (FETCH ~= algorithmic bytes);
+  // 1 / 2: LDS-free gather variants (thread-per-float4 / wave-per-row).  Measured equal or slower on MI355X: with
+  // ~8K waves in flight their sliding-window working set (~49 MB) thrashes the 32 MB of L2 (hit rate 32 %).
+  static int variant = -1;
+  if (variant < 0) { const char* e = getenv("GH_SPMM_VARIANT"); variant = e ? atoi(e) : 0; }
   prof_begin(s);
-  if (v4) {
+  if (v4 && variant == 2 && h / 4 <= 128) {
+    constexpr int RPW = 5;
+    const int wpg = (r + RPW - 1) / RPW;
+    hipLaunchKernelGGL(spmm_wave_kernel<RPW>, dim3((n * wpg + 3) / 4), dim3(256), 0, s, bits, dinv, vals, keep, x, y, r, h,
+                       transpose, accumulate, wpg);
+  } else if (v4 && variant == 1) {
+    const int bpg = (r * (h / 4) + 2047) / 2048;      // ~8 float4 outputs per thread
+    hipLaunchKernelGGL(spmm_gather_kernel, dim3(n * bpg), dim3(256), 0, s, bits, dinv, vals, keep, x, y, r, h, transpose,
+                       accumulate, bpg);
+  } else if (v4) {
     static bool attr4 = false;
     if (!attr4) { hipFuncSetAttribute((const void*)spmm_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr4 = true; }
     hipLaunchKernelGGL(spmm_kernel<4>, grid, dim3(256), lds, s, bits, dinv, vals, keep, x, y, r, h, slab, transpose, accumulate);
