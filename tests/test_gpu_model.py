@@ -147,3 +147,59 @@ def test_bench_shape_forward_backward_properties():
     sub = wl["oracle_slice"](4)
     phi_o = sub["phi"]
     assert float((phi[:4].detach().cpu() - phi_o).abs().max()) <= 1e-4
+
+
+def test_politifact_shaped_long_evidence_vs_oracle():
+    """BASELINE configs[2] shape (L_right=200, 10 evidences/claim) at reduced width: full model, native
+    graphs, HIP vs the CPU oracle (logits 1e-4, attention weights 1e-5, live gradients 1e-3)."""
+    from get_amd import ops
+    from get_amd.synth import SynthConfig
+    cfg = SynthConfig(batch=4, n_evd=10, len_right=200, emb_dim=64, hidden=64, vocab=500, n_article_src=30,
+                      n_claim_src=10, src_dim=16, word_heads=3, evd_heads=1, window=5, gsl_rate=0.8)
+    seed = 4242
+    model = build_model(cfg, seed)
+    raw = make_raw_batch(cfg, seed)
+    inp = assemble_inputs(raw, cfg, O.convert_text)
+    kargs = to_dev(reference_kargs(inp, torch, output_ranking=True))
+    da, d_ids, _ = ops.graph_build(torch.from_numpy(raw["evd_tokens"]).to(DEV), torch.from_numpy(raw["evd_len"]).to(DEV), cfg.window)
+    assert da.words == 4 and np.array_equal(d_ids.cpu().numpy(), inp["doc_ids"])
+    kargs["docs_adj"] = da
+    phi, (ww, ew) = model(torch.from_numpy(inp["query"]).to(DEV), torch.from_numpy(inp["document"]).to(DEV), **kargs)
+    torch.nn.functional.cross_entropy(phi, torch.from_numpy(inp["labels"]).to(DEV)).backward()
+    emb, art, clm = make_embeddings(cfg, seed)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    p = {k: T(v).requires_grad_(True) for k, v in make_state_dict(cfg, seed).items()}
+    p["embedding.weight"] = T(emb)
+    p["article_source_embs.weight"] = T(art).requires_grad_(True)
+    phi_o, ww_o, ew_o = O.model_forward(p, cfg.__dict__, T(inp["query"]), T(inp["document"]), T(inp["query_adj"]),
+                                        T(inp["doc_ids"]), T(inp["doc_adj"]), T(inp["query_lens"]), inp["evd_counts"],
+                                        T(inp["doc_sources"]), T(inp["query_sources"]))
+    O.cross_entropy(phi_o, T(inp["labels"])).backward()
+    assert float((phi.detach().cpu() - phi_o.detach()).abs().max()) <= 1e-4
+    assert float((ww.detach().cpu() - ww_o.detach()).abs().max()) <= 1e-5
+    assert float((ew.detach().cpu() - ew_o.detach()).abs().max()) <= 1e-5
+    for k, prm in model.named_parameters():
+        if k in p and p[k].grad is not None and prm.grad is not None:
+            go = p[k].grad
+            err = float((prm.grad.cpu() - go).abs().max())
+            assert err <= 1e-3 * float(go.abs().max()) + 1e-6, (k, err)
+
+
+def test_ragged_realistic_batch_properties():
+    """Evidence counts drawn U[1,30] (B1 not a multiple of any tile): weights sum to one, padded slots and
+    padded nodes get exactly zero attention, gradients finite, logits equal the oracle on a slice."""
+    from bench import build_workload
+    wl = build_workload(batch=16, n_evd=0, seed=77, device=DEV)
+    model = wl["model"].train(False)
+    phi, (ww, ew) = model(wl["query"], wl["document"], **dict(wl["kargs"], output_ranking=True))
+    counts = wl["raw"]["evd_counts"]
+    assert ww.shape[0] == int(counts.sum())
+    assert torch.allclose(ww.sum(1), torch.ones_like(ww.sum(1)), atol=1e-5)
+    assert torch.allclose(ew.sum(1), torch.ones_like(ew.sum(1)), atol=1e-5)
+    e = ew.detach().cpu().numpy()
+    for b, c in enumerate(counts):
+        assert np.all(e[b, c:] == 0)
+    torch.nn.functional.cross_entropy(phi, wl["labels"]).backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    sub = wl["oracle_slice"](3)
+    assert float((phi[:3].detach().cpu() - sub["phi"]).abs().max()) <= 1e-4
