@@ -57,6 +57,6 @@ int launch_att_softmax_fwd(const float* e, const float* mask, const float* right
 int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w, int b,
                            int l, int dr, int heads, float* de, float* dright, hipStream_t s);
 int launch_att_dpre(const float* de, const float* w2, const float* t, int b, int l, int ha, int heads, float* dpre,
-                    float* du, hipStream_t s);
+                    float* du, float* dw2_part, hipStream_t s);
 
 }  // namespace gh

@@ -450,7 +450,17 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, int b, i
   if (!left) xl = 0;
   const int ldw = xl + dr;
   if (int e = launch_att_softmax_bwd(right, weights, g_att, g_w, b, l, dr, heads, de, dright, s)) return e;
-  if (int e = launch_att_dpre(de, w2, t, b, l, ha, heads, dpre, du, s)) return e;
+  // dW2 = de^T t rides along with the dpre pass (per-pair partials in the workspace, one reduce)
+  const size_t dw2_bytes = (size_t)b * heads * ha * sizeof(float);
+  float* dw2_part = (g_ws && dw2_bytes <= g_ws_bytes && ha % 4 == 0) ? g_ws : nullptr;
+  if (int e = launch_att_dpre(de, w2, t, b, l, ha, heads, dpre, du, dw2_part, s)) return e;
+  if (dw2_part) {
+    ReduceArgs R;
+    R.n = 1;
+    R.it[0] = ReduceItem{dw2_part, dw2, heads, ha, ha, b, (long long)heads * ha};
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((heads * (ha / 4) + 255) / 256, 1), dim3(256), 0, s, R);
+    GH_LAUNCH_CHECK();
+  }
   {  // dright += dpre W1[:, xl:]
     Batch bt(false, M, s);
     Problem p = gemm_problem(M, dr, EPI_STORE, dright, dr, dpre, ha, w1 + xl, ldw, ha);
@@ -471,7 +481,7 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, int b, i
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }
-  {  // own launch: `heads` rows are not float4-shaped, so this one takes the generic kernel
+  if (!dw2_part) {  // no workspace: `heads` rows are not float4-shaped, so this one takes the generic kernel
     Batch bt(true, M, s);
     bt.add(tn_problem(heads, ha, dw2, ha, de, heads, t, ha, M));
     bt.flush();

@@ -297,31 +297,52 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
   __syncthreads();
   if (blockIdx.y == 0)
     for (int i = tid; i < L * C; i += 256) weights[(size_t)b * L * C + i] = ws[i];
-  const int d = blockIdx.y * 256 + tid;
-  if (d < Dr) {
-    float acc[8];
+  // attended[d][c] = sum_l right[l][d] w[l][c]: blockIdx.y owns a slab of 64 float4 columns, the four
+  // waves take every fourth row (16-byte coalesced reads), partial sums meet in LDS
+  float* part = ws + L * C;                      // [4][64][4][C] floats
+  const int D4 = Dr / 4;
+  const int d4 = blockIdx.y * 64 + lane;
+  float acc[4][8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
-    const float* rb = right + (size_t)b * L * Dr + d;
-    for (int l = 0; l < L; ++l) {
-      const float rv = rb[(size_t)l * Dr];
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
+  if (d4 < D4) {
+    const float4* rb = reinterpret_cast<const float4*>(right + (size_t)b * L * Dr) + d4;
+    for (int l = wave; l < L; l += 4) {
+      const float4 rv = rb[(size_t)l * D4];
 #pragma unroll
       for (int c = 0; c < 8; ++c)
-        if (c < C) acc[c] += rv * ws[l * C + c];
+        if (c < C) {
+          const float w = ws[l * C + c];
+          acc[0][c] += rv.x * w; acc[1][c] += rv.y * w; acc[2][c] += rv.z * w; acc[3][c] += rv.w * w;
+        }
     }
-    float* o = attended + ((size_t)b * Dr + d) * C;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
 #pragma unroll
     for (int c = 0; c < 8; ++c)
-      if (c < C) o[c] = acc[c];
+      if (c < C) part[((wave * 64 + lane) * 4 + k) * C + c] = acc[k][c];
+  __syncthreads();
+  for (int i = tid; i < 64 * 4 * C; i += 256) {
+    const int ln = i / (4 * C), rem = i % (4 * C);     // rem = k*C + c -> output offset within the float4 column group
+    const int dd = (blockIdx.y * 64 + ln) * 4 + rem / C;
+    if (dd < Dr) {
+      float v = 0.f;
+      for (int w = 0; w < 4; ++w) v += part[((w * 64 + ln) * 4) * C + rem];
+      attended[((size_t)b * Dr + dd) * C + rem % C] = v;
+    }
   }
 }
 
 int launch_att_softmax_fwd(const float* e, const float* mask, const float* right, int b, int l, int dr, int heads,
                            float* weights, float* attended, hipStream_t s) {
-  const size_t lds = (size_t)l * heads * 4;
+  GH_REQUIRE(dr % 4 == 0 && (reinterpret_cast<uintptr_t>(right) & 15) == 0, "att_softmax_fwd: right rows must be float4-shaped (dr=%d)", dr);
+  const size_t lds = ((size_t)l * heads + 4 * 64 * 4 * heads) * 4;
   GH_REQUIRE(lds <= 64 * 1024, "att_softmax_fwd: sequence %d x heads %d too large", l, heads);
   prof_begin(s);
-  hipLaunchKernelGGL(att_softmax_fwd_kernel, dim3(b, (dr + 255) / 256), dim3(256), lds, s, e, mask, right, l, dr,
+  hipLaunchKernelGGL(att_softmax_fwd_kernel, dim3(b, (dr / 4 + 63) / 64), dim3(256), lds, s, e, mask, right, l, dr,
                      heads, weights, attended);
   prof_end(PROF_ATT_SOFTMAX_FWD, 4.0 * (double)b * ((double)l * dr + 2.0 * l * heads + l + (double)dr * heads), s);
   GH_LAUNCH_CHECK();
@@ -342,23 +363,25 @@ att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict_
   for (int i = tid; i < Dr * C; i += 256) ga[i] = g_att[(size_t)b * Dr * C + i];
   for (int i = tid; i < L * C; i += 256) ws[i] = weights[(size_t)b * L * C + i];
   __syncthreads();
+  const int D4 = Dr / 4;
   for (int l = wave; l < L; l += 4) {
     float part[8], wl[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) { part[c] = 0.f; wl[c] = (c < C) ? ws[l * C + c] : 0.f; }
-    const float* rr = right + ((size_t)b * L + l) * Dr;
-    float* dr_ = dright + ((size_t)b * L + l) * Dr;
-    for (int d = lane; d < Dr; d += 64) {
-      const float rv = rr[d];
-      float acc = 0.f;
+    const float4* rr = reinterpret_cast<const float4*>(right + ((size_t)b * L + l) * Dr);
+    float4* dr_ = reinterpret_cast<float4*>(dright + ((size_t)b * L + l) * Dr);
+    for (int d4 = lane; d4 < D4; d4 += 64) {
+      const float4 rv = rr[d4];
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float* g4 = ga + (size_t)d4 * 4 * C;
 #pragma unroll
       for (int c = 0; c < 8; ++c)
         if (c < C) {
-          const float gv = ga[d * C + c];
-          acc += wl[c] * gv;
-          part[c] += rv * gv;
+          const float g0 = g4[c], g1 = g4[C + c], g2 = g4[2 * C + c], g3 = g4[3 * C + c];
+          acc.x += wl[c] * g0; acc.y += wl[c] * g1; acc.z += wl[c] * g2; acc.w += wl[c] * g3;
+          part[c] += rv.x * g0 + rv.y * g1 + rv.z * g2 + rv.w * g3;
         }
-      dr_[d] = acc;
+      dr_[d4] = acc;
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -379,6 +402,8 @@ att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict_
 
 int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w, int b,
                            int l, int dr, int heads, float* de, float* dright, hipStream_t s) {
+  GH_REQUIRE(dr % 4 == 0 && (reinterpret_cast<uintptr_t>(right) & 15) == 0 && (reinterpret_cast<uintptr_t>(dright) & 15) == 0,
+             "att_softmax_bwd: right rows must be float4-shaped (dr=%d)", dr);
   const size_t lds = ((size_t)dr * heads + 2 * (size_t)l * heads) * 4;
   GH_REQUIRE(lds <= 160 * 1024, "att_softmax_bwd: %zu B of LDS needed", lds);
   static bool attr = false;
@@ -391,35 +416,68 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
   return 0;
 }
 
-// dpre[m][n] = (sum_c de[m][c] w2[c][n]) (1 - t[m][n]^2) ; du[b][n] = sum_l dpre[b*L+l][n]
-__global__ void __launch_bounds__(256)
-att_dpre_kernel(const float* __restrict__ de, const float* __restrict__ w2, const float* __restrict__ t, int L,
-                int Ha, int C, float* __restrict__ dpre, float* __restrict__ du) {
+// dpre[m][n] = (sum_c de[m][c] w2[c][n]) (1 - t[m][n]^2) ; du[b][n] = sum_l dpre[b*L+l][n] ;
+// dw2 partial [b][c][n] = sum_l de[m][c] t[m][n]   (summed over b by reduce_partials afterwards).
+// One workgroup per pair: threads = (float4 column, row lane); row lanes take every RL-th row.
+__global__ void att_dpre_kernel(const float* __restrict__ de, const float* __restrict__ w2, const float* __restrict__ t,
+                                int L, int Ha, int C, int RL, float* __restrict__ dpre, float* __restrict__ du,
+                                float* __restrict__ dw2_part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  float4* red = reinterpret_cast<float4*>(dsm);           // [RL][1 + C][n4]
   const int b = blockIdx.x;
-  const int n = blockIdx.y * 256 + threadIdx.x;
-  if (n >= Ha) return;
-  float wc[8];
+  const int n4 = Ha / 4;
+  const int c4 = threadIdx.x % n4, rl = threadIdx.x / n4;
+  float4 wc[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) wc[c] = (c < C) ? w2[c * Ha + n] : 0.f;
-  float acc = 0.f;
-  for (int l = 0; l < L; ++l) {
-    const size_t m = (size_t)b * L + l;
-    float dt = 0.f;
+  for (int c = 0; c < 8; ++c) wc[c] = (c < C && rl < RL) ? reinterpret_cast<const float4*>(w2 + (size_t)c * Ha)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 dw[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) dw[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rl < RL) {
+    for (int l = rl; l < L; l += RL) {
+      const size_t m = (size_t)b * L + l;
+      const float4 tv = reinterpret_cast<const float4*>(t + m * Ha)[c4];
+      float4 dt = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < C) {
+          const float e = de[m * C + c];
+          dt.x += e * wc[c].x; dt.y += e * wc[c].y; dt.z += e * wc[c].z; dt.w += e * wc[c].w;
+          dw[c].x += e * tv.x; dw[c].y += e * tv.y; dw[c].z += e * tv.z; dw[c].w += e * tv.w;
+        }
+      const float4 dp = make_float4(dt.x * (1.f - tv.x * tv.x), dt.y * (1.f - tv.y * tv.y), dt.z * (1.f - tv.z * tv.z),
+                                    dt.w * (1.f - tv.w * tv.w));
+      reinterpret_cast<float4*>(dpre + m * Ha)[c4] = dp;
+      acc.x += dp.x; acc.y += dp.y; acc.z += dp.z; acc.w += dp.w;
+    }
+    red[(rl * (1 + C) + 0) * n4 + c4] = acc;
 #pragma unroll
     for (int c = 0; c < 8; ++c)
-      if (c < C) dt += de[m * C + c] * wc[c];
-    const float tv = t[m * Ha + n];
-    const float dp = dt * (1.f - tv * tv);
-    dpre[m * Ha + n] = dp;
-    acc += dp;
+      if (c < C) red[(rl * (1 + C) + 1 + c) * n4 + c4] = dw[c];
   }
-  du[(size_t)b * Ha + n] = acc;
+  __syncthreads();
+  for (int i = threadIdx.x; i < (1 + C) * n4; i += blockDim.x) {
+    const int which = i / n4, cc = i % n4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < RL; ++k) {
+      const float4 x = red[(k * (1 + C) + which) * n4 + cc];
+      v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+    }
+    if (which == 0) reinterpret_cast<float4*>(du + (size_t)b * Ha)[cc] = v;
+    else if (dw2_part) reinterpret_cast<float4*>(dw2_part + ((size_t)b * C + (which - 1)) * Ha)[cc] = v;
+  }
 }
 
 int launch_att_dpre(const float* de, const float* w2, const float* t, int b, int l, int ha, int heads, float* dpre,
-                    float* du, hipStream_t s) {
+                    float* du, float* dw2_part, hipStream_t s) {
+  GH_REQUIRE(ha % 4 == 0 && ha / 4 <= 256, "att_dpre: attention hidden %d must be a multiple of 4 and <= 1024", ha);
+  const int n4 = ha / 4;
+  const int RL = (256 / n4) > 0 ? (256 / n4) : 1;
+  const int threads = ((n4 * RL + 63) / 64) * 64;
+  const size_t lds = (size_t)RL * (1 + heads) * n4 * 16;
   prof_begin(s);
-  hipLaunchKernelGGL(att_dpre_kernel, dim3(b, (ha + 255) / 256), dim3(256), 0, s, de, w2, t, l, ha, heads, dpre, du);
+  hipLaunchKernelGGL(att_dpre_kernel, dim3(b), dim3(threads), lds, s, de, w2, t, l, ha, heads, RL, dpre, du, dw2_part);
   prof_end(PROF_ATT_DPRE, 4.0 * (double)b * (2.0 * l * ha + (double)l * heads + ha), s);
   GH_LAUNCH_CHECK();
   return 0;
