@@ -161,7 +161,7 @@ struct Batch {
   Batch(bool tn_, int rows_hint, hipStream_t s_) : tn(tn_), s(s_) {
     big = tn_ || rows_hint >= 8192;
     bm = big ? (big_cfg() == 0 ? 128 : 64) : 32;
-    bn = big ? (big_cfg() == 0 ? GH_BN_BIG : 320) : GH_BN_SMALL;
+    bn = big ? (big_cfg() == 0 ? GH_BN_BIG : (big_cfg() == 3 ? 160 : 320)) : GH_BN_SMALL;
     reset();
   }
   void reset() { L.nprob = 0; L.m_tiles = 0; L.ksplit = 1; L.kchunk = 0; k_total = 0; }
@@ -236,7 +236,8 @@ struct Batch {
 
   hipError_t launch_any() {
     return !big ? launch_cfg<1, 4, 5>(L, tn, s)
-                : (big_cfg() == 0 ? launch_cfg<4, 1, 19>(L, tn, s) : launch_cfg<2, 2, 10>(L, tn, s));
+                : (big_cfg() == 0 ? launch_cfg<4, 1, 19>(L, tn, s)
+                   : (big_cfg() == 3 ? launch_cfg<2, 2, 5>(L, tn, s) : launch_cfg<2, 2, 10>(L, tn, s)));
   }
 
   // Few-row NT GEMMs (evidence level, head): too few row tiles to fill 256 CUs, so split K across
