@@ -17,6 +17,7 @@ _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
 _L = ctypes.c_int64
+_U = ctypes.c_uint32
 
 # name -> argtypes (mirrors include/get_hip.h; tests/test_abi.py checks the two agree)
 SIGNATURES = {
@@ -26,9 +27,9 @@ SIGNATURES = {
     "gh_spmm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gh_transpose": [_P, _P, _I, _I, _P],
     "gh_transpose_batch": [_I, _P, _P, _P, _P, _P],
-    "gh_ggnn_cell_fwd": [_P] * 6 + [_I] * 4 + [_P] * 10 + [_P] * 7 + [_P],
-    "gh_ggnn_cell_bwd": [_P] * 6 + [_I] * 4 + [_P] * 7 + [_P] * 7 + [_P] * 5 + [_P] * 14 + [_P],
-    "gh_scorer_gsl": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "gh_ggnn_cell_fwd": [_P] * 6 + [_I] * 4 + [_P] * 10 + [_P] * 7 + [_F, _U, _P],
+    "gh_ggnn_cell_bwd": [_P] * 6 + [_I] * 4 + [_P] * 7 + [_P] * 7 + [_P] * 5 + [_P] * 14 + [_F, _U, _P],
+    "gh_scorer_gsl": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _U, _P],
     "gh_gsl_topk": [_P, _I, _I, _I, _P, _P],
     "gh_adj_unpack": [_P, _P, _P, _P, _I, _I, _P, _P],
     "gh_concat_att_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -51,7 +51,8 @@ int launch_colsum3(const float* a, const float* b, const float* c, float* oa, fl
                    hipStream_t s, float* oa2 = nullptr, float* ob2 = nullptr, float* oc2 = nullptr);
 int launch_colsum(const float* a, float* oa, int m, int h, hipStream_t s);
 void set_colsum_workspace(float* p, size_t bytes);
-int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m, int d, hipStream_t s);
+int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m, int d, hipStream_t s,
+                       float drop_p = 0.f, unsigned drop_seed = 0);
 int launch_att_softmax_fwd(const float* e, const float* mask, const float* right, int b, int l, int dr, int heads,
                            float* weights, float* attended, hipStream_t s);
 int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w, int b,

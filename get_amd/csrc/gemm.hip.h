@@ -50,6 +50,12 @@ struct Problem {
   const float* in0; const float* in1;   // same leading dimension as C
   const float* u; const float* w2; float* e; int ldu; int R; int heads;
   long long split_stride;   // TN: element offset of K-chunk `ks`'s partial tile (0 = all chunks hit C, atomically)
+  // stateless input dropout (wrapper.py:189-190): element (row, col) of the dropped matrix [rows][drop_ld] is kept
+  // iff hash(seed, row*drop_ld + col) >= drop_thresh and then scaled by drop_scale = 1/(1-p).
+  // drop_mode: 0 off, 1 = A of segment 0 (NT), 3 = C in the EPI_STORE epilogue (gradient w.r.t. the dropped
+  //            input).  Fast kernel only.  (The weight-gradient GEMM gets its masked operand from gather_rows:
+  //            hashing in the TN loader pushed that kernel over 168 VGPRs, i.e. from 3 to 2 waves per SIMD.)
+  int drop_mode; int drop_ld; int drop_col0; unsigned drop_seed; unsigned drop_thresh; float drop_scale;
 };
 
 #define GH_MAX_PROBLEMS 8
@@ -60,6 +66,19 @@ struct Launch {
   int ksplit;    // TN: number of K chunks (1 otherwise)
   int kchunk;    // TN: rows per chunk, multiple of 16
 };
+
+__host__ __device__ __forceinline__ unsigned drop_hash(unsigned seed, unsigned idx) {
+  unsigned x = idx * 0x9E3779B1u + seed;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float4 drop4(float4 v, unsigned seed, unsigned idx, unsigned thresh, float scale) {
+  v.x = drop_hash(seed, idx + 0) >= thresh ? v.x * scale : 0.f;
+  v.y = drop_hash(seed, idx + 1) >= thresh ? v.y * scale : 0.f;
+  v.z = drop_hash(seed, idx + 2) >= thresh ? v.z * scale : 0.f;
+  v.w = drop_hash(seed, idx + 3) >= thresh ? v.w * scale : 0.f;
+  return v;
+}
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {

@@ -115,6 +115,10 @@ gemm_fast_kernel(const Launch L_byval) {
 
   float4 ra[NA], rb[NB];
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int drop_mode = P.drop_mode;
+  const unsigned drop_seed = P.drop_seed, drop_thresh = P.drop_thresh;
+  const float drop_scale = P.drop_scale;
+  const int drop_ld = P.drop_ld, drop_col0 = P.drop_col0;
 
   // Tile addressing shared by the load (issue) and store (mask + LDS write) halves.
   struct TileAddr { const float* Ab; const float* Bb; int ldb, k0, klim; bool s1; };
@@ -161,7 +165,9 @@ gemm_fast_kernel(const Launch L_byval) {
         if (!TN) {
           const int row = idx >> 2, kq = idx & 3;
           const bool ok = a_ok[j] && (a.k0 + 4 * kq < a.klim);
-          const float4 v = ok ? ra[j] : zero4;
+          float4 v = ok ? ra[j] : zero4;
+          if (drop_mode == 1 && !a.s1)
+            v = drop4(v, drop_seed, (unsigned)(m0 + row) * (unsigned)drop_ld + (unsigned)(a.k0 + 4 * kq), drop_thresh, drop_scale);
           as[(4 * kq + 0) * LDA + row] = v.x;
           as[(4 * kq + 1) * LDA + row] = v.y;
           as[(4 * kq + 2) * LDA + row] = v.z;
@@ -324,6 +330,8 @@ gemm_fast_kernel(const Launch L_byval) {
           v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
         }
         if (epi == EPI_STORE) {
+          if (drop_mode == 3)
+            v = drop4(v, drop_seed, (unsigned)row * (unsigned)drop_ld + (unsigned)(drop_col0 + col), drop_thresh, drop_scale);
           if (accumulate) {
             const float4 p = *reinterpret_cast<const float4*>(C + o);
             v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;

@@ -28,6 +28,11 @@ static bool fast_ok(const Launch& L, bool tn) {
   }
   return true;
 }
+static bool wants_dropout(const Launch& L) {
+  for (int i = 0; i < L.nprob; ++i)
+    if (L.p[i].drop_mode) return true;
+  return false;
+}
 
 template <int WM, int WN, int NI>
 static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
@@ -41,7 +46,9 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
       for (int j = 0; j < L.p[i].nseg; ++j) flops += 2.0 * L.p[i].M * L.p[i].N * (double)L.p[i].seg[j].K;
     prof_begin(s);
   }
-  if (fast_ok(L, tn)) {
+  const bool fast = fast_ok(L, tn);
+  if (!fast && wants_dropout(L)) return hipErrorInvalidValue;     // fused dropout exists in the fast kernel only
+  if (fast) {
     if (tn) hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, true>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
     else hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, false>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
   } else {
@@ -176,6 +183,7 @@ struct Batch {
         q.seg[i].vecB = vec_ok(q.seg[i].B, q.seg[i].ldb, q.N);
       }
       q.C += n0;
+      q.drop_col0 = p.drop_col0 + n0;
       if (q.bias) q.bias += n0;
       if (q.out1) q.out1 += n0;
       if (q.in0) q.in0 += n0;
@@ -248,7 +256,7 @@ struct Batch {
     int kmax = 0;
     for (int i = 0; i < L.nprob; ++i) {
       const Problem& q = L.p[i];
-      if (q.nseg != 1 || (q.epi != EPI_STORE && q.epi != EPI_ATT)) return false;
+      if (q.nseg != 1 || (q.epi != EPI_STORE && q.epi != EPI_ATT) || q.drop_mode == 3) return false;
       if (q.seg[0].K > kmax) kmax = q.seg[0].K;
     }
     int ks = kmax / 64;
@@ -296,6 +304,13 @@ static Problem gemm_problem(int M, int N, int epi, float* C, int ldc, const floa
 static void add_seg(Problem& p, const float* A, int lda, const float* B, int ldb, int K) {
   p.seg[p.nseg++] = make_seg(A, lda, B, ldb, K, p.N);
 }
+static void set_dropout(Problem& p, int mode, int ld, float drop_p, unsigned seed) {
+  if (drop_p <= 0.f) return;
+  p.drop_mode = mode; p.drop_ld = ld; p.drop_col0 = 0; p.drop_seed = seed;
+  const double t = (double)drop_p * 4294967296.0;
+  p.drop_thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+  p.drop_scale = 1.0f / (1.0f - drop_p);
+}
 static Problem tn_problem(int I, int J, float* C, int ldc, const float* A, int lda, const float* B, int ldb, int K,
                           const int32_t* gatherB = nullptr) {
   Problem p = make_problem(I, J, EPI_ATOMIC, C, ldc);
@@ -313,14 +328,18 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
                                 const float* wt_r1, const float* wt_h0, const float* wt_h1,
                                 const float* b_z, const float* b_r, const float* b_h,
                                 float* xp, float* a, float* z, float* rr, float* rx, float* hh, float* out,
-                                gh_stream_t stream) {
+                                float drop_p, uint32_t drop_seed, gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const int M = n * r;
   GH_REQUIRE(n > 0 && r > 0 && din > 0 && h > 0, "ggnn_cell_fwd: bad sizes n=%d r=%d din=%d h=%d", n, r, din, h);
-  {  // xp = x Wp^T   (wrapper.py:191), embedding rows gathered in the A loader when ids != NULL
+  GH_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ggnn_cell_fwd: dropout p=%f not in [0,1)", drop_p);
+  {  // xp = dropout(x) Wp^T   (wrapper.py:189-191); embedding rows gathered and the dropout mask applied in the A loader
     Batch b(false, M, s);
-    b.add(gemm_problem(M, h, EPI_STORE, xp, h, x, din, wt_p, h, din, ids));
+    Problem p = gemm_problem(M, h, EPI_STORE, xp, h, x, din, wt_p, h, din, ids);
+    set_dropout(p, 1, din, drop_p, drop_seed);
+    b.add(p);
     b.flush();
+    GH_REQUIRE(b.err != hipErrorInvalidValue || drop_p == 0.f, "ggnn_cell_fwd: fused dropout needs float4-shaped rows (din=%d, h=%d)", din, h);
     GH_CHECK_HIP(b.err);
   }
   if (int e = launch_spmm(bits, dinv, vals, keep, xp, a, n, r, h, 0, 0, s)) return e;   // a = A_hat xp (:192)
@@ -357,7 +376,8 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
                                 float* dhp, float* dzp, float* drp, float* dxp, float* da,
                                 float* dx, float* dw_p, float* dw_z0, float* dw_z1, float* dw_r0, float* dw_r1,
                                 float* dw_h0, float* dw_h1, float* db_z, float* db_r, float* db_h,
-                                float* db_z1, float* db_r1, float* db_h1, gh_stream_t stream) {
+                                float* db_z1, float* db_r1, float* db_h1, float drop_p, uint32_t drop_seed,
+                                gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const int M = n * r;
   GH_REQUIRE(n > 0 && r > 0 && din > 0 && h > 0, "ggnn_cell_bwd: bad sizes");
@@ -385,9 +405,11 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
     GH_CHECK_HIP(b.err);
   }
   if (int e = launch_spmm(bits, dinv, vals, keep, da, dxp, n, r, h, 1, 1, s)) return e;   // dxp += A_hat^T da
-  if (dx) {  // dx = dxp Wp
+  if (dx) {  // dx = (dxp Wp) . mask/(1-p)
     Batch b(false, M, s);
-    b.add(gemm_problem(M, din, EPI_STORE, dx, din, dxp, h, w_p, din, h));
+    Problem p = gemm_problem(M, din, EPI_STORE, dx, din, dxp, h, w_p, din, h);
+    set_dropout(p, 3, din, drop_p, drop_seed);
+    b.add(p);
     b.flush();
     GH_CHECK_HIP(b.err);
   }
@@ -399,11 +421,13 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
     b.add(tn_problem(h, h, dw_r1, h, drp, h, xp, h, M));
     b.add(tn_problem(h, h, dw_h0, h, dhp, h, a, h, M));
     b.add(tn_problem(h, h, dw_h1, h, dhp, h, rx, h, M));
-    if (ids && din <= h) {
-      // embedding rows materialised once into the (now free) `da` scratch, so the split-K GEMM streams them
-      if (int e = launch_gather_rows(x, ids, da, M, din, s)) return e;
+    if ((ids || drop_p > 0.f) && din <= h) {
+      // operand rows materialised once into the (now free) `da` scratch -- embedding gather and/or the forward's
+      // dropout mask applied in that one streaming pass -- so the split-K GEMM loader stays a plain copy
+      if (int e = launch_gather_rows(x, ids, da, M, din, s, drop_p, drop_seed)) return e;
       b.add(tn_problem(h, din, dw_p, din, dxp, h, da, din, M));
     } else {
+      GH_REQUIRE(drop_p == 0.f, "ggnn_cell_bwd: fused dropout needs din (%d) <= h (%d)", din, h);
       b.add(tn_problem(h, din, dw_p, din, dxp, h, x, din, M, ids));
     }
     b.flush();

@@ -3,6 +3,7 @@
 // no MFMA here by design.
 #include "../../include/get_hip.h"
 #include "common.h"
+#include "gemm.hip.h"
 #include <stdlib.h>
 
 namespace gh {
@@ -387,7 +388,8 @@ __device__ __forceinline__ void topk_keep(const float* ss, int R, int k, uint64_
 __global__ void __launch_bounds__(256)
 scorer_gsl_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
                   const float* __restrict__ feat, const float* __restrict__ w_p, const float* __restrict__ gate,
-                  int R, int H, int k, float* __restrict__ score, uint64_t* __restrict__ keep) {
+                  int R, int H, int k, float* __restrict__ score, uint64_t* __restrict__ keep, unsigned drop_thresh,
+                  float drop_scale, unsigned drop_seed) {
   __shared__ float xs[MAX_R];
   __shared__ float ss[MAX_R];
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -401,11 +403,17 @@ scorer_gsl_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ d
       const float4* fr = reinterpret_cast<const float4*>(fg + (size_t)j * H);
       const float4* wr = reinterpret_cast<const float4*>(w_p);
       for (int c = lane; c < H / 4; c += 64) {
-        const float4 a = fr[c], b = wr[c];
+        float4 a = fr[c];
+        const float4 b = wr[c];
+        if (drop_thresh) a = drop4(a, drop_seed, (unsigned)(g * R + j) * (unsigned)H + 4u * c, drop_thresh, drop_scale);
         acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
       }
     } else {
-      for (int c = lane; c < H; c += 64) acc += fg[(size_t)j * H + c] * w_p[c];
+      for (int c = lane; c < H; c += 64) {
+        float a = fg[(size_t)j * H + c];
+        if (drop_thresh) a = drop_hash(drop_seed, (unsigned)(g * R + j) * (unsigned)H + c) >= drop_thresh ? a * drop_scale : 0.f;
+        acc += a * w_p[c];
+      }
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if (lane == 0) xs[j] = acc;
@@ -498,13 +506,16 @@ extern "C" int gh_spmm(const uint64_t* bits, const float* dinv, const float* val
 
 extern "C" int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const float* feat,
                              const float* w_p, const float* gate, int n, int r, int h, int k, float* score,
-                             uint64_t* keep, gh_stream_t stream) {
+                             uint64_t* keep, float drop_p, uint32_t drop_seed, gh_stream_t stream) {
   GH_REQUIRE(r > 0 && r <= MAX_R, "scorer_gsl: r=%d not in [1,%d]", r, MAX_R);
   GH_REQUIRE(vals || dinv, "scorer_gsl: need dinv or vals");
   if (n <= 0) return 0;
   prof_begin((hipStream_t)stream);
+  GH_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "scorer_gsl: dropout p=%f not in [0,1)", drop_p);
+  const double th = (double)drop_p * 4294967296.0;
+  const unsigned thresh = drop_p > 0.f ? (th >= 4294967295.0 ? 4294967295u : (unsigned)th) : 0u;
   hipLaunchKernelGGL(scorer_gsl_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, bits, dinv, vals, feat, w_p,
-                     gate, r, h, k, score, keep);
+                     gate, r, h, k, score, keep, thresh, 1.0f / (1.0f - drop_p), drop_seed);
   prof_end(PROF_SCORER_GSL, (double)n * (4.0 * r * h + 8.0 * r * words_for(r) + 8.0 * r + 8.0 * words_for(r)),
            (hipStream_t)stream);
   GH_LAUNCH_CHECK();

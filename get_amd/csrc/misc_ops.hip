@@ -3,6 +3,7 @@
 // weight transpose, fused flat Adam.  Plus the library's error plumbing.
 #include "../../include/get_hip.h"
 #include "common.h"
+#include "gemm.hip.h"
 #include <stdarg.h>
 #include <vector>
 
@@ -248,23 +249,36 @@ int launch_colsum(const float* a, float* oa, int m, int h, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------- row gather (embedding rows for the dW_proj GEMM)
+// dst[r][:] = dropout(table[ids ? ids[r] : r][:]) -- the operand of the dW_proj GEMM, with the forward's mask
 __global__ void __launch_bounds__(256)
 gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids, float* __restrict__ dst, int m,
-                   int d) {
+                   int d, unsigned drop_thresh, float drop_scale, unsigned drop_seed) {
   const int per = (d + 3) / 4;
   for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < (size_t)m * per; it += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(it / per), c = 4 * (int)(it % per);
-    const float* s = table + (size_t)ids[r] * d + c;
+    const float* s = table + (size_t)(ids ? ids[r] : r) * d + c;
     float* o = dst + (size_t)r * d + c;
-    if (d % 4 == 0) *reinterpret_cast<float4*>(o) = *reinterpret_cast<const float4*>(s);
-    else for (int k = 0; k < 4 && c + k < d; ++k) o[k] = s[k];
+    if (d % 4 == 0) {
+      float4 v = *reinterpret_cast<const float4*>(s);
+      if (drop_thresh) v = drop4(v, drop_seed, (unsigned)r * (unsigned)d + (unsigned)c, drop_thresh, drop_scale);
+      *reinterpret_cast<float4*>(o) = v;
+    } else {
+      for (int k = 0; k < 4 && c + k < d; ++k) {
+        float v = s[k];
+        if (drop_thresh) v = drop_hash(drop_seed, (unsigned)r * (unsigned)d + (unsigned)(c + k)) >= drop_thresh ? v * drop_scale : 0.f;
+        o[k] = v;
+      }
+    }
   }
 }
-int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m, int d, hipStream_t s) {
+int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m, int d, hipStream_t s, float drop_p,
+                       unsigned drop_seed) {
   if (m <= 0) return 0;
   const size_t n = (size_t)m * ((d + 3) / 4);
+  const double th = (double)drop_p * 4294967296.0;
+  const unsigned thresh = drop_p > 0.f ? (th >= 4294967295.0 ? 4294967295u : (unsigned)th) : 0u;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s,
-                     table, ids, dst, m, d);
+                     table, ids, dst, m, d, thresh, 1.0f / (1.0f - drop_p), drop_seed);
   GH_LAUNCH_CHECK();
   return 0;
 }

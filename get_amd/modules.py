@@ -66,22 +66,34 @@ class GGNN(nn.Module):
         return (self.proj.linear.weight, *g(self.linearz0), *g(self.linearz1), *g(self.linearr0), *g(self.linearr1),
                 *g(self.linearh0), *g(self.linearh1))
 
+    def _drop(self):
+        """(p, seed) of the fused input dropout for this call, or None to use the materialised nn.Dropout."""
+        if not (hasattr(self, "dropout") and self.training and self.dropout.p > 0):
+            return (0.0, 0)
+        w = self.proj.linear.weight
+        if ops.fused_dropout_ok(w.shape[1], w.shape[0]):
+            return (float(self.dropout.p), ops.new_dropout_seed())
+        return None
+
     def forward(self, adj, x):
-        """adj: dense (N,R,R) or PackedAdj; x: (N,R,Din).  Returns (N,R,Dout)."""
+        """adj: dense (N,R,R) or PackedAdj; x: (N,R,Din).  Returns (N,R,Dout).
+        Training-mode input dropout (wrapper.py:189-190) runs inside the first GEMM's loader."""
         adj = ops.as_packed(adj)
-        if hasattr(self, "dropout"):
-            x = self.dropout(x)
-        return ops.ggnn_cell(adj, x, None, self._params())
+        d = self._drop()
+        if d is None:
+            return ops.ggnn_cell(adj, self.dropout(x), None, self._params())
+        return ops.ggnn_cell(adj, x, None, self._params(), d[0], d[1])
 
     def forward_ids(self, adj, embedding: nn.Embedding, ids: torch.Tensor):
         """Same cell on ``embedding(ids)`` with the row gather fused into the first GEMM
-        (graph_based_semantic_structure.py:100,150).  Falls back to an explicit lookup only when
-        input dropout is active (training), which needs the materialised rows."""
+        (graph_based_semantic_structure.py:100,150); training-mode dropout is applied there too.  Falls
+        back to an explicit lookup + nn.Dropout only for widths that are not float4-shaped."""
         adj = ops.as_packed(adj)
-        if hasattr(self, "dropout") and self.training and self.dropout.p > 0:
+        d = self._drop()
+        if d is None:
             x = self.dropout(embedding(ids.long()))
             return ops.ggnn_cell(adj, x, None, self._params())
-        return ops.ggnn_cell(adj, embedding.weight, ids.to(torch.int32).reshape(-1), self._params())
+        return ops.ggnn_cell(adj, embedding.weight, ids.to(torch.int32).reshape(-1), self._params(), d[0], d[1])
 
 
 # ------------------------------------------------------------------ Models/BiDAF/wrapper.py:210-227
@@ -121,10 +133,11 @@ class GGNN_with_GSL(nn.Module):
 
     def _refine(self, adj: PackedAdj, feat):
         s = self.word_scorer1
+        drop_p, seed = 0.0, 0
         if hasattr(s, "dropout") and self.training and s.dropout.p > 0:
-            feat = s.dropout(feat)          # word_scorer1's own input dropout (wrapper.py:189-190)
+            drop_p, seed = float(s.dropout.p), ops.new_dropout_seed()   # word_scorer1's own input dropout (wrapper.py:189-190)
         k = int(self.gsl1.rate * adj.r)
-        score, keep = ops.scorer_gsl(adj, feat, s.proj.linear.weight, self._gate12(), k)
+        score, keep = ops.scorer_gsl(adj, feat, s.proj.linear.weight, self._gate12(), k, drop_p, seed)
         self.last_score, self.last_keep = score, keep
         return adj.with_keep(keep)
 

@@ -180,7 +180,7 @@ class _GGNNCell(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ids, adj: PackedAdj, w_p, w_z0, b_z0, w_z1, b_z1, w_r0, b_r0, w_r1, b_r1, w_h0, b_h0, w_h1,
-                b_h1):
+                b_h1, drop_p=0.0, drop_seed=0):
         x = _f32(x)
         n, r = adj.n, adj.r
         h, din = w_p.shape
@@ -200,8 +200,9 @@ class _GGNNCell(torch.autograd.Function):
         xp, a, z, rr, rx, hh, out = buf.unbind(0)
         call("gh_ggnn_cell_fwd", *adj._args(), ptr(x), ptr(ids), n, r, din, h,
              *[ptr(t) for t in wts], ptr(b_z), ptr(b_r), ptr(b_h),
-             ptr(xp), ptr(a), ptr(z), ptr(rr), ptr(rx), ptr(hh), ptr(out), stream())
+             ptr(xp), ptr(a), ptr(z), ptr(rr), ptr(rx), ptr(hh), ptr(out), float(drop_p), int(drop_seed), stream())
         ctx.adj, ctx.ids, ctx.dims = adj, ids, (n, r, din, h)
+        ctx.drop = (float(drop_p), int(drop_seed))
         ctx.params = (w_p, w_z0, b_z0, w_z1, b_z1, w_r0, b_r0, w_r1, b_r1, w_h0, b_h0, w_h1, b_h1)
         ctx.save_for_backward(x, buf, *ws)
         ctx.x_needs_grad = ctx.needs_input_grad[0]
@@ -237,7 +238,7 @@ class _GGNNCell(torch.autograd.Function):
              ptr(w_p), ptr(w_z0), ptr(w_z1), ptr(w_r0), ptr(w_r1), ptr(w_h0), ptr(w_h1),
              ptr(xp), ptr(a), ptr(z), ptr(rr), ptr(rx), ptr(hh), ptr(g),
              ptr(dhp), ptr(dzp), ptr(drp), ptr(dxp), ptr(da),
-             ptr(dx), *[ptr(t) for t in gw], *[ptr(t) for t in gb], stream())
+             ptr(dx), *[ptr(t) for t in gw], *[ptr(t) for t in gb], ctx.drop[0], ctx.drop[1], stream())
         if want_dx:
             if ids is not None:      # trainable embedding table: scatter the row gradients
                 demb = torch.zeros_like(x)
@@ -246,20 +247,47 @@ class _GGNNCell(torch.autograd.Function):
             else:
                 dx = dx.view(x.shape)
         if direct:
-            return (dx, None, None) + (None,) * 13
+            return (dx, None, None) + (None,) * 15
         dz0, dz1, dr0, dr1, dh0, dh1 = dws.unbind(0)
         bz, br, bh = dbs.unbind(0)
-        return (dx, None, None, dw_p, dz0, bz, dz1, bz, dr0, br, dr1, br, dh0, bh, dh1, bh)
+        return (dx, None, None, dw_p, dz0, bz, dz1, bz, dr0, br, dr1, br, dh0, bh, dh1, bh, None, None)
 
 
-def ggnn_cell(adj: PackedAdj, x, ids, params):
-    """params: (w_p, w_z0, b_z0, w_z1, b_z1, w_r0, b_r0, w_r1, b_r1, w_h0, b_h0, w_h1, b_h1)."""
-    return _GGNNCell.apply(x, ids, adj, *params)
+def ggnn_cell(adj: PackedAdj, x, ids, params, drop_p: float = 0.0, drop_seed: int = 0):
+    """params: (w_p, w_z0, b_z0, w_z1, b_z1, w_r0, b_r0, w_r1, b_r1, w_h0, b_h0, w_h1, b_h1).
+    drop_p > 0 applies the cell's input dropout inside the first GEMM (stateless hash mask keyed by drop_seed)."""
+    return _GGNNCell.apply(x, ids, adj, *params, drop_p, drop_seed)
+
+
+def fused_dropout_ok(din: int, h: int) -> bool:
+    """The in-kernel dropout lives in the float4 fast path of the GEMM."""
+    return din % 4 == 0 and h % 4 == 0 and 4 <= din <= h
+
+
+def new_dropout_seed() -> int:
+    """Fresh 31-bit seed from torch's CPU generator (follows torch.manual_seed, no device sync)."""
+    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+
+def dropout_mask_reference(seed: int, rows: int, cols: int, p: float):
+    """Host replica of the kernels' stateless mask (tests): bool (rows, cols), True = kept."""
+    import numpy as np
+    idx = (np.arange(rows, dtype=np.uint64)[:, None] * np.uint64(cols) + np.arange(cols, dtype=np.uint64)[None, :])
+    x = (idx * np.uint64(0x9E3779B1) + np.uint64(seed)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(13)
+    x = (x * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    t = p * 4294967296.0
+    thresh = np.uint64(4294967295 if t >= 4294967295.0 else int(t))
+    return x >= thresh
 
 
 # --------------------------------------------------------------------------- word scorer + GSL (no gradient)
 @torch.no_grad()
-def scorer_gsl(adj: PackedAdj, feat: torch.Tensor, w_p, gate12: torch.Tensor, k: int):
+def scorer_gsl(adj: PackedAdj, feat: torch.Tensor, w_p, gate12: torch.Tensor, k: int, drop_p: float = 0.0,
+               drop_seed: int = 0):
     """GGNN(h->1) score of every node and the top-k keep set (wrapper.py:167-168, :215-219).
     Returns (score (N,R) fp32, keep (N,W) int64 bit words)."""
     feat = _f32(feat.detach())
@@ -269,7 +297,7 @@ def scorer_gsl(adj: PackedAdj, feat: torch.Tensor, w_p, gate12: torch.Tensor, k:
     w_p = _f32(w_p.detach().reshape(-1))
     gate12 = _f32(gate12.detach())
     call("gh_scorer_gsl", ptr(adj.bits), ptr(adj.dinv), ptr(adj.vals), ptr(feat), ptr(w_p), ptr(gate12), n, r, h,
-         int(k), ptr(score), ptr(keep), stream())
+         int(k), ptr(score), ptr(keep), float(drop_p), int(drop_seed), stream())
     return score, keep
 
 

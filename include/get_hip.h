@@ -74,14 +74,17 @@ int gh_transpose_batch(int n, const void* const* src_host, void* const* dst_host
  * wt_*: TRANSPOSED weights (gh_transpose of the reference's linear.weight):
  *   wt_p[din][h]; wt_z0,wt_z1,wt_r0,wt_r1,wt_h0,wt_h1 [h][h].
  * b_z = bz0+bz1, b_r = br0+br1, b_h = bh0+bh1 (each [h]).
- * Saved for backward (all [m][h]): xp, a, z, r, rx, hh.  out [m][h]. */
+ * Saved for backward (all [m][h]): xp, a, z, r, rx, hh.  out [m][h].
+ * drop_p > 0: the cell's input dropout (wrapper.py:185-190) is applied inside the first GEMM's loader with a
+ * stateless mask -- element (m,k) kept iff hash(drop_seed, m*din+k) >= drop_p*2^32, scaled by 1/(1-drop_p);
+ * pass the same (drop_p, drop_seed) to the backward.  Needs din % 4 == 0 and h % 4 == 0. */
 int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
                      const float* x, const int32_t* ids, int n, int r, int din, int h,
                      const float* wt_p, const float* wt_z0, const float* wt_z1, const float* wt_r0,
                      const float* wt_r1, const float* wt_h0, const float* wt_h1,
                      const float* b_z, const float* b_r, const float* b_h,
                      float* xp, float* a, float* z, float* rr, float* rx, float* hh, float* out,
-                     gh_stream_t stream);
+                     float drop_p, uint32_t drop_seed, gh_stream_t stream);
 
 /* Backward of the cell.  w_*: the reference's UNtransposed weights [h][h] / w_p[h][din].
  * g [m][h] = dL/dout.  Scratch (all [m][h]): dhp, dzp, drp, dxp, da.
@@ -98,15 +101,16 @@ int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const float* vals,
                      float* dhp, float* dzp, float* drp, float* dxp, float* da,
                      float* dx, float* dw_p, float* dw_z0, float* dw_z1, float* dw_r0, float* dw_r1,
                      float* dw_h0, float* dw_h1, float* db_z, float* db_r, float* db_h,
-                     float* db_z1, float* db_r1, float* db_h1, gh_stream_t stream);
+                     float* db_z1, float* db_r1, float* db_h1, float drop_p, uint32_t drop_seed, gh_stream_t stream);
 
 /* ---- a2(300->1) + a3  word scorer + GSL top-k: wrapper.py:167-168, GSL.forward :215-227 ----
  * feat [n][r][h]; w_p[h] = scorer proj.linear.weight; gate[12] = {wz0,bz0,wz1,bz1,wr0,br0,wr1,br1,
  * wh0,bh0,wh1,bh1} (the six 1x1 linears).  k = int(rate * r) computed by the caller.
- * Out: score[n][r], keep[n][W] (bit i set <=> node i among the k best; ties -> lower index). */
+ * Out: score[n][r], keep[n][W] (bit i set <=> node i among the k best; ties -> lower index).
+ * drop_p/drop_seed: the scorer cell's own input dropout in training mode (same stateless mask as above). */
 int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const float* feat,
                   const float* w_p, const float* gate, int n, int r, int h, int k,
-                  float* score, uint64_t* keep, gh_stream_t stream);
+                  float* score, uint64_t* keep, float drop_p, uint32_t drop_seed, gh_stream_t stream);
 /* GSL alone on given scores (GSL.forward on arbitrary score input). */
 int gh_gsl_topk(const float* score, int n, int r, int k, uint64_t* keep, gh_stream_t stream);
 /* Dense view of a (refined) packed adjacency, for callers that want GSL.forward's dense result. */

@@ -345,3 +345,49 @@ def test_adam_flat_matches_torch():
         opt.step()
         ops.adam_step_flat(p, T(g), m, v, step, lr=1e-4, weight_decay=1e-3)
         assert maxerr(p.cpu(), ref.detach()) <= 2e-7, step
+
+
+# ---------------------------------------------------------------- fused (in-kernel) dropout
+def test_fused_dropout_matches_masked_oracle():
+    """Training-mode input dropout of the GGNN cell is applied inside the GEMM loaders with a stateless
+    hash mask: replaying the same mask on the host, output and every gradient must equal the oracle cell
+    run on x * mask / (1 - p) (so forward, dW_proj and dX all use one consistent mask)."""
+    from get_amd import modules, ops
+    rng = np.random.default_rng(31)
+    n, r, d, h, p_drop, seed = 6, 100, 48, 64, 0.25, 123457
+    toks, lens, ids, adj = cases.graphs(rng, n, r, 3, O.convert_text, vocab=80)
+    x = rng.standard_normal((n, r, d)).astype(np.float32)
+    prm = cases.cell_params(rng, d, h)
+    gw = rng.standard_normal((n, r, h)).astype(np.float32)
+    mod = modules.GGNN(d, h, dropout=p_drop)
+    _load_cell(mod, prm)
+    mod = mod.to(DEV)
+    padj, node_ids, _ = ops.graph_build(T(toks), T(lens), 3)
+    keep = ops.dropout_mask_reference(seed, n * r, d, p_drop).reshape(n, r, d)
+    assert abs(keep.mean() - (1 - p_drop)) < 0.01                       # the mask has the right density
+    xt = T(x, grad=True)
+    out = ops.ggnn_cell(padj, xt, None, mod._params(), p_drop, seed)
+    (out * T(gw)).sum().backward()
+    po = {k: torch.from_numpy(v).requires_grad_(True) for k, v in prm.items()}
+    xo = torch.from_numpy(x).requires_grad_(True)
+    oo = O.ggnn_cell(torch.from_numpy(adj).float(), xo * torch.from_numpy(keep).float() / (1 - p_drop), po)
+    (oo * torch.from_numpy(gw)).sum().backward()
+    assert maxerr(out.detach().cpu(), oo.detach()) <= 2e-5
+    assert maxerr(xt.grad.cpu(), xo.grad) <= 1e-3 * float(xo.grad.abs().max()) + 1e-6
+    for name, q in mod.named_parameters():
+        go = po[name].grad
+        assert maxerr(q.grad.cpu(), go) <= 1e-3 * float(go.abs().max()) + 1e-5, name
+    # embedding-gather path uses the same mask indexing (logical row, not table row)
+    emb = rng.standard_normal((80, d)).astype(np.float32)
+    e = torch.nn.Embedding.from_pretrained(torch.from_numpy(emb), freeze=True).to(DEV)
+    out2 = ops.ggnn_cell(padj, e.weight, node_ids.reshape(-1), mod._params(), p_drop, seed)
+    xe = torch.from_numpy(emb)[torch.from_numpy(ids)]
+    oo2 = O.ggnn_cell(torch.from_numpy(adj).float(), xe * torch.from_numpy(keep).float() / (1 - p_drop),
+                      {k: v.detach() for k, v in po.items()})
+    assert maxerr(out2.detach().cpu(), oo2) <= 2e-5
+    # module-level: train mode draws a fresh seed per call, eval mode is deterministic
+    mod.train(True)
+    a1, a2 = mod(padj, T(x)), mod(padj, T(x))
+    assert maxerr(a1.detach().cpu(), a2.detach().cpu()) > 1e-3
+    mod.train(False)
+    assert maxerr(mod(padj, T(x)).detach().cpu(), mod(padj, T(x)).detach().cpu()) == 0.0
