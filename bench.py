@@ -53,35 +53,15 @@ def build_workload(batch=32, n_evd=30, seed=20240229, device="cuda:0", cfg: Synt
     torch.manual_seed(seed)
     model = modules.Graph_basedSemantiStructure(cfg.model_params(emb, art, clm)).to(device)
     raw = make_raw_batch(cfg, seed)
-    dev = torch.device(device)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    claim_tokens, claim_len = t(raw["claim_tokens"]), t(raw["claim_len"])
-    evd_tokens, evd_len = t(raw["evd_tokens"]), t(raw["evd_len"])
-    counts = t(raw["evd_counts"])
-    b1 = int(raw["evd_counts"].sum())
-    n = cfg.fixed_num_evidences
-    # slot of every pair inside the (B, n, R) padded evidence tensor
-    offs = np.concatenate([[0], np.cumsum(raw["evd_counts"])])[:-1]
-    p2c = np.repeat(np.arange(cfg.batch), raw["evd_counts"])
-    slot = t((p2c * n + (np.arange(b1) - offs[p2c])).astype(np.int64))
-    labels = t(raw["labels"])
-
-    def make_inputs():
-        """The per-step device work that replaces the reference's host graph construction + H2D of
-        dense float64 adjacency: ids -> packed graphs (interactions.py:334-351)."""
-        qa, q_ids, q_n = ops.graph_build(claim_tokens, claim_len, cfg.window)
-        da, d_ids, d_n = ops.graph_build(evd_tokens, evd_len, cfg.window)
-        document = torch.zeros((cfg.batch * n, cfg.len_right), device=dev, dtype=torch.int32)
-        document.index_copy_(0, slot, d_ids)
-        kargs = {
-            "query_lens": q_n, "docs_lens": None, "doc_lens_indices": None,
-            "doc_content_without_padding_evidences": d_ids, "evd_cnt_each_query": counts,
-            "fixed_num_evidences": n, "query_adj": qa, "docs_adj": da,
-            "doc_sources": t_doc_sources, "query_sources": t_query_sources,
-        }
-        return q_ids, document.view(cfg.batch, n, cfg.len_right), kargs
-
-    t_doc_sources, t_query_sources = t(raw["doc_sources"]), t(raw["query_sources"])
+    from get_amd.batch import NativeBatch
+    batch_obj = NativeBatch(raw["claim_tokens"], raw["claim_len"], raw["evd_tokens"], raw["evd_len"], raw["evd_counts"],
+                            raw["doc_sources"], raw["query_sources"], raw["labels"], window=cfg.window,
+                            n_max=cfg.fixed_num_evidences, device=device)
+    b1 = batch_obj.b1
+    labels = batch_obj.labels
+    # per-step device work that replaces the reference's host graph construction + H2D of dense float64
+    # adjacency: token ids -> packed graphs (interactions.py:334-351)
+    make_inputs = batch_obj.inputs
     query, document, kargs = make_inputs()
     nnz = float(torch.count_nonzero(kargs["docs_adj"].to_dense()).item()) / max(b1, 1)
 

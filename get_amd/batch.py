@@ -1,0 +1,81 @@
+"""Device-resident mini-batches for the GET hot path.
+
+The reference re-materialises dense ``(N,30,100,100)`` float64 adjacency on the host every epoch
+(handlers/mz_sampler.py:115-176), de-pads it per claim in a Python loop with two device syncs per claim
+(Fitting/FittingFC/char_man_fitter_query_repr1.py:204-250) and ships 76.8 MB per step over PCIe.
+:class:`NativeBatch` keeps only token ids and counts on the device and rebuilds the packed graphs per
+step with ``gh_graph_build``; :func:`kargs_from_reference_tensors` is the compatibility shim for callers
+that still hand over the reference's dense tensors.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from .keywords import KeyWordSettings as K
+
+
+class NativeBatch:
+    """Raw token form of one mini-batch, resident in HBM.
+
+    claim_tokens (B,L) / claim_len (B,): post-padded claim token ids and lengths;
+    evd_tokens (B1,R) / evd_len (B1,): the de-padded evidences of all claims, claim-major;
+    evd_counts (B,): evidences per claim (sum = B1); doc_sources (B,n_max) with -1 padding;
+    query_sources (B,1); labels (B,).
+    """
+
+    def __init__(self, claim_tokens, claim_len, evd_tokens, evd_len, evd_counts, doc_sources, query_sources, labels,
+                 window: int, n_max: int = 30, device="cuda:0"):
+        dev = torch.device(device)
+        t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a).to(dev)
+        counts_host = np.asarray(evd_counts.cpu() if torch.is_tensor(evd_counts) else evd_counts, dtype=np.int64)
+        self.window, self.n_max, self.device = int(window), int(n_max), dev
+        self.claim_tokens, self.claim_len = t(claim_tokens).int(), t(claim_len).int()
+        self.evd_tokens, self.evd_len = t(evd_tokens).int(), t(evd_len).int()
+        self.counts = t(counts_host)
+        self.doc_sources, self.query_sources, self.labels = t(doc_sources), t(query_sources), t(labels)
+        self.b, self.b1 = int(counts_host.shape[0]), int(counts_host.sum())
+        assert self.evd_tokens.shape[0] == self.b1, "evd_tokens must hold sum(evd_counts) rows"
+        assert counts_host.max(initial=0) <= self.n_max
+        # slot of every pair inside the (B, n_max, R) padded evidence tensor -- host arithmetic, done once
+        offs = np.concatenate([[0], np.cumsum(counts_host)])[:-1]
+        p2c = np.repeat(np.arange(self.b), counts_host)
+        self._slot = t((p2c * self.n_max + (np.arange(self.b1) - offs[p2c])).astype(np.int64))
+
+    def inputs(self):
+        """Per-step device work: token ids -> (query node ids, padded document ids, kargs) for
+        ``Graph_basedSemantiStructure.forward`` (interactions.py:334-351 runs as two kernel launches)."""
+        qa, q_ids, q_n = ops.graph_build(self.claim_tokens, self.claim_len, self.window)
+        da, d_ids, _ = ops.graph_build(self.evd_tokens, self.evd_len, self.window)
+        r = self.evd_tokens.shape[1]
+        document = torch.zeros((self.b * self.n_max, r), device=self.device, dtype=torch.int32)
+        document.index_copy_(0, self._slot, d_ids)
+        kargs = {
+            K.Query_lens: q_n, K.Doc_lens: None, K.DocLensIndices: None,
+            K.DocContentNoPaddingEvidence: d_ids, K.EvidenceCountPerQuery: self.counts,
+            K.FIXED_NUM_EVIDENCES: self.n_max, K.Query_Adj: qa, K.Evd_Docs_Adj: da,
+            K.DocSources: self.doc_sources, K.QuerySources: self.query_sources,
+        }
+        return q_ids, document.view(self.b, self.n_max, r), kargs
+
+
+def kargs_from_reference_tensors(query_lens, evd_doc_contents, evd_docs_adj, query_adj, evd_counts, doc_sources,
+                                 query_sources=None, n_max: int = 30):
+    """Compatibility shim: the tensors the reference fitter holds before its de-padding loop
+    (char_man_fitter_query_repr1.py:196-223) -> forward kargs, with the per-claim ``[:evd_cnt]`` slicing
+    done by ONE boolean-mask gather on the device instead of a Python loop with 2 syncs per claim.
+
+    evd_doc_contents (B,n,R) ids, evd_docs_adj (B,n,R,R) dense, query_adj (B,L,L), evd_counts (B,)."""
+    b, n, r = evd_doc_contents.shape
+    valid = torch.arange(n, device=evd_counts.device)[None, :] < evd_counts[:, None]          # (B,n)
+    e_conts = evd_doc_contents[valid]                                                         # (B1,R) claim-major
+    e_adj = evd_docs_adj[valid]                                                               # (B1,R,R)
+    kargs = {
+        K.Query_lens: query_lens, K.Doc_lens: None, K.DocLensIndices: None,
+        K.DocContentNoPaddingEvidence: e_conts, K.EvidenceCountPerQuery: evd_counts,
+        K.FIXED_NUM_EVIDENCES: n_max, K.Query_Adj: query_adj, K.Evd_Docs_Adj: e_adj, K.DocSources: doc_sources,
+    }
+    if query_sources is not None:
+        kargs[K.QuerySources] = query_sources
+    return kargs

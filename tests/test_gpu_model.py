@@ -203,3 +203,34 @@ def test_ragged_realistic_batch_properties():
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     sub = wl["oracle_slice"](3)
     assert float((phi[:3].detach().cpu() - sub["phi"]).abs().max()) <= 1e-4
+
+
+def test_batch_shim_matches_fitter_depadding():
+    """get_amd.batch: the dense compatibility shim reproduces the fitter's per-claim de-padding
+    (char_man_fitter_query_repr1.py:204-223) and the native batch yields the same ids/graphs."""
+    from get_amd.batch import NativeBatch, kargs_from_reference_tensors
+    cfg, seed = MODEL_CASES["small"]
+    raw = make_raw_batch(cfg, seed)
+    inp = assemble_inputs(raw, cfg, O.convert_text)
+    B, n, R = inp["document"].shape
+    adj_padded = np.zeros((B, n, R, R))
+    last = 0
+    for b, c in enumerate(inp["evd_counts"]):
+        adj_padded[b, :c] = inp["doc_adj"][last:last + c]
+        last += c
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    kargs = kargs_from_reference_tensors(T(inp["query_lens"]), T(inp["document"]), T(adj_padded), T(inp["query_adj"]),
+                                         T(inp["evd_counts"]), T(inp["doc_sources"]), T(inp["query_sources"]))
+    assert np.array_equal(kargs["doc_content_without_padding_evidences"].cpu().numpy(), inp["doc_ids"])
+    assert np.array_equal(kargs["docs_adj"].cpu().numpy(), inp["doc_adj"])
+    nb = NativeBatch(raw["claim_tokens"], raw["claim_len"], raw["evd_tokens"], raw["evd_len"], raw["evd_counts"],
+                     raw["doc_sources"], raw["query_sources"], raw["labels"], window=cfg.window, device=DEV)
+    q_ids, document, k2 = nb.inputs()
+    assert np.array_equal(q_ids.cpu().numpy(), inp["query"]) and np.array_equal(document.cpu().numpy(), inp["document"])
+    assert np.abs(k2["docs_adj"].to_dense().cpu().numpy() - inp["doc_adj"]).max() <= 2e-7
+    model = build_model(cfg, seed)
+    z, _ = load("g7_model_small.npz")
+    phi_a = model(T(inp["query"]), T(inp["document"]), **kargs)
+    phi_b = model(q_ids, document, **k2)
+    assert np.abs(phi_a.detach().cpu().numpy() - z["phi"]).max() <= 1e-4
+    assert np.abs(phi_b.detach().cpu().numpy() - z["phi"]).max() <= 1e-4
