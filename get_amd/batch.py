@@ -79,3 +79,27 @@ def kargs_from_reference_tensors(query_lens, evd_doc_contents, evd_docs_adj, que
     if query_sources is not None:
         kargs[K.QuerySources] = query_sources
     return kargs
+
+
+@torch.no_grad()
+def batched_predict(model, batch: "NativeBatch", claims_per_call: int = 0):
+    """Evaluation without the reference's one-claim-per-forward loop
+    (Fitting/FittingFC/char_man_fitter_query_repr1.py:260-364 runs ~780 B=1 forwards per validation pass):
+    all claims of `batch` go through the ragged kernels in one forward (or in chunks of `claims_per_call`).
+
+    Returns (phi (B,C), word_att list of (n_b, R, hw) tensors per claim, evd_att (B, n_max, he)) -- the
+    observables `_prepare_error_analysis` consumes (:422-472), with each head's weights summing to one."""
+    was_training = model.training
+    model.train(False)
+    try:
+        query, document, kargs = batch.inputs()
+        kargs = dict(kargs)
+        kargs[K.OutputRankingKey] = True
+        if claims_per_call and claims_per_call < batch.b:
+            raise NotImplementedError("chunked evaluation: build one NativeBatch per chunk")
+        phi, (word_w, evd_w) = model(query, document, **kargs)
+        counts = batch.counts.cpu().tolist()
+        word_per_claim = list(torch.split(word_w, counts, dim=0))
+        return phi, word_per_claim, evd_w
+    finally:
+        model.train(was_training)

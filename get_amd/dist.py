@@ -65,6 +65,19 @@ class FlatTrainer:
         emb_ids = {id(m.weight) for m in model.modules() if isinstance(m, torch.nn.Embedding)}
         self._matrices = [p for p in self.params if p.dim() == 2 and id(p) not in emb_ids and min(p.shape) > 1]
 
+    # -- checkpoint / resume (the reference saves only net.state_dict(), char_man_fitter_query_repr1.py:143-144;
+    #    multi-GPU runs also need the optimiser moments and step count to resume bit-identically)
+    def state_dict(self) -> dict:
+        return {"t": self.t, "m": self.flat_m.detach().cpu().clone(), "v": self.flat_v.detach().cpu().clone(),
+                "names": list(self.live_names), "numel": self.numel,
+                "hyper": {"lr": self.lr, "weight_decay": self.weight_decay, "betas": tuple(self.betas), "eps": self.eps}}
+
+    def load_state_dict(self, sd: dict):
+        assert sd["names"] == self.live_names and sd["numel"] == self.numel, "optimizer state does not match this model"
+        self.t = int(sd["t"])
+        self.flat_m.copy_(sd["m"].to(self.flat_m.device))
+        self.flat_v.copy_(sd["v"].to(self.flat_v.device))
+
     @property
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1

@@ -234,3 +234,56 @@ def test_batch_shim_matches_fitter_depadding():
     phi_b = model(q_ids, document, **k2)
     assert np.abs(phi_a.detach().cpu().numpy() - z["phi"]).max() <= 1e-4
     assert np.abs(phi_b.detach().cpu().numpy() - z["phi"]).max() <= 1e-4
+
+
+def test_batched_predict_equals_per_claim_predict():
+    """Row (f)3: one ragged forward over all claims == the reference-style B=1 evaluation loop."""
+    from get_amd.batch import NativeBatch, batched_predict
+    cfg, seed = MODEL_CASES["small"]
+    model = build_model(cfg, seed)
+    raw = make_raw_batch(cfg, seed)
+    mk = lambda sl_c, sl_e, cnt, b: NativeBatch(raw["claim_tokens"][sl_c], raw["claim_len"][sl_c], raw["evd_tokens"][sl_e],
+                                                raw["evd_len"][sl_e], cnt, raw["doc_sources"][sl_c], raw["query_sources"][sl_c],
+                                                raw["labels"][sl_c], window=cfg.window, device=DEV)
+    full = mk(slice(None), slice(None), raw["evd_counts"], cfg.batch)
+    phi, word_w, evd_w = batched_predict(model, full)
+    offs = np.concatenate([[0], np.cumsum(raw["evd_counts"])])
+    for b in range(cfg.batch):
+        one = mk(slice(b, b + 1), slice(offs[b], offs[b + 1]), raw["evd_counts"][b:b + 1], 1)
+        q, d, k = one.inputs()
+        p1, (w1, e1) = model.predict(q, d, **dict(k, output_ranking=True))
+        assert float((p1[0] - phi[b]).abs().max()) <= 1e-5
+        assert float((w1 - word_w[b]).abs().max()) <= 1e-6 and float((e1[0] - evd_w[b]).abs().max()) <= 1e-6
+        assert torch.allclose(word_w[b].sum(1), torch.ones_like(word_w[b].sum(1)), atol=1e-5)
+
+
+def test_trainer_checkpoint_resume_is_bit_identical():
+    """Row (f)4: model state_dict + FlatTrainer.state_dict() resume reproduces the next step exactly (eval mode)."""
+    from get_amd.batch import NativeBatch
+    from get_amd.dist import FlatTrainer
+    cfg, seed = MODEL_CASES["small"]
+    raw = make_raw_batch(cfg, seed)
+    nb = NativeBatch(raw["claim_tokens"], raw["claim_len"], raw["evd_tokens"], raw["evd_len"], raw["evd_counts"],
+                     raw["doc_sources"], raw["query_sources"], raw["labels"], window=cfg.window, device=DEV)
+
+    def step(model, tr):
+        tr.zero_grad()
+        q, d, k = nb.inputs()
+        torch.nn.functional.cross_entropy(model(q, d, **k), nb.labels).backward()
+        tr.step()
+
+    m1 = build_model(cfg, seed)
+    t1 = FlatTrainer(m1)
+    step(m1, t1)
+    ck_model = {k: v.detach().cpu().clone() for k, v in m1.state_dict().items()}
+    ck_opt = t1.state_dict()
+    step(m1, t1)
+    m2 = build_model(cfg, seed + 1)                 # different init, then restored
+    m2.load_state_dict(ck_model, strict=True)
+    t2 = FlatTrainer(m2)
+    t2.load_state_dict(ck_opt)
+    step(m2, t2)
+    # split-K partial sums are order-deterministic (no atomics), so the resumed step matches bit for bit
+    for (k1, p1), (k2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if k1 in t1.live_names:
+            assert torch.equal(p1.detach(), p2.detach()), k1
