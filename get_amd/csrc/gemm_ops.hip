@@ -76,7 +76,15 @@ reduce_partials_kernel(const ReduceArgs R) {
     const int i = (int)(e / J4), j = 4 * (int)(e % J4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* p = it.ws + (size_t)i * it.J + j;
-    for (int k = 0; k < it.ks; ++k) {
+    int k = 0;
+    for (; k + 8 <= it.ks; k += 8) {           // 8 independent 16-byte loads in flight, fixed summation order
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(k + u) * it.stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; k < it.ks; ++k) {
       const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * it.stride);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
