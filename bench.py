@@ -247,8 +247,14 @@ def main():
                 kernels[name] = entry
             dom = max((k for k in kernels if k.startswith("gemm")), key=lambda k: kernels[k]["ms_per_step"])
             d = kernels[dom]
+            traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[dom]
+                traffic = (pm["fetch_kib"] * pm["fetch_correction"] + pm["write_kib"]) * 1024.0
+            except Exception:
+                pass
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["achieved_tflops"],
-                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": d["frac"], "traffic": None,
+                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": d["frac"], "traffic": traffic,
                                "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_per_step"],
                                "alg_flops_per_launch": prof[dom]["work"] / prof[dom]["launches"]}
             out["kernels"] = kernels

@@ -397,6 +397,7 @@ scorer_gsl_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ d
   const float* fg = feat + (size_t)g * R * H;
   // x_j = feat_j . w_p   (proj, no bias)
   const bool v4 = (H % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat) & 15) == 0) && ((reinterpret_cast<uintptr_t>(w_p) & 15) == 0);
+#pragma unroll 4
   for (int j = wave; j < R; j += 4) {
     float acc = 0.f;
     if (v4) {

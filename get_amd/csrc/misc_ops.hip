@@ -323,6 +323,7 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
     for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
   if (d4 < D4) {
     const float4* rb = reinterpret_cast<const float4*>(right + (size_t)b * L * Dr) + d4;
+#pragma unroll 4
     for (int l = wave; l < L; l += 4) {
       const float4 rv = rb[(size_t)l * D4];
 #pragma unroll
@@ -378,6 +379,7 @@ att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict_
   for (int i = tid; i < L * C; i += 256) ws[i] = weights[(size_t)b * L * C + i];
   __syncthreads();
   const int D4 = Dr / 4;
+#pragma unroll 2
   for (int l = wave; l < L; l += 4) {
     float part[8], wl[8];
 #pragma unroll
@@ -449,6 +451,7 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
 #pragma unroll
   for (int c = 0; c < 8; ++c) dw[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (rl < RL) {
+#pragma unroll 4
     for (int l = rl; l < L; l += RL) {
       const size_t m = (size_t)b * L + l;
       const float4 tv = reinterpret_cast<const float4*>(t + m * Ha)[c4];
