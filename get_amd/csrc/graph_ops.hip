@@ -144,22 +144,50 @@ spmm_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, c
   const int HV = H / V;
   const int ncol = min(slab, HV - c0);
   const float* xg = x + (size_t)g * R * H;
-  for (int it = tid; it < R * ncol; it += 256) {
-    const int i = it / ncol, c = it % ncol;
-    if (V == 4) reinterpret_cast<float4*>(xs)[i * slab + c] = reinterpret_cast<const float4*>(xg + (size_t)i * H)[c0 + c];
-    else xs[i * slab + c] = xg[(size_t)i * H + c0 + c];
-  }
-  for (int it = tid; it < R * W; it += 256) {
-    const int i = it / W, w = it % W;
-    unsigned long long m = bits[((size_t)g * R + i) * W + w];
-    if (keep) {
-      const bool ki = (keep[(size_t)g * W + (i >> 6)] >> (i & 63)) & 1ull;
-      if (!ki) m &= keep[(size_t)g * W + w];          // edge survives iff keep(i) || keep(j)
+  // Stage everything with ONE memory round trip: the slab (up to SL 16-byte loads per thread from a clamped
+  // index -- unconditional, so no branch or per-load s_waitcnt), this thread's bit-row word and dinv entry
+  // are all issued back to back; sched_barrier keeps them ahead of the first LDS write (the scheduler otherwise
+  // pairs each load with its store: one HBM latency per element).  Out-of-range slots rewrite the last
+  // element with its own value, which keeps the stores unconditional too.
+  {
+    constexpr int SL = 12;
+    const int total = R * ncol;
+    // bit rows / dinv first (R*W <= 1024 and R <= 256 -> at most 4 + 1 per thread); consumed after the slab
+    unsigned long long mw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mw[u] = bits[(size_t)g * R * W + min(tid + u * 256, R * W - 1)];
+    const float dvv = vals ? 0.f : dinv[(size_t)g * R + min(tid, R - 1)];
+    for (int base = tid; base < total; base += SL * 256) {
+      float4 tmp[SL];
+#pragma unroll
+      for (int k = 0; k < SL; ++k) {
+        const int it = min(base + k * 256, total - 1);
+        const int i = it / ncol, c = it % ncol;
+        if (V == 4) tmp[k] = reinterpret_cast<const float4*>(xg + (size_t)i * H)[c0 + c];
+        else tmp[k].x = xg[(size_t)i * H + c0 + c];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < SL; ++k) {
+        const int it = min(base + k * 256, total - 1);
+        const int i = it / ncol, c = it % ncol;
+        if (V == 4) reinterpret_cast<float4*>(xs)[i * slab + c] = tmp[k];
+        else xs[i * slab + c] = tmp[k].x;
+      }
     }
-    rb[it] = m;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int it = min(tid + u * 256, R * W - 1);
+      unsigned long long m = mw[u];
+      if (keep) {
+        const int i = it / W, w = it % W;
+        const bool ki = (keep[(size_t)g * W + (i >> 6)] >> (i & 63)) & 1ull;
+        if (!ki) m &= keep[(size_t)g * W + w];          // edge survives iff keep(i) || keep(j)
+      }
+      rb[it] = m;
+    }
+    if (!vals) dv[min(tid, R - 1)] = dvv;
   }
-  if (!vals)
-    for (int i = tid; i < R; i += 256) dv[i] = dinv[(size_t)g * R + i];
   __syncthreads();
   const float* vg = vals ? vals + (size_t)g * R * R : nullptr;
   float* yg = y + (size_t)g * R * H;
@@ -351,12 +379,12 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
     hipLaunchKernelGGL(spmm_gather_kernel, dim3(n * bpg), dim3(256), 0, s, bits, dinv, vals, keep, x, y, r, h, transpose,
                        accumulate, bpg);
   } else if (v4) {
-    static bool attr4 = false;
-    if (!attr4) { hipFuncSetAttribute((const void*)spmm_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr4 = true; }
+    static bool attr4 = false;     // only raise the dynamic-LDS cap when a launch actually needs more than 64 KB
+    if (!attr4 && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)spmm_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr4 = true; }
     hipLaunchKernelGGL(spmm_kernel<4>, grid, dim3(256), lds, s, bits, dinv, vals, keep, x, y, r, h, slab, transpose, accumulate);
   } else {
     static bool attr1 = false;
-    if (!attr1) { hipFuncSetAttribute((const void*)spmm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+    if (!attr1 && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)spmm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
     hipLaunchKernelGGL(spmm_kernel<1>, grid, dim3(256), lds, s, bits, dinv, vals, keep, x, y, r, h, slab, transpose, accumulate);
   }
   prof_end(PROF_SPMM, alg_bytes, s);

@@ -423,7 +423,7 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
   const size_t lds = ((size_t)dr * heads + 2 * (size_t)l * heads) * 4;
   GH_REQUIRE(lds <= 160 * 1024, "att_softmax_bwd: %zu B of LDS needed", lds);
   static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)att_softmax_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  if (!attr && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)att_softmax_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   prof_begin(s);
   hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(b), dim3(256), lds, s, right, weights, g_att, g_w, l, dr, heads, de,
                      dright);
