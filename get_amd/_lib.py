@@ -18,22 +18,24 @@ _I = ctypes.c_int
 _F = ctypes.c_float
 _L = ctypes.c_int64
 _U = ctypes.c_uint32
+ABI_VERSION = 2          # GH_ABI_VERSION of include/get_hip.h
 
 # name -> argtypes (mirrors include/get_hip.h; tests/test_abi.py checks the two agree)
 SIGNATURES = {
     "gh_graph_build": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "gh_adj_pack_f64": [_P, _I, _I, _P, _P, _P],
     "gh_adj_pack_f32": [_P, _I, _I, _P, _P, _P],
-    "gh_spmm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gh_ragged_plan": [_P, _P, _I, _I, _P, _P, _P, _P, _P],
+    "gh_spmm": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "gh_transpose": [_P, _P, _I, _I, _P],
     "gh_transpose_batch": [_I, _P, _P, _P, _P, _P],
-    "gh_ggnn_cell_fwd": [_P] * 6 + [_I] * 4 + [_P] * 10 + [_P] * 7 + [_F, _U, _P],
-    "gh_ggnn_cell_bwd": [_P] * 6 + [_I] * 4 + [_P] * 7 + [_P] * 7 + [_P] * 5 + [_P] * 14 + [_F, _U, _P],
-    "gh_scorer_gsl": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _U, _P],
+    "gh_ggnn_cell_fwd": [_P] * 5 + [_I, _I] + [_P] * 2 + [_I] * 4 + [_P] * 10 + [_P] * 7 + [_F, _U, _P],
+    "gh_ggnn_cell_bwd": [_P] * 5 + [_I] + [_P] * 2 + [_I] * 4 + [_P] * 7 + [_P] * 7 + [_P] * 5 + [_P] * 14 + [_F, _U, _P],
+    "gh_scorer_gsl": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _U, _P],
     "gh_gsl_topk": [_P, _I, _I, _I, _P, _P],
     "gh_adj_unpack": [_P, _P, _P, _P, _I, _I, _P, _P],
-    "gh_concat_att_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
-    "gh_concat_att_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gh_concat_att_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "gh_concat_att_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "gh_linear_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "gh_linear_bwd": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "gh_seg_offsets": [_P, _I, _P, _P, _I, _P],
@@ -84,8 +86,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = args
         fn.restype = _I
-    if lib.gh_abi_version() != 1:
-        raise RuntimeError(f"get_amd: ABI version mismatch ({lib.gh_abi_version()} != 1)")
+    if lib.gh_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"get_amd: ABI version mismatch ({lib.gh_abi_version()} != {ABI_VERSION})")
     _lib = lib
     return lib
 

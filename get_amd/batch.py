@@ -9,6 +9,8 @@ that still hand over the reference's dense tensors.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -26,7 +28,7 @@ class NativeBatch:
     """
 
     def __init__(self, claim_tokens, claim_len, evd_tokens, evd_len, evd_counts, doc_sources, query_sources, labels,
-                 window: int, n_max: int = 30, device="cuda:0"):
+                 window: int, n_max: int = 30, device="cuda:0", compact: bool = None):
         dev = torch.device(device)
         t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a).to(dev)
         counts_host = np.asarray(evd_counts.cpu() if torch.is_tensor(evd_counts) else evd_counts, dtype=np.int64)
@@ -42,12 +44,23 @@ class NativeBatch:
         offs = np.concatenate([[0], np.cumsum(counts_host)])[:-1]
         p2c = np.repeat(np.arange(self.b), counts_host)
         self._slot = t((p2c * self.n_max + (np.arange(self.b1) - offs[p2c])).astype(np.int64))
+        # node-compact layout (ops.RaggedPlan): the host has to know the total number of real evidence nodes, i.e.
+        # the unique tokens per evidence -- what convert_text returns as `length_` (interactions.py:351) at load time
+        if compact is None:
+            compact = os.environ.get("GET_AMD_PADDED", "0") != "1"
+        self.compact = bool(compact)
+        et = np.asarray(evd_tokens.cpu() if torch.is_tensor(evd_tokens) else evd_tokens)
+        el = np.clip(np.asarray(evd_len.cpu() if torch.is_tensor(evd_len) else evd_len), 0, et.shape[1] if et.ndim == 2 else 0)
+        self.evd_nodes_host = np.array([len(set(row[:n].tolist())) for row, n in zip(et, el)], dtype=np.int64)
+        self.m_real = int(self.evd_nodes_host.sum())
 
     def inputs(self):
         """Per-step device work: token ids -> (query node ids, padded document ids, kargs) for
         ``Graph_basedSemantiStructure.forward`` (interactions.py:334-351 runs as two kernel launches)."""
         qa, q_ids, q_n = ops.graph_build(self.claim_tokens, self.claim_len, self.window)
-        da, d_ids, _ = ops.graph_build(self.evd_tokens, self.evd_len, self.window)
+        da, d_ids, d_n = ops.graph_build(self.evd_tokens, self.evd_len, self.window)
+        if self.compact:
+            da = da.with_plan(ops.RaggedPlan(d_n, d_ids, self.m_real))
         r = self.evd_tokens.shape[1]
         document = torch.zeros((self.b * self.n_max, r), device=self.device, dtype=torch.int32)
         document.index_copy_(0, self._slot, d_ids)

@@ -43,8 +43,9 @@ void prof_begin(hipStream_t s);
 void prof_end(int tag, double work, hipStream_t s);
 
 // internal launchers implemented in graph_ops.hip / misc_ops.hip, used by the fused entry points
-int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const float* x,
-                float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s);
+// goff != NULL: node-compact layout (include/get_hip.h) -- graph g owns rows [goff[g], goff[g+1]); m_real = goff[n]
+int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const int32_t* goff,
+                int m_real, const float* x, float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s);
 int launch_gate_bwd_pre(const float* g, const float* z, const float* hh, const float* xp, float* dhp, float* dzp,
                         float* dxp, size_t count, hipStream_t s);
 int launch_colsum3(const float* a, const float* b, const float* c, float* oa, float* ob, float* oc, int m, int h,
@@ -53,11 +54,12 @@ int launch_colsum(const float* a, float* oa, int m, int h, hipStream_t s);
 void set_colsum_workspace(float* p, size_t bytes);
 int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m, int d, hipStream_t s,
                        float drop_p = 0.f, unsigned drop_seed = 0);
-int launch_att_softmax_fwd(const float* e, const float* mask, const float* right, int b, int l, int dr, int heads,
-                           float* weights, float* attended, hipStream_t s);
-int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w, int b,
-                           int l, int dr, int heads, float* de, float* dright, hipStream_t s);
-int launch_att_dpre(const float* de, const float* w2, const float* t, int b, int l, int ha, int heads, float* dpre,
-                    float* du, float* dw2_part, hipStream_t s);
+int launch_att_softmax_fwd(const float* e, const float* mask, const float* right, const int32_t* goff, int m_real,
+                           int b, int l, int dr, int heads, float* weights, float* attended, hipStream_t s);
+int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w,
+                           const int32_t* goff, int m_real, int b, int l, int dr, int heads, float* de, float* dright,
+                           hipStream_t s);
+int launch_att_dpre(const float* de, const float* w2, const float* t, const int32_t* goff, int m_real, int b, int l,
+                    int ha, int heads, float* dpre, float* du, float* dw2_part, hipStream_t s);
 
 }  // namespace gh

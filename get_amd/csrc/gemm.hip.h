@@ -27,7 +27,7 @@ enum EpiKind : int {
   EPI_SIGMOID_Z,   // z = sigmoid(v+bias) -> C
   EPI_SIGMOID_R,   // r = sigmoid(v+bias) -> C ; out1 = r * in0            (in0 = xp)
   EPI_TANH_H,      // h = tanh(v+bias) -> C ; out1 = h*z + xp*(1-z)        (in0 = z, in1 = xp)
-  EPI_ATT,         // t = tanh(v + u[row/R][col]) -> C ; e[row][c] = sum_col t*w2[c][col]
+  EPI_ATT,         // t = tanh(v + u[rowg ? rowg[row] : row/R][col]) -> C ; e[row][c] = sum_col t*w2[c][col]
   EPI_BWD_DRX,     // v = d(r*xp): C(drp) = v*xp*r*(1-r) ; out1(dxp) += v*r  (in0 = xp, in1 = r)
   EPI_ATOMIC,      // atomicAdd(C, v)   (TN split-K)
 };
@@ -49,6 +49,7 @@ struct Problem {
   float* out1;
   const float* in0; const float* in1;   // same leading dimension as C
   const float* u; const float* w2; float* e; int ldu; int R; int heads;
+  const int32_t* rowg;      // EPI_ATT: u row of output row m is rowg[m] when non-null (node-compact layout), else m / R
   long long split_stride;   // TN: element offset of K-chunk `ks`'s partial tile (0 = all chunks hit C, atomically)
   // stateless input dropout (wrapper.py:189-190): element (row, col) of the dropped matrix [rows][drop_ld] is kept
   // iff hash(seed, row*drop_ld + col) >= drop_thresh and then scaled by drop_scale = 1/(1-p).
@@ -291,7 +292,7 @@ gemm_kernel(const Launch L_byval) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) pe[c] = 0.f;
         if (mi < mi_cnt && row < M) {
-          const float* urow = P.u + (size_t)(row / P.R) * P.ldu;
+          const float* urow = P.u + (size_t)(P.rowg ? P.rowg[row] : row / P.R) * P.ldu;
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) {
             const int col = wcol + ni * 16 + l15;

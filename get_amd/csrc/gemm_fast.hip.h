@@ -252,6 +252,7 @@ gemm_fast_kernel(const Launch L_byval) {
     const int heads = P.heads;
     const float* U = P.u; const float* W2 = P.w2; float* E = P.e;
     const int ldu = P.ldu, R = P.R;
+    const int32_t* rowg = P.rowg;
     auto att_rows = [&](auto MI) __attribute__((always_inline)) {
       constexpr int mi = decltype(MI)::value;
       const int lrow = wrow + mi * 16 + l15;
@@ -260,7 +261,7 @@ gemm_fast_kernel(const Launch L_byval) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) pe[c] = 0.f;
       if (mi < mi_cnt && row < M) {
-        const float* urow = U + (size_t)(row / R) * ldu;
+        const float* urow = U + (size_t)(rowg ? rowg[row] : row / R) * ldu;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           const int col = wcol + ni * 16 + 4 * q;

@@ -98,6 +98,7 @@ reduce_partials_kernel(const ReduceArgs R) {
 struct FinishItem {
   const float* ws; long long stride; int ks; int M, N, epi, accumulate, ldc;
   float* C; const float* bias; const float* u; const float* w2; float* e; int ldu, R, heads;
+  const int32_t* rowg;
 };
 struct FinishArgs { FinishItem it[GH_MAX_PROBLEMS]; int n; };
 
@@ -121,7 +122,7 @@ nt_finish_kernel(const FinishArgs F) {
     }
     float* o = it.C + (size_t)row * it.ldc + col;
     if (it.epi == EPI_ATT) {
-      const float4 u4 = *reinterpret_cast<const float4*>(it.u + (size_t)(row / it.R) * it.ldu + col);
+      const float4 u4 = *reinterpret_cast<const float4*>(it.u + (size_t)(it.rowg ? it.rowg[row] : row / it.R) * it.ldu + col);
       const float4 t = make_float4(tanhf_(v.x + u4.x), tanhf_(v.y + u4.y), tanhf_(v.z + u4.z), tanhf_(v.w + u4.w));
       *reinterpret_cast<float4*>(o) = t;
 #pragma unroll
@@ -285,7 +286,7 @@ struct Batch {
     for (int i = 0; i < L.nprob; ++i) {
       Problem& q = L.p[i];
       F.it[i] = FinishItem{w, (long long)q.M * q.N, ks, q.M, q.N, q.epi, q.accumulate, q.ldc,
-                           q.C, q.bias, q.u, q.w2, q.e, q.ldu, q.R, q.heads};
+                           q.C, q.bias, q.u, q.w2, q.e, q.ldu, q.R, q.heads, q.rowg};
       q.C = w; q.ldc = q.N; q.epi = EPI_STORE; q.accumulate = 0; q.bias = nullptr;
       q.split_stride = (long long)q.M * q.N;
       w += (size_t)ks * q.M * q.N;
@@ -331,6 +332,7 @@ static Problem tn_problem(int I, int J, float* C, int ldc, const float* A, int l
 using namespace gh;
 
 extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                                const int32_t* goff, int m_real, int m_rows,
                                 const float* x, const int32_t* ids, int n, int r, int din, int h,
                                 const float* wt_p, const float* wt_z0, const float* wt_z1, const float* wt_r0,
                                 const float* wt_r1, const float* wt_h0, const float* wt_h1,
@@ -338,8 +340,11 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
                                 float* xp, float* a, float* z, float* rr, float* rx, float* hh, float* out,
                                 float drop_p, uint32_t drop_seed, gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  const int M = n * r;
   GH_REQUIRE(n > 0 && r > 0 && din > 0 && h > 0, "ggnn_cell_fwd: bad sizes n=%d r=%d din=%d h=%d", n, r, din, h);
+  if (!goff) { m_real = n * r; m_rows = n * r; }
+  GH_REQUIRE(m_real >= 0 && m_real <= m_rows && m_rows <= n * r, "ggnn_cell_fwd: node-compact rows %d/%d do not fit n*r=%d", m_real, m_rows, n * r);
+  const int M = m_rows;
+  if (M == 0) return 0;
   GH_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ggnn_cell_fwd: dropout p=%f not in [0,1)", drop_p);
   {  // xp = dropout(x) Wp^T   (wrapper.py:189-191); embedding rows gathered and the dropout mask applied in the A loader
     Batch b(false, M, s);
@@ -350,7 +355,9 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
     GH_REQUIRE(b.err != hipErrorInvalidValue || drop_p == 0.f, "ggnn_cell_fwd: fused dropout needs float4-shaped rows (din=%d, h=%d)", din, h);
     GH_CHECK_HIP(b.err);
   }
-  if (int e = launch_spmm(bits, dinv, vals, keep, xp, a, n, r, h, 0, 0, s)) return e;   // a = A_hat xp (:192)
+  if (int e = launch_spmm(bits, dinv, vals, keep, goff, m_real, xp, a, n, r, h, 0, 0, s)) return e;   // a = A_hat xp (:192)
+  if (m_rows > m_real)   // padding rows of the node-compact layout have no neighbours
+    GH_CHECK_HIP(hipMemsetAsync(a + (size_t)m_real * h, 0, sizeof(float) * (size_t)(m_rows - m_real) * h, s));
   {  // z, r gates (:194-200): [a | xp] . [W?0 | W?1]^T as two K segments
     Batch b(false, M, s);
     Problem pz = gemm_problem(M, h, EPI_SIGMOID_Z, z, h, a, h, wt_z0, h, h);
@@ -376,6 +383,7 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
 }
 
 extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                                const int32_t* goff, int m_real,
                                 const float* x, const int32_t* ids, int n, int r, int din, int h,
                                 const float* w_p, const float* w_z0, const float* w_z1, const float* w_r0,
                                 const float* w_r1, const float* w_h0, const float* w_h1,
@@ -387,8 +395,11 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
                                 float* db_z1, float* db_r1, float* db_h1, float drop_p, uint32_t drop_seed,
                                 gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  const int M = n * r;
   GH_REQUIRE(n > 0 && r > 0 && din > 0 && h > 0, "ggnn_cell_bwd: bad sizes");
+  if (!goff) m_real = n * r;
+  GH_REQUIRE(m_real >= 0 && m_real <= n * r, "ggnn_cell_bwd: node-compact rows %d do not fit n*r=%d", m_real, n * r);
+  const int M = m_real;      // padding rows receive no gradient and contribute none
+  if (M == 0) return 0;
   // out = h z + xp (1-z):  dhp = g z (1-h^2), dzp = g (h-xp) z (1-z), dxp = g (1-z)
   if (int e = launch_gate_bwd_pre(g, z, hh, xp, dhp, dzp, dxp, (size_t)M * h, s)) return e;
   {  // hp = a Wh0^T + (r xp) Wh1^T:  da = dhp Wh0 ; d(r xp) = dhp Wh1 -> drp, dxp += .
@@ -412,7 +423,7 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
     b.flush();
     GH_CHECK_HIP(b.err);
   }
-  if (int e = launch_spmm(bits, dinv, vals, keep, da, dxp, n, r, h, 1, 1, s)) return e;   // dxp += A_hat^T da
+  if (int e = launch_spmm(bits, dinv, vals, keep, goff, m_real, da, dxp, n, r, h, 1, 1, s)) return e;   // dxp += A_hat^T da
   if (dx) {  // dx = (dxp Wp) . mask/(1-p)
     Batch b(false, M, s);
     Problem p = gemm_problem(M, din, EPI_STORE, dx, din, dxp, h, w_p, din, h);
@@ -444,14 +455,18 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
   return launch_colsum3(dzp, drp, dhp, db_z, db_r, db_h, M, h, s, db_z1, db_r1, db_h1);
 }
 
-extern "C" int gh_concat_att_fwd(const float* left, const float* right, const float* mask, int b, int l, int xl,
+extern "C" int gh_concat_att_fwd(const float* left, const float* right, const float* mask, const int32_t* goff,
+                                 const int32_t* rowg, int m_real, int b, int l, int xl,
                                  int dr, int ha, int heads, const float* w1t, const float* w2,
                                  float* u, float* t, float* e, float* weights, float* attended,
                                  gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   GH_REQUIRE(heads >= 1 && heads <= 8, "concat_att: heads=%d not in [1,8]", heads);
   GH_REQUIRE(b > 0 && l > 0 && dr > 0 && ha > 0, "concat_att_fwd: bad sizes");
-  const int M = b * l;
+  GH_REQUIRE((goff == nullptr) == (rowg == nullptr), "concat_att_fwd: goff and rowg come together");
+  if (!goff) m_real = b * l;
+  GH_REQUIRE(m_real >= 0 && m_real <= b * l, "concat_att_fwd: node-compact rows %d do not fit b*l=%d", m_real, b * l);
+  const int M = m_real;
   GH_REQUIRE(ha <= ((M >= 8192 && big_cfg() == 0) ? GH_BN_BIG : GH_BN_SMALL), "concat_att_fwd: attention hidden %d exceeds one column block", ha);
   if (left && xl > 0) {  // u = W1[:, :xl] . left -- once per pair, not per token (two_branches_attention.py:137-140)
     Batch bt(false, b, s);
@@ -462,31 +477,33 @@ extern "C" int gh_concat_att_fwd(const float* left, const float* right, const fl
     GH_CHECK_HIP(hipMemsetAsync(u, 0, sizeof(float) * (size_t)b * ha, s));
     xl = 0;
   }
-  {  // t = tanh(W1[:, xl:] . right_t + u) ; e = W2 t  (:140-141)
+  if (M > 0) {  // t = tanh(W1[:, xl:] . right_t + u) ; e = W2 t  (:140-141)
     Batch bt(false, M, s);
     Problem p = gemm_problem(M, ha, EPI_ATT, t, ha, right, dr, w1t + (size_t)xl * ha, ha, dr);
-    p.u = u; p.ldu = ha; p.R = l; p.w2 = w2; p.heads = heads; p.e = e;
+    p.u = u; p.ldu = ha; p.R = l; p.w2 = w2; p.heads = heads; p.e = e; p.rowg = rowg;
     bt.add(p);
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }
-  return launch_att_softmax_fwd(e, mask, right, b, l, dr, heads, weights, attended, s);   // (:142-147)
+  return launch_att_softmax_fwd(e, mask, right, goff, m_real, b, l, dr, heads, weights, attended, s);   // (:142-147)
 }
 
-extern "C" int gh_concat_att_bwd(const float* left, const float* right, int b, int l, int xl, int dr, int ha,
-                                 int heads, const float* w1, const float* w2, const float* t, const float* weights,
+extern "C" int gh_concat_att_bwd(const float* left, const float* right, const int32_t* goff, int m_real, int b, int l,
+                                 int xl, int dr, int ha, int heads, const float* w1, const float* w2, const float* t, const float* weights,
                                  const float* g_att, const float* g_w, float* de, float* dpre, float* du,
                                  float* dleft, float* dright, float* dw1, float* dw2, gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   GH_REQUIRE(heads >= 1 && heads <= 8, "concat_att: heads=%d not in [1,8]", heads);
-  const int M = b * l;
+  if (!goff) m_real = b * l;
+  GH_REQUIRE(m_real >= 0 && m_real <= b * l, "concat_att_bwd: node-compact rows %d do not fit b*l=%d", m_real, b * l);
+  const int M = m_real;
   if (!left) xl = 0;
   const int ldw = xl + dr;
-  if (int e = launch_att_softmax_bwd(right, weights, g_att, g_w, b, l, dr, heads, de, dright, s)) return e;
+  if (int e = launch_att_softmax_bwd(right, weights, g_att, g_w, goff, m_real, b, l, dr, heads, de, dright, s)) return e;
   // dW2 = de^T t rides along with the dpre pass (per-pair partials in the workspace, one reduce)
   const size_t dw2_bytes = (size_t)b * heads * ha * sizeof(float);
   float* dw2_part = (g_ws && dw2_bytes <= g_ws_bytes && ha % 4 == 0) ? g_ws : nullptr;
-  if (int e = launch_att_dpre(de, w2, t, b, l, ha, heads, dpre, du, dw2_part, s)) return e;
+  if (int e = launch_att_dpre(de, w2, t, goff, m_real, b, l, ha, heads, dpre, du, dw2_part, s)) return e;
   if (dw2_part) {
     ReduceArgs R;
     R.n = 1;
@@ -494,7 +511,7 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, int b, i
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((heads * (ha / 4) + 255) / 256, 1), dim3(256), 0, s, R);
     GH_LAUNCH_CHECK();
   }
-  {  // dright += dpre W1[:, xl:]
+  if (M > 0) {  // dright += dpre W1[:, xl:]
     Batch bt(false, M, s);
     Problem p = gemm_problem(M, dr, EPI_STORE, dright, dr, dpre, ha, w1 + xl, ldw, ha);
     p.accumulate = 1;
@@ -508,13 +525,13 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, int b, i
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }
-  {
+  if (M > 0) {
     Batch bt(true, M, s);
     bt.add(tn_problem(ha, dr, dw1 + xl, ldw, dpre, ha, right, dr, M));
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }
-  if (!dw2_part) {  // no workspace: `heads` rows are not float4-shaped, so this one takes the generic kernel
+  if (!dw2_part && M > 0) {  // no workspace: `heads` rows are not float4-shaped, so this one takes the generic kernel
     Batch bt(true, M, s);
     bt.add(tn_problem(heads, ha, dw2, ha, de, heads, t, ha, M));
     bt.flush();

@@ -131,8 +131,8 @@ adj_unpack_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ d
 template <int V>   // V = 4: float4 columns, V = 1: scalar columns
 __global__ void __launch_bounds__(256)
 spmm_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
-            const uint64_t* __restrict__ keep, const float* __restrict__ x, float* __restrict__ y, int R, int H,
-            int slab, int transpose, int accumulate) {
+            const uint64_t* __restrict__ keep, const int32_t* __restrict__ goff, const float* __restrict__ x,
+            float* __restrict__ y, int R, int H, int slab, int transpose, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   const int W = (R + 63) / 64;
   float* xs = reinterpret_cast<float*>(dsm);                                  // [R][slab*V]
@@ -143,7 +143,12 @@ spmm_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, c
   const int c0 = blockIdx.y * slab;                 // first column (in units of V floats)
   const int HV = H / V;
   const int ncol = min(slab, HV - c0);
-  const float* xg = x + (size_t)g * R * H;
+  // node-compact layout: graph g owns feature rows [goff[g], goff[g+1]) -- its real nodes only; bit rows, dinv and
+  // vals keep their padded [g][R] indexing (node i of graph g is feature row goff[g] + i)
+  const int row0 = goff ? goff[g] : g * R;
+  const int NR = goff ? goff[g + 1] - row0 : R;
+  if (NR <= 0) return;
+  const float* xg = x + (size_t)row0 * H;
   // Stage everything with ONE memory round trip: the slab (up to SL 16-byte loads per thread from a clamped
   // index -- unconditional, so no branch or per-load s_waitcnt), this thread's bit-row word and dinv entry
   // are all issued back to back; sched_barrier keeps them ahead of the first LDS write (the scheduler otherwise
@@ -151,7 +156,7 @@ spmm_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, c
   // element with its own value, which keeps the stores unconditional too.
   {
     constexpr int SL = 12;
-    const int total = R * ncol;
+    const int total = NR * ncol;
     // bit rows / dinv first (R*W <= 1024 and R <= 256 -> at most 4 + 1 per thread); consumed after the slab
     unsigned long long mw[4];
 #pragma unroll
@@ -190,8 +195,8 @@ spmm_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, c
   }
   __syncthreads();
   const float* vg = vals ? vals + (size_t)g * R * R : nullptr;
-  float* yg = y + (size_t)g * R * H;
-  for (int it = tid; it < R * ncol; it += 256) {
+  float* yg = y + (size_t)row0 * H;
+  for (int it = tid; it < NR * ncol; it += 256) {
     const int i = it / ncol, c = it % ncol;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const float di = vals ? 0.f : dv[i];
@@ -346,8 +351,8 @@ spmm_wave_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
   }
 }
 
-int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const float* x,
-                float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s) {
+int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const int32_t* goff,
+                int m_real, const float* x, float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s) {
   GH_REQUIRE(r <= MAX_R, "spmm: padded graph size %d > %d", r, MAX_R);
   GH_REQUIRE(vals || dinv, "spmm: need dinv or vals");
   const int W = words_for(r);
@@ -361,35 +366,75 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   const size_t lds = ((((size_t)r * slab * V) + 3) & ~(size_t)3) * 4 + (size_t)r * W * 8 + (size_t)r * 4;
   dim3 grid(n, nslab);
   // algorithmic bytes: x in + y out (+ y in when accumulating) + bit rows + dinv (or the touched dense values)
-  const double alg_bytes = (double)n * ((2.0 + (accumulate ? 1.0 : 0.0)) * r * h * 4.0 + (double)r * W * 8.0 +
-                                        (vals ? (double)r * r * 4.0 : (double)r * 4.0));
+  const double rows = goff ? (double)m_real : (double)n * r;
+  const double alg_bytes = (2.0 + (accumulate ? 1.0 : 0.0)) * rows * h * 4.0 +
+                           (double)n * ((double)r * W * 8.0 + (vals ? (double)r * r * 4.0 : (double)r * 4.0));
   // 0 (default): LDS-staged slab kernel -- every feature row leaves HBM exactly once (FETCH ~= algorithmic bytes);
   // 1 / 2: LDS-free gather variants (thread-per-float4 / wave-per-row).  Measured equal or slower on MI355X: with
   // ~8K waves in flight their sliding-window working set (~49 MB) thrashes the 32 MB of L2 (hit rate 32 %).
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("GH_SPMM_VARIANT"); variant = e ? atoi(e) : 0; }
   prof_begin(s);
-  if (v4 && variant == 2 && h / 4 <= 128) {
+  if (v4 && variant == 2 && h / 4 <= 128 && !goff) {
     constexpr int RPW = 5;
     const int wpg = (r + RPW - 1) / RPW;
     hipLaunchKernelGGL(spmm_wave_kernel<RPW>, dim3((n * wpg + 3) / 4), dim3(256), 0, s, bits, dinv, vals, keep, x, y, r, h,
                        transpose, accumulate, wpg);
-  } else if (v4 && variant == 1) {
+  } else if (v4 && variant == 1 && !goff) {
     const int bpg = (r * (h / 4) + 2047) / 2048;      // ~8 float4 outputs per thread
     hipLaunchKernelGGL(spmm_gather_kernel, dim3(n * bpg), dim3(256), 0, s, bits, dinv, vals, keep, x, y, r, h, transpose,
                        accumulate, bpg);
   } else if (v4) {
     static bool attr4 = false;     // only raise the dynamic-LDS cap when a launch actually needs more than 64 KB
     if (!attr4 && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)spmm_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr4 = true; }
-    hipLaunchKernelGGL(spmm_kernel<4>, grid, dim3(256), lds, s, bits, dinv, vals, keep, x, y, r, h, slab, transpose, accumulate);
+    hipLaunchKernelGGL(spmm_kernel<4>, grid, dim3(256), lds, s, bits, dinv, vals, keep, goff, x, y, r, h, slab, transpose, accumulate);
   } else {
     static bool attr1 = false;
     if (!attr1 && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)spmm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
-    hipLaunchKernelGGL(spmm_kernel<1>, grid, dim3(256), lds, s, bits, dinv, vals, keep, x, y, r, h, slab, transpose, accumulate);
+    hipLaunchKernelGGL(spmm_kernel<1>, grid, dim3(256), lds, s, bits, dinv, vals, keep, goff, x, y, r, h, slab, transpose, accumulate);
   }
   prof_end(PROF_SPMM, alg_bytes, s);
   GH_LAUNCH_CHECK();
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// node-compact layout plan.  goff = exclusive prefix sum of the node counts (one workgroup, n <= a few
+// thousand graphs), then one workgroup per graph fills the row maps.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+ragged_scan_kernel(const int32_t* __restrict__ n_nodes, int n, int R, int32_t* __restrict__ goff) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = min(tid * per, n), hi = min(lo + per, n);
+  int sum = 0;
+  for (int g = lo; g < hi; ++g) sum += min(max(n_nodes[g], 0), R);
+  part[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {          // Hillis-Steele inclusive scan of the per-thread sums
+    const int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - sum;
+  for (int g = lo; g < hi; ++g) { goff[g] = run; run += min(max(n_nodes[g], 0), R); }
+  if (tid == 1023) goff[n] = part[1023];
+}
+
+__global__ void __launch_bounds__(256)
+ragged_fill_kernel(const int32_t* __restrict__ goff, const int32_t* __restrict__ node_ids, int n, int R,
+                   int32_t* __restrict__ rowg, int32_t* __restrict__ src, int32_t* __restrict__ cids) {
+  const int g = blockIdx.x;
+  const int row0 = goff[g], NR = goff[g + 1] - row0;
+  const int pad0 = goff[n] + g * R - row0 - NR;
+  for (int j = threadIdx.x; j < R; j += 256) {
+    const int row = j < NR ? row0 + j : pad0 + j;
+    rowg[row] = g;
+    src[row] = g * R + j;
+    if (cids) cids[row] = node_ids[(size_t)g * R + j];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -415,32 +460,39 @@ __device__ __forceinline__ void topk_keep(const float* ss, int R, int k, uint64_
 // word scorer (GGNN 300->1, wrapper.py:167) + GSL top-k (:216-219), one workgroup per graph
 __global__ void __launch_bounds__(256)
 scorer_gsl_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
-                  const float* __restrict__ feat, const float* __restrict__ w_p, const float* __restrict__ gate,
-                  int R, int H, int k, float* __restrict__ score, uint64_t* __restrict__ keep, unsigned drop_thresh,
+                  const int32_t* __restrict__ goff, const float* __restrict__ feat, const float* __restrict__ w_p,
+                  const float* __restrict__ gate, int R, int H, int k, float* __restrict__ score, uint64_t* __restrict__ keep, unsigned drop_thresh,
                   float drop_scale, unsigned drop_seed) {
   __shared__ float xs[MAX_R];
   __shared__ float ss[MAX_R];
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = (R + 63) / 64;
-  const float* fg = feat + (size_t)g * R * H;
+  // node-compact layout: real node j < NR sits in feature row goff[g] + j; padding node j >= NR of graph g in row
+  // goff[n] + (g*R - goff[g]) + (j - NR)  (all padding rows follow the real rows of the whole batch).  The padding
+  // nodes still compete in the top-k with their own (bias- and dropout-driven) scores, as in wrapper.py:216-219.
+  const int row0 = goff ? goff[g] : g * R;
+  const int NR = goff ? goff[g + 1] - row0 : R;
+  const int pad0 = goff ? goff[gridDim.x] + g * R - row0 - NR : row0;
   // x_j = feat_j . w_p   (proj, no bias)
   const bool v4 = (H % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat) & 15) == 0) && ((reinterpret_cast<uintptr_t>(w_p) & 15) == 0);
 #pragma unroll 4
   for (int j = wave; j < R; j += 4) {
     float acc = 0.f;
+    const unsigned frow = (unsigned)(j < NR ? row0 + j : pad0 + j);
+    const float* fg = feat + (size_t)frow * H;
     if (v4) {
-      const float4* fr = reinterpret_cast<const float4*>(fg + (size_t)j * H);
+      const float4* fr = reinterpret_cast<const float4*>(fg);
       const float4* wr = reinterpret_cast<const float4*>(w_p);
       for (int c = lane; c < H / 4; c += 64) {
         float4 a = fr[c];
         const float4 b = wr[c];
-        if (drop_thresh) a = drop4(a, drop_seed, (unsigned)(g * R + j) * (unsigned)H + 4u * c, drop_thresh, drop_scale);
+        if (drop_thresh) a = drop4(a, drop_seed, frow * (unsigned)H + 4u * c, drop_thresh, drop_scale);
         acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
       }
     } else {
       for (int c = lane; c < H; c += 64) {
-        float a = fg[(size_t)j * H + c];
-        if (drop_thresh) a = drop_hash(drop_seed, (unsigned)(g * R + j) * (unsigned)H + c) >= drop_thresh ? a * drop_scale : 0.f;
+        float a = fg[c];
+        if (drop_thresh) a = drop_hash(drop_seed, frow * (unsigned)H + c) >= drop_thresh ? a * drop_scale : 0.f;
         acc += a * w_p[c];
       }
     }
@@ -501,6 +553,17 @@ extern "C" int gh_graph_build(const int32_t* tokens, const int32_t* lengths, int
   return 0;
 }
 
+extern "C" int gh_ragged_plan(const int32_t* n_nodes, const int32_t* node_ids, int n, int r, int32_t* goff,
+                              int32_t* rowg, int32_t* src, int32_t* cids, gh_stream_t stream) {
+  GH_REQUIRE(r > 0 && r <= MAX_R, "ragged_plan: r=%d not in [1,%d]", r, MAX_R);
+  GH_REQUIRE((cids == nullptr) || (node_ids != nullptr), "ragged_plan: cids needs node_ids");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(ragged_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_nodes, n, r, goff);
+  hipLaunchKernelGGL(ragged_fill_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, goff, node_ids, n, r, rowg, src, cids);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int gh_adj_pack_f64(const double* adj, int n, int r, uint64_t* bits, float* vals, gh_stream_t stream) {
   GH_REQUIRE(r > 0 && r <= MAX_R, "adj_pack: r=%d not in [1,%d]", r, MAX_R);
   if (n <= 0) return 0;
@@ -527,14 +590,14 @@ extern "C" int gh_adj_unpack(const uint64_t* bits, const float* dinv, const floa
 }
 
 extern "C" int gh_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
-                       const float* x, float* y, int n, int r, int h, int transpose, int accumulate,
-                       gh_stream_t stream) {
+                       const int32_t* goff, int m_real, const float* x, float* y, int n, int r, int h, int transpose,
+                       int accumulate, gh_stream_t stream) {
   if (n <= 0) return 0;
-  return launch_spmm(bits, dinv, vals, keep, x, y, n, r, h, transpose, accumulate, (hipStream_t)stream);
+  return launch_spmm(bits, dinv, vals, keep, goff, m_real, x, y, n, r, h, transpose, accumulate, (hipStream_t)stream);
 }
 
-extern "C" int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const float* feat,
-                             const float* w_p, const float* gate, int n, int r, int h, int k, float* score,
+extern "C" int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const int32_t* goff,
+                             const float* feat, const float* w_p, const float* gate, int n, int r, int h, int k, float* score,
                              uint64_t* keep, float drop_p, uint32_t drop_seed, gh_stream_t stream) {
   GH_REQUIRE(r > 0 && r <= MAX_R, "scorer_gsl: r=%d not in [1,%d]", r, MAX_R);
   GH_REQUIRE(vals || dinv, "scorer_gsl: need dinv or vals");
@@ -543,8 +606,8 @@ extern "C" int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const floa
   GH_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "scorer_gsl: dropout p=%f not in [0,1)", drop_p);
   const double th = (double)drop_p * 4294967296.0;
   const unsigned thresh = drop_p > 0.f ? (th >= 4294967295.0 ? 4294967295u : (unsigned)th) : 0u;
-  hipLaunchKernelGGL(scorer_gsl_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, bits, dinv, vals, feat, w_p,
-                     gate, r, h, k, score, keep, thresh, 1.0f / (1.0f - drop_p), drop_seed);
+  hipLaunchKernelGGL(scorer_gsl_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, bits, dinv, vals, goff, feat,
+                     w_p, gate, r, h, k, score, keep, thresh, 1.0f / (1.0f - drop_p), drop_seed);
   prof_end(PROF_SCORER_GSL, (double)n * (4.0 * r * h + 8.0 * r * words_for(r) + 8.0 * r + 8.0 * words_for(r)),
            (hipStream_t)stream);
   GH_LAUNCH_CHECK();

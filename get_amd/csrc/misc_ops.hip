@@ -287,12 +287,16 @@ int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m
 // e [b][l][C] -> weights = softmax over l (two_branches_attention.py:142-146), attended[b][d][c] = sum_l right[b][l][d] w[l][c] (:147)
 __global__ void __launch_bounds__(256)
 att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ mask, const float* __restrict__ right,
-                       int L, int Dr, int C, float* __restrict__ weights, float* __restrict__ attended) {
+                       const int32_t* __restrict__ goff, int Lmax, int Dr, int C, float* __restrict__ weights,
+                       float* __restrict__ attended) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-  float* ws = reinterpret_cast<float*>(dsm);   // [L][C]
+  float* ws = reinterpret_cast<float*>(dsm);   // [Lmax][C]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* eb = e + (size_t)b * L * C;
-  const float* mb = mask + (size_t)b * L;
+  // node-compact layout: pair b owns rows [goff[b], goff[b+1]) of e / mask / right / weights
+  const int row0 = goff ? goff[b] : b * Lmax;
+  const int L = goff ? goff[b + 1] - row0 : Lmax;
+  const float* eb = e + (size_t)row0 * C;
+  const float* mb = mask + (size_t)row0;
   for (int c = wave; c < C; c += 4) {
     float mx = -INFINITY;
     for (int l = lane; l < L; l += 64)
@@ -310,10 +314,10 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
   }
   __syncthreads();
   if (blockIdx.y == 0)
-    for (int i = tid; i < L * C; i += 256) weights[(size_t)b * L * C + i] = ws[i];
+    for (int i = tid; i < L * C; i += 256) weights[(size_t)row0 * C + i] = ws[i];
   // attended[d][c] = sum_l right[l][d] w[l][c]: blockIdx.y owns a slab of 64 float4 columns, the four
   // waves take every fourth row (16-byte coalesced reads), partial sums meet in LDS
-  float* part = ws + L * C;                      // [4][64][4][C] floats
+  float* part = ws + Lmax * C;                   // [4][64][4][C] floats
   const int D4 = Dr / 4;
   const int d4 = blockIdx.y * 64 + lane;
   float acc[4][8];
@@ -322,7 +326,7 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
   if (d4 < D4) {
-    const float4* rb = reinterpret_cast<const float4*>(right + (size_t)b * L * Dr) + d4;
+    const float4* rb = reinterpret_cast<const float4*>(right + (size_t)row0 * Dr) + d4;
 #pragma unroll 4
     for (int l = wave; l < L; l += 4) {
       const float4 rv = rb[(size_t)l * D4];
@@ -346,20 +350,22 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
     if (dd < Dr) {
       float v = 0.f;
       for (int w = 0; w < 4; ++w) v += part[((w * 64 + ln) * 4) * C + rem];
+      if (L == 0) v = NAN;                      // no rows at all: the reference's softmax over an all -inf column
       attended[((size_t)b * Dr + dd) * C + rem % C] = v;
     }
   }
 }
 
-int launch_att_softmax_fwd(const float* e, const float* mask, const float* right, int b, int l, int dr, int heads,
-                           float* weights, float* attended, hipStream_t s) {
+int launch_att_softmax_fwd(const float* e, const float* mask, const float* right, const int32_t* goff, int m_real,
+                           int b, int l, int dr, int heads, float* weights, float* attended, hipStream_t s) {
   GH_REQUIRE(dr % 4 == 0 && (reinterpret_cast<uintptr_t>(right) & 15) == 0, "att_softmax_fwd: right rows must be float4-shaped (dr=%d)", dr);
   const size_t lds = ((size_t)l * heads + 4 * 64 * 4 * heads) * 4;
   GH_REQUIRE(lds <= 64 * 1024, "att_softmax_fwd: sequence %d x heads %d too large", l, heads);
   prof_begin(s);
-  hipLaunchKernelGGL(att_softmax_fwd_kernel, dim3(b, (dr / 4 + 63) / 64), dim3(256), lds, s, e, mask, right, l, dr,
+  hipLaunchKernelGGL(att_softmax_fwd_kernel, dim3(b, (dr / 4 + 63) / 64), dim3(256), lds, s, e, mask, right, goff, l, dr,
                      heads, weights, attended);
-  prof_end(PROF_ATT_SOFTMAX_FWD, 4.0 * (double)b * ((double)l * dr + 2.0 * l * heads + l + (double)dr * heads), s);
+  const double rows = goff ? (double)m_real : (double)b * l;
+  prof_end(PROF_ATT_SOFTMAX_FWD, 4.0 * (rows * dr + 2.0 * rows * heads + rows + (double)b * dr * heads), s);
   GH_LAUNCH_CHECK();
   return 0;
 }
@@ -368,15 +374,18 @@ int launch_att_softmax_fwd(const float* e, const float* mask, const float* right
 // dright[l][d] = sum_c w[l][c] g_att[d][c]  (first contribution; the GEMM adds dpre W1r on top)
 __global__ void __launch_bounds__(256)
 att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict__ weights,
-                       const float* __restrict__ g_att, const float* __restrict__ g_w, int L, int Dr, int C,
+                       const float* __restrict__ g_att, const float* __restrict__ g_w,
+                       const int32_t* __restrict__ goff, int Lmax, int Dr, int C,
                        float* __restrict__ de, float* __restrict__ dright) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   float* ga = reinterpret_cast<float*>(dsm);   // [Dr][C]
-  float* ws = ga + (size_t)Dr * C;             // [L][C]
-  float* dw = ws + (size_t)L * C;              // [L][C]
+  float* ws = ga + (size_t)Dr * C;             // [Lmax][C]
+  float* dw = ws + (size_t)Lmax * C;           // [Lmax][C]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = goff ? goff[b] : b * Lmax;
+  const int L = goff ? goff[b + 1] - row0 : Lmax;
   for (int i = tid; i < Dr * C; i += 256) ga[i] = g_att[(size_t)b * Dr * C + i];
-  for (int i = tid; i < L * C; i += 256) ws[i] = weights[(size_t)b * L * C + i];
+  for (int i = tid; i < L * C; i += 256) ws[i] = weights[(size_t)row0 * C + i];
   __syncthreads();
   const int D4 = Dr / 4;
 #pragma unroll 2
@@ -384,8 +393,8 @@ att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict_
     float part[8], wl[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) { part[c] = 0.f; wl[c] = (c < C) ? ws[l * C + c] : 0.f; }
-    const float4* rr = reinterpret_cast<const float4*>(right + ((size_t)b * L + l) * Dr);
-    float4* dr_ = reinterpret_cast<float4*>(dright + ((size_t)b * L + l) * Dr);
+    const float4* rr = reinterpret_cast<const float4*>(right + ((size_t)row0 + l) * Dr);
+    float4* dr_ = reinterpret_cast<float4*>(dright + ((size_t)row0 + l) * Dr);
     for (int d4 = lane; d4 < D4; d4 += 64) {
       const float4 rv = rr[d4];
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -403,7 +412,7 @@ att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict_
     for (int c = 0; c < 8; ++c) {
       float v = part[c];
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-      if (lane == 0 && c < C) dw[l * C + c] = v + (g_w ? g_w[((size_t)b * L + l) * C + c] : 0.f);
+      if (lane == 0 && c < C) dw[l * C + c] = v + (g_w ? g_w[((size_t)row0 + l) * C + c] : 0.f);
     }
   }
   __syncthreads();
@@ -412,12 +421,13 @@ att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict_
     for (int l = lane; l < L; l += 64) sum += ws[l * C + c] * dw[l * C + c];
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     for (int l = lane; l < L; l += 64)
-      de[((size_t)b * L + l) * C + c] = ws[l * C + c] * (dw[l * C + c] - sum);
+      de[((size_t)row0 + l) * C + c] = ws[l * C + c] * (dw[l * C + c] - sum);
   }
 }
 
-int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w, int b,
-                           int l, int dr, int heads, float* de, float* dright, hipStream_t s) {
+int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w,
+                           const int32_t* goff, int m_real, int b, int l, int dr, int heads, float* de, float* dright,
+                           hipStream_t s) {
   GH_REQUIRE(dr % 4 == 0 && (reinterpret_cast<uintptr_t>(right) & 15) == 0 && (reinterpret_cast<uintptr_t>(dright) & 15) == 0,
              "att_softmax_bwd: right rows must be float4-shaped (dr=%d)", dr);
   const size_t lds = ((size_t)dr * heads + 2 * (size_t)l * heads) * 4;
@@ -425,9 +435,10 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
   static bool attr = false;
   if (!attr && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)att_softmax_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   prof_begin(s);
-  hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(b), dim3(256), lds, s, right, weights, g_att, g_w, l, dr, heads, de,
+  hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(b), dim3(256), lds, s, right, weights, g_att, g_w, goff, l, dr, heads, de,
                      dright);
-  prof_end(PROF_ATT_SOFTMAX_BWD, 4.0 * (double)b * (2.0 * l * dr + 3.0 * l * heads + (double)dr * heads), s);
+  const double rows = goff ? (double)m_real : (double)b * l;
+  prof_end(PROF_ATT_SOFTMAX_BWD, 4.0 * (2.0 * rows * dr + 3.0 * rows * heads + (double)b * dr * heads), s);
   GH_LAUNCH_CHECK();
   return 0;
 }
@@ -436,11 +447,13 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
 // dw2 partial [b][c][n] = sum_l de[m][c] t[m][n]   (summed over b by reduce_partials afterwards).
 // One workgroup per pair: threads = (float4 column, row lane); row lanes take every RL-th row.
 __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __restrict__ w2, const float* __restrict__ t,
-                                int L, int Ha, int C, int RL, float* __restrict__ dpre, float* __restrict__ du,
-                                float* __restrict__ dw2_part) {
+                                const int32_t* __restrict__ goff, int Lmax, int Ha, int C, int RL,
+                                float* __restrict__ dpre, float* __restrict__ du, float* __restrict__ dw2_part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   float4* red = reinterpret_cast<float4*>(dsm);           // [RL][1 + C][n4]
   const int b = blockIdx.x;
+  const int row0 = goff ? goff[b] : b * Lmax;
+  const int L = goff ? goff[b + 1] - row0 : Lmax;
   const int n4 = Ha / 4;
   const int c4 = threadIdx.x % n4, rl = threadIdx.x / n4;
   float4 wc[8];
@@ -453,7 +466,7 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
   if (rl < RL) {
 #pragma unroll 4
     for (int l = rl; l < L; l += RL) {
-      const size_t m = (size_t)b * L + l;
+      const size_t m = (size_t)row0 + l;
       const float4 tv = reinterpret_cast<const float4*>(t + m * Ha)[c4];
       float4 dt = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -486,16 +499,17 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
   }
 }
 
-int launch_att_dpre(const float* de, const float* w2, const float* t, int b, int l, int ha, int heads, float* dpre,
-                    float* du, float* dw2_part, hipStream_t s) {
+int launch_att_dpre(const float* de, const float* w2, const float* t, const int32_t* goff, int m_real, int b, int l,
+                    int ha, int heads, float* dpre, float* du, float* dw2_part, hipStream_t s) {
   GH_REQUIRE(ha % 4 == 0 && ha / 4 <= 256, "att_dpre: attention hidden %d must be a multiple of 4 and <= 1024", ha);
   const int n4 = ha / 4;
   const int RL = (256 / n4) > 0 ? (256 / n4) : 1;
   const int threads = ((n4 * RL + 63) / 64) * 64;
   const size_t lds = (size_t)RL * (1 + heads) * n4 * 16;
   prof_begin(s);
-  hipLaunchKernelGGL(att_dpre_kernel, dim3(b), dim3(threads), lds, s, de, w2, t, l, ha, heads, RL, dpre, du, dw2_part);
-  prof_end(PROF_ATT_DPRE, 4.0 * (double)b * (2.0 * l * ha + (double)l * heads + ha), s);
+  hipLaunchKernelGGL(att_dpre_kernel, dim3(b), dim3(threads), lds, s, de, w2, t, goff, l, ha, heads, RL, dpre, du, dw2_part);
+  const double rows = goff ? (double)m_real : (double)b * l;
+  prof_end(PROF_ATT_DPRE, 4.0 * (2.0 * rows * ha + rows * heads + (double)b * ha), s);
   GH_LAUNCH_CHECK();
   return 0;
 }

@@ -75,25 +75,31 @@ class GGNN(nn.Module):
             return (float(self.dropout.p), ops.new_dropout_seed())
         return None
 
-    def forward(self, adj, x):
+    def forward(self, adj, x, plan=None, rows=0):
         """adj: dense (N,R,R) or PackedAdj; x: (N,R,Din).  Returns (N,R,Dout).
-        Training-mode input dropout (wrapper.py:189-190) runs inside the first GEMM's loader."""
+        Training-mode input dropout (wrapper.py:189-190) runs inside the first GEMM's loader.
+        plan (ops.RaggedPlan, internal fast path): x is node-compact (>= rows, Din); returns (rows, Dout)."""
         adj = ops.as_packed(adj)
         d = self._drop()
         if d is None:
-            return ops.ggnn_cell(adj, self.dropout(x), None, self._params())
-        return ops.ggnn_cell(adj, x, None, self._params(), d[0], d[1])
+            return ops.ggnn_cell(adj, self.dropout(x), None, self._params(), plan=plan, rows=rows)
+        return ops.ggnn_cell(adj, x, None, self._params(), d[0], d[1], plan=plan, rows=rows)
 
-    def forward_ids(self, adj, embedding: nn.Embedding, ids: torch.Tensor):
+    def forward_ids(self, adj, embedding: nn.Embedding, ids: torch.Tensor, plan=None, rows=0):
         """Same cell on ``embedding(ids)`` with the row gather fused into the first GEMM
         (graph_based_semantic_structure.py:100,150); training-mode dropout is applied there too.  Falls
-        back to an explicit lookup + nn.Dropout only for widths that are not float4-shaped."""
+        back to an explicit lookup + nn.Dropout only for widths that are not float4-shaped.
+        plan: node-compact layout, the ids come from ``plan.cids``; returns (rows, Dout)."""
         adj = ops.as_packed(adj)
         d = self._drop()
+        if plan is not None:
+            rows = rows or plan.m_real
+            ids = plan.cids[:rows]
         if d is None:
             x = self.dropout(embedding(ids.long()))
-            return ops.ggnn_cell(adj, x, None, self._params())
-        return ops.ggnn_cell(adj, embedding.weight, ids.to(torch.int32).reshape(-1), self._params(), d[0], d[1])
+            return ops.ggnn_cell(adj, x, None, self._params(), plan=plan, rows=rows)
+        return ops.ggnn_cell(adj, embedding.weight, ids.to(torch.int32).reshape(-1), self._params(), d[0], d[1],
+                             plan=plan, rows=rows)
 
 
 # ------------------------------------------------------------------ Models/BiDAF/wrapper.py:210-227
@@ -131,13 +137,13 @@ class GGNN_with_GSL(nn.Module):
             parts += [m.linear.weight.reshape(1), m.linear.bias.reshape(1)]
         return torch.cat(parts)
 
-    def _refine(self, adj: PackedAdj, feat):
+    def _refine(self, adj: PackedAdj, feat, plan=None):
         s = self.word_scorer1
         drop_p, seed = 0.0, 0
         if hasattr(s, "dropout") and self.training and s.dropout.p > 0:
             drop_p, seed = float(s.dropout.p), ops.new_dropout_seed()   # word_scorer1's own input dropout (wrapper.py:189-190)
         k = int(self.gsl1.rate * adj.r)
-        score, keep = ops.scorer_gsl(adj, feat, s.proj.linear.weight, self._gate12(), k, drop_p, seed)
+        score, keep = ops.scorer_gsl(adj, feat, s.proj.linear.weight, self._gate12(), k, drop_p, seed, plan=plan)
         self.last_score, self.last_keep = score, keep
         return adj.with_keep(keep)
 
@@ -147,11 +153,18 @@ class GGNN_with_GSL(nn.Module):
         adj_refined = self._refine(adj, feat)
         return self.feat_prop2(adj_refined, feat)
 
-    def forward_ids(self, adj, embedding, ids):
+    def forward_ids(self, adj, embedding, ids, plan=None):
+        """plan (ops.RaggedPlan): node-compact fast path -- the first cell and the scorer run on every row (the
+        padding nodes' scores compete in the top-k), the second cell on the real-node rows only; returns
+        (plan.m_real, H) instead of (N,R,H)."""
         adj = ops.as_packed(adj)
-        feat = self.feat_prop1.forward_ids(adj, embedding, ids)
-        adj_refined = self._refine(adj, feat)
-        return self.feat_prop2(adj_refined, feat)
+        if plan is None:
+            feat = self.feat_prop1.forward_ids(adj, embedding, ids)
+            adj_refined = self._refine(adj, feat)
+            return self.feat_prop2(adj_refined, feat)
+        feat = self.feat_prop1.forward_ids(adj, embedding, ids, plan=plan, rows=plan.m_tot)
+        adj_refined = self._refine(adj, feat, plan)
+        return self.feat_prop2(adj_refined, feat, plan=plan, rows=plan.m_real)
 
 
 # ------------------------------------------------------------------ Models/BiDAF/wrapper.py:229-276
@@ -177,11 +190,13 @@ class ConcatNotEqualSelfAtt(nn.Module):
         self.linear1 = nn.Linear(inp_dim, out_dim, bias=False)
         self.linear2 = nn.Linear(out_dim, num_heads, bias=False)
 
-    def forward(self, left: torch.Tensor, right: torch.Tensor, mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        assert left.size(0) == right.size(0), "Must same dimensions"
-        assert len(left.size()) == 2 and len(right.size()) == 3
+    def forward(self, left: torch.Tensor, right: torch.Tensor, mask: torch.Tensor, plan=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """plan (ops.RaggedPlan): `right` / `mask` are node-compact (m_real, D) / (m_real,), weights come back compact."""
+        if plan is None:
+            assert left.size(0) == right.size(0), "Must same dimensions"
+            assert len(left.size()) == 2 and len(right.size()) == 3
         assert self.inp_dim == (left.size(-1) + right.size(-1))
-        return ops.concat_att(left, right, mask, self.linear1.weight, self.linear2.weight)
+        return ops.concat_att(left, right, mask, self.linear1.weight, self.linear2.weight, plan)
 
 
 class ConcatSelfAtt(ConcatNotEqualSelfAtt):
@@ -319,11 +334,19 @@ class Graph_basedSemantiStructure(nn.Module):
         q_repr = ops.masked_mean(q_hid, query, kargs[K.Query_lens])            # (B, H)
         query_repr = ops.seg_broadcast(q_repr, seg)                            # (B1, H)
 
-        # evidence branch (:107): GGNN -> scorer + GSL -> GGNN on the refined graph
-        doc_out = self.ggnn_with_gsl.forward_ids(kargs[K.Evd_Docs_Adj], self.embedding, doc)
+        # evidence branch (:107): GGNN -> scorer + GSL -> GGNN on the refined graph.  A PackedAdj that carries a
+        # node-compact plan (NativeBatch) takes the fast path that skips the padding nodes wherever they cannot
+        # influence a result (ops.RaggedPlan); anything else runs the reference's padded layout.
+        d_adj = kargs[K.Evd_Docs_Adj]
+        plan = d_adj.plan if isinstance(d_adj, PackedAdj) else None
+        doc_out = self.ggnn_with_gsl.forward_ids(d_adj, self.embedding, doc, plan=plan)
 
         # word-level attention (:173-193); the claim vector WITHOUT its source embedding (:110)
-        att, word_att_weights = self.self_att_word(query_repr, doc_out, doc >= 1)
+        if plan is None:
+            att, word_att_weights = self.self_att_word(query_repr, doc_out, doc >= 1)
+        else:
+            att, word_w = self.self_att_word(query_repr, doc_out, plan.cids[:plan.m_real] >= 1, plan=plan)
+            word_att_weights = None
         avg = torch.flatten(att, start_dim=1)                                   # (B1, H*hw), head fastest
 
         if self.use_claim_source:
@@ -342,6 +365,8 @@ class Graph_basedSemantiStructure(nn.Module):
         output = torch.cat([new_left, torch.flatten(attended_avg, start_dim=1)], dim=-1)   # (:251-267)
         phi = self.out(output)
         if kargs.get(K.OutputRankingKey, False):
+            if word_att_weights is None:
+                word_att_weights = plan.to_padded(word_w)          # (B1, R, hw), zeros at the padding nodes
             return phi, (word_att_weights, evd_att_weight)
         return phi
 

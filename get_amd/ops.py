@@ -85,10 +85,11 @@ class PackedAdj:
     ``graph_build``) or dense fp32 values (any adjacency the reference API hands over), plus an
     optional GSL keep-set."""
 
-    __slots__ = ("bits", "dinv", "vals", "keep", "n", "r")
+    __slots__ = ("bits", "dinv", "vals", "keep", "n", "r", "plan")
 
-    def __init__(self, bits, dinv, vals, keep, n, r):
+    def __init__(self, bits, dinv, vals, keep, n, r, plan=None):
         self.bits, self.dinv, self.vals, self.keep, self.n, self.r = bits, dinv, vals, keep, n, r
+        self.plan = plan        # optional RaggedPlan (node-compact row layout) for callers that opt in
 
     @property
     def words(self):
@@ -115,7 +116,10 @@ class PackedAdj:
         return PackedAdj(bits, None, vals, None, n, r)
 
     def with_keep(self, keep: Optional[torch.Tensor]) -> "PackedAdj":
-        return PackedAdj(self.bits, self.dinv, self.vals, keep, self.n, self.r)
+        return PackedAdj(self.bits, self.dinv, self.vals, keep, self.n, self.r, self.plan)
+
+    def with_plan(self, plan: "RaggedPlan") -> "PackedAdj":
+        return PackedAdj(self.bits, self.dinv, self.vals, self.keep, self.n, self.r, plan)
 
     def to_dense(self) -> torch.Tensor:
         out = torch.empty((self.n, self.r, self.r), device=self.device, dtype=torch.float32)
@@ -150,28 +154,76 @@ def as_packed(adj) -> PackedAdj:
     return adj if isinstance(adj, PackedAdj) else PackedAdj.from_dense(adj)
 
 
+class RaggedPlan:
+    """Node-compact row layout of ``n`` graphs padded to ``r`` nodes (include/get_hip.h): the real nodes of
+    all graphs back to back (graph g at rows ``goff[g] .. goff[g+1]``), every padding node after them.
+
+    The reference runs all n*r padded rows through every layer (graph_based_semantic_structure.py:99-107);
+    padding nodes have no edges and are masked out of the word attention (:180), so only the first cell's
+    forward and the scorer (whose padding scores compete in GSL's top-k, wrapper.py:216-219) need them.
+    ``m_real`` (sum of node counts) must be known on the HOST: it sizes the launches."""
+
+    __slots__ = ("n", "r", "m_real", "m_tot", "goff", "rowg", "src", "cids")
+
+    def __init__(self, n_nodes: torch.Tensor, node_ids: torch.Tensor, m_real: int):
+        _lib.require_cuda(n_nodes, node_ids)
+        n, r = node_ids.shape
+        dev = node_ids.device
+        self.n, self.r, self.m_real, self.m_tot = int(n), int(r), int(m_real), int(n * r)
+        assert 0 <= self.m_real <= self.m_tot
+        n_nodes = n_nodes.to(torch.int32).contiguous()
+        node_ids = node_ids.to(torch.int32).contiguous()
+        self.goff = torch.empty((n + 1,), device=dev, dtype=torch.int32)
+        self.rowg = torch.empty((n * r,), device=dev, dtype=torch.int32)
+        self.src = torch.empty((n * r,), device=dev, dtype=torch.int32)
+        self.cids = torch.empty((n * r,), device=dev, dtype=torch.int32)
+        call("gh_ragged_plan", ptr(n_nodes), ptr(node_ids), n, r, ptr(self.goff), ptr(self.rowg), ptr(self.src),
+             ptr(self.cids), stream())
+
+    def to_padded(self, x: torch.Tensor, rows: Optional[int] = None) -> torch.Tensor:
+        """Compact rows (m, ...) -> padded (n, r, ...) with zeros where no compact row was given."""
+        m = x.shape[0] if rows is None else rows
+        out = torch.zeros((self.m_tot,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)
+        out.index_copy_(0, self.src[:m].long(), x[:m])
+        return out.view(self.n, self.r, *x.shape[1:])
+
+    def from_padded(self, x: torch.Tensor, rows: Optional[int] = None) -> torch.Tensor:
+        """Padded (n, r, ...) -> compact rows (m_tot or `rows`, ...)."""
+        m = self.m_tot if rows is None else rows
+        return x.reshape(self.m_tot, *x.shape[2:]).index_select(0, self.src[:m].long())
+
+
 # --------------------------------------------------------------------------- aggregation (a = A x)
 class _Spmm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, adj: PackedAdj):
+    def forward(ctx, x, adj: PackedAdj, plan):
         x = _f32(x)
-        n, r, h = x.shape
+        h = x.shape[-1]
+        if plan is not None:
+            assert x.dim() == 2 and x.shape[0] == plan.m_real, "node-compact spmm takes the (m_real, h) real rows"
+        else:
+            assert x.dim() == 3 and x.shape[0] == adj.n and x.shape[1] == adj.r
         y = torch.empty_like(x)
-        call("gh_spmm", *adj._args(), ptr(x), ptr(y), n, r, h, 0, 0, stream())
-        ctx.adj = adj
+        call("gh_spmm", *adj._args(), *_plan_args(plan), ptr(x), ptr(y), adj.n, adj.r, h, 0, 0, stream())
+        ctx.adj, ctx.plan = adj, plan
         return y
 
     @staticmethod
     def backward(ctx, g):
         g = _f32(g)
-        n, r, h = g.shape
         dx = torch.empty_like(g)
-        call("gh_spmm", *ctx.adj._args(), ptr(g), ptr(dx), n, r, h, 1, 0, stream())
-        return dx, None
+        call("gh_spmm", *ctx.adj._args(), *_plan_args(ctx.plan), ptr(g), ptr(dx), ctx.adj.n, ctx.adj.r, g.shape[-1], 1, 0,
+             stream())
+        return dx, None, None
 
 
-def spmm(adj: PackedAdj, x: torch.Tensor) -> torch.Tensor:
-    return _Spmm.apply(x, adj)
+def _plan_args(plan):
+    """(goff, m_real) of the C-ABI: NULL/0 selects the padded layout."""
+    return (None, 0) if plan is None else (ptr(plan.goff), plan.m_real)
+
+
+def spmm(adj: PackedAdj, x: torch.Tensor, plan: "RaggedPlan" = None) -> torch.Tensor:
+    return _Spmm.apply(x, adj, plan)
 
 
 # --------------------------------------------------------------------------- GGNN cell
@@ -180,14 +232,19 @@ class _GGNNCell(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ids, adj: PackedAdj, w_p, w_z0, b_z0, w_z1, b_z1, w_r0, b_r0, w_r1, b_r1, w_h0, b_h0, w_h1,
-                b_h1, drop_p=0.0, drop_seed=0):
+                b_h1, drop_p=0.0, drop_seed=0, plan=None, rows=0):
         x = _f32(x)
         n, r = adj.n, adj.r
         h, din = w_p.shape
-        m = n * r
+        m = n * r if plan is None else int(rows)      # rows the forward computes (node-compact: m_real or m_tot)
+        mb = n * r if plan is None else plan.m_real    # rows the backward computes
+        if plan is not None:
+            assert plan.n == n and plan.r == r and plan.m_real <= m <= plan.m_tot
         if ids is not None:
-            assert ids.dtype == torch.int32 and ids.numel() == m and x.dim() == 2 and x.shape[1] == din
+            assert ids.dtype == torch.int32 and ids.numel() >= m and x.dim() == 2 and x.shape[1] == din
             ids = ids.contiguous()
+        elif plan is not None:
+            assert x.dim() == 2 and x.shape[1] == din and x.shape[0] >= m, "node-compact cell takes (rows, din) features"
         else:
             assert x.numel() == m * din, f"x has {x.numel()} elements, expected {m}x{din}"
         dev = x.device
@@ -198,30 +255,36 @@ class _GGNNCell(torch.autograd.Function):
         b_h = _f32((b_h0 + b_h1).detach())
         buf = torch.empty((7, m, h), device=dev, dtype=torch.float32)
         xp, a, z, rr, rx, hh, out = buf.unbind(0)
-        call("gh_ggnn_cell_fwd", *adj._args(), ptr(x), ptr(ids), n, r, din, h,
+        call("gh_ggnn_cell_fwd", *adj._args(), *_plan_args(plan), m, ptr(x), ptr(ids), n, r, din, h,
              *[ptr(t) for t in wts], ptr(b_z), ptr(b_r), ptr(b_h),
              ptr(xp), ptr(a), ptr(z), ptr(rr), ptr(rx), ptr(hh), ptr(out), float(drop_p), int(drop_seed), stream())
-        ctx.adj, ctx.ids, ctx.dims = adj, ids, (n, r, din, h)
+        ctx.adj, ctx.ids, ctx.dims, ctx.plan, ctx.rows = adj, ids, (n, r, din, h), plan, (m, mb)
         ctx.drop = (float(drop_p), int(drop_seed))
         ctx.params = (w_p, w_z0, b_z0, w_z1, b_z1, w_r0, b_r0, w_r1, b_r1, w_h0, b_h0, w_h1, b_h1)
         ctx.save_for_backward(x, buf, *ws)
         ctx.x_needs_grad = ctx.needs_input_grad[0]
-        return out.view(n, r, h)
+        return out.view(n, r, h) if plan is None else out
 
     @staticmethod
     def backward(ctx, g):
         x, buf, w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1 = ctx.saved_tensors
         xp, a, z, rr, rx, hh, _ = buf.unbind(0)
         n, r, din, h = ctx.dims
-        m = n * r
+        m_fwd, m = ctx.rows                   # the backward runs on the real-node rows only (m == m_fwd when padded)
+        plan = ctx.plan
         dev = g.device
-        g = _f32(g).reshape(m, h)
+        g = _f32(g).reshape(m_fwd, h)
         _lib.ensure_workspace(dev)
-        scratch = torch.empty((5, m, h), device=dev, dtype=torch.float32)
+        scratch = torch.empty((5, max(m, 1), h), device=dev, dtype=torch.float32)
         dhp, dzp, drp, dxp, da = scratch.unbind(0)
         ids = ctx.ids
         want_dx = ctx.x_needs_grad
-        dx = torch.empty((m, din), device=dev, dtype=torch.float32) if want_dx else None
+        dx = None
+        if want_dx:
+            x_rows = m if ids is not None else x.shape[0] if plan is not None else m
+            dx = torch.empty((x_rows, din), device=dev, dtype=torch.float32)
+            if x_rows > m:
+                dx[m:].zero_()               # padding rows (and unused tail rows of x) get no gradient
         P = ctx.params
         direct = all(_direct(p) for p in P)
         if direct:     # weight/bias gradients land in the parameters' own .grad (flat bucket) -- no adds, no fills
@@ -234,7 +297,7 @@ class _GGNNCell(torch.autograd.Function):
             dbs = torch.zeros((3, h), device=dev, dtype=torch.float32)
             gw = [dw_p] + [dws[i] for i in range(6)]
             gb = [dbs[0], dbs[1], dbs[2], None, None, None]
-        call("gh_ggnn_cell_bwd", *ctx.adj._args(), ptr(x), ptr(ids), n, r, din, h,
+        call("gh_ggnn_cell_bwd", *ctx.adj._args(), *_plan_args(plan), ptr(x), ptr(ids), n, r, din, h,
              ptr(w_p), ptr(w_z0), ptr(w_z1), ptr(w_r0), ptr(w_r1), ptr(w_h0), ptr(w_h1),
              ptr(xp), ptr(a), ptr(z), ptr(rr), ptr(rx), ptr(hh), ptr(g),
              ptr(dhp), ptr(dzp), ptr(drp), ptr(dxp), ptr(da),
@@ -242,21 +305,26 @@ class _GGNNCell(torch.autograd.Function):
         if want_dx:
             if ids is not None:      # trainable embedding table: scatter the row gradients
                 demb = torch.zeros_like(x)
-                demb.index_add_(0, ids.long(), dx)
+                demb.index_add_(0, ids[:m].long(), dx)
                 dx = demb
             else:
                 dx = dx.view(x.shape)
         if direct:
-            return (dx, None, None) + (None,) * 15
+            return (dx, None, None) + (None,) * 17
         dz0, dz1, dr0, dr1, dh0, dh1 = dws.unbind(0)
         bz, br, bh = dbs.unbind(0)
-        return (dx, None, None, dw_p, dz0, bz, dz1, bz, dr0, br, dr1, br, dh0, bh, dh1, bh, None, None)
+        return (dx, None, None, dw_p, dz0, bz, dz1, bz, dr0, br, dr1, br, dh0, bh, dh1, bh, None, None, None, None)
 
 
-def ggnn_cell(adj: PackedAdj, x, ids, params, drop_p: float = 0.0, drop_seed: int = 0):
+def ggnn_cell(adj: PackedAdj, x, ids, params, drop_p: float = 0.0, drop_seed: int = 0, plan: "RaggedPlan" = None,
+              rows: int = 0):
     """params: (w_p, w_z0, b_z0, w_z1, b_z1, w_r0, b_r0, w_r1, b_r1, w_h0, b_h0, w_h1, b_h1).
-    drop_p > 0 applies the cell's input dropout inside the first GEMM (stateless hash mask keyed by drop_seed)."""
-    return _GGNNCell.apply(x, ids, adj, *params, drop_p, drop_seed)
+    drop_p > 0 applies the cell's input dropout inside the first GEMM (stateless hash mask keyed by drop_seed).
+    plan: node-compact layout -- x is (>= rows, din) (or table + ids), the forward computes the first `rows`
+    rows (plan.m_real or plan.m_tot), the backward the plan.m_real real-node rows; returns (rows, h)."""
+    if plan is not None and not rows:
+        rows = plan.m_real
+    return _GGNNCell.apply(x, ids, adj, *params, drop_p, drop_seed, plan, rows)
 
 
 def fused_dropout_ok(din: int, h: int) -> bool:
@@ -287,16 +355,21 @@ def dropout_mask_reference(seed: int, rows: int, cols: int, p: float):
 # --------------------------------------------------------------------------- word scorer + GSL (no gradient)
 @torch.no_grad()
 def scorer_gsl(adj: PackedAdj, feat: torch.Tensor, w_p, gate12: torch.Tensor, k: int, drop_p: float = 0.0,
-               drop_seed: int = 0):
+               drop_seed: int = 0, plan: "RaggedPlan" = None):
     """GGNN(h->1) score of every node and the top-k keep set (wrapper.py:167-168, :215-219).
-    Returns (score (N,R) fp32, keep (N,W) int64 bit words)."""
+    feat: (N,R,H), or node-compact (N*R, H) incl. the padding rows when `plan` is given.
+    Returns (score (N,R) fp32, keep (N,W) int64 bit words) -- both in padded node indexing."""
     feat = _f32(feat.detach())
-    n, r, h = feat.shape
+    if plan is not None:
+        assert feat.dim() == 2 and feat.shape[0] == plan.m_tot, "the scorer needs every row (padding nodes compete in top-k)"
+        n, r, h = plan.n, plan.r, feat.shape[1]
+    else:
+        n, r, h = feat.shape
     score = torch.empty((n, r), device=feat.device, dtype=torch.float32)
     keep = torch.empty((n, adj.words), device=feat.device, dtype=torch.int64)
     w_p = _f32(w_p.detach().reshape(-1))
     gate12 = _f32(gate12.detach())
-    call("gh_scorer_gsl", ptr(adj.bits), ptr(adj.dinv), ptr(adj.vals), ptr(feat), ptr(w_p), ptr(gate12), n, r, h,
+    call("gh_scorer_gsl", ptr(adj.bits), ptr(adj.dinv), ptr(adj.vals), _plan_args(plan)[0], ptr(feat), ptr(w_p), ptr(gate12), n, r, h,
          int(k), ptr(score), ptr(keep), float(drop_p), int(drop_seed), stream())
     return score, keep
 
@@ -315,9 +388,15 @@ class _ConcatAtt(torch.autograd.Function):
     """two_branches_attention.py:121-148 (left given) / self_attention.py:75-100 (left None)."""
 
     @staticmethod
-    def forward(ctx, left, right, mask, w1, w2):
+    def forward(ctx, left, right, mask, w1, w2, plan=None):
         right = _f32(right)
-        b, l, dr = right.shape
+        if plan is not None:     # node-compact: right (m_real, dr), mask (m_real,), weights come back (m_real, heads)
+            assert right.dim() == 2 and right.shape[0] == plan.m_real and mask.numel() == plan.m_real
+            b, l, dr = plan.n, plan.r, right.shape[1]
+            m = plan.m_real
+        else:
+            b, l, dr = right.shape
+            m = b * l
         ha, inp = w1.shape
         heads = w2.shape[0]
         xl = 0
@@ -330,13 +409,15 @@ class _ConcatAtt(torch.autograd.Function):
         w1c, w2c = _f32(w1.detach()), _f32(w2.detach())
         w1t = transposed(w1)
         u = torch.empty((b, ha), device=dev, dtype=torch.float32)
-        t = torch.empty((b * l, ha), device=dev, dtype=torch.float32)
-        e = torch.empty((b * l, heads), device=dev, dtype=torch.float32)
-        weights = torch.empty((b, l, heads), device=dev, dtype=torch.float32)
+        t = torch.empty((m, ha), device=dev, dtype=torch.float32)
+        e = torch.empty((m, heads), device=dev, dtype=torch.float32)
+        weights = torch.empty((m, heads) if plan is not None else (b, l, heads), device=dev, dtype=torch.float32)
         attended = torch.empty((b, dr, heads), device=dev, dtype=torch.float32)
-        call("gh_concat_att_fwd", ptr(left), ptr(right), ptr(maskf), b, l, xl, dr, ha, heads, ptr(w1t), ptr(w2c),
+        pl = (None, None, 0) if plan is None else (ptr(plan.goff), ptr(plan.rowg), plan.m_real)
+        call("gh_concat_att_fwd", ptr(left), ptr(right), ptr(maskf), *pl, b, l, xl, dr, ha, heads, ptr(w1t), ptr(w2c),
              ptr(u), ptr(t), ptr(e), ptr(weights), ptr(attended), stream())
-        ctx.dims = (b, l, xl, dr, ha, heads)
+        ctx.dims = (b, l, xl, dr, ha, heads, m)
+        ctx.plan = plan
         ctx.params = (w1, w2)
         ctx.has_left = left is not None
         ctx.save_for_backward(left if left is not None else right.new_empty(0), right, w1c, w2c, t, weights)
@@ -345,34 +426,36 @@ class _ConcatAtt(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_att, g_w):
         left, right, w1, w2, t, weights = ctx.saved_tensors
-        b, l, xl, dr, ha, heads = ctx.dims
+        b, l, xl, dr, ha, heads, m = ctx.dims
+        plan = ctx.plan
         dev = right.device
         if not ctx.has_left:
             left = None
         _lib.ensure_workspace(dev)
         g_att = _f32(g_att) if g_att is not None else torch.zeros((b, dr, heads), device=dev)
         g_w = _f32(g_w) if g_w is not None else None
-        de = torch.empty((b * l, heads), device=dev, dtype=torch.float32)
-        dpre = torch.empty((b * l, ha), device=dev, dtype=torch.float32)
+        de = torch.empty((m, heads), device=dev, dtype=torch.float32)
+        dpre = torch.empty((m, ha), device=dev, dtype=torch.float32)
         du = torch.empty((b, ha), device=dev, dtype=torch.float32)
         dleft = torch.empty((b, xl), device=dev, dtype=torch.float32) if left is not None else None
-        dright = torch.empty((b, l, dr), device=dev, dtype=torch.float32)
+        dright = torch.empty_like(right)
         direct = all(_direct(p) for p in ctx.params)
         if direct:
             dw1, dw2 = ctx.params[0].grad, ctx.params[1].grad
         else:
             dw1 = torch.zeros((ha, xl + dr), device=dev, dtype=torch.float32)
             dw2 = torch.zeros((heads, ha), device=dev, dtype=torch.float32)
-        call("gh_concat_att_bwd", ptr(left), ptr(right), b, l, xl, dr, ha, heads, ptr(w1), ptr(w2), ptr(t),
+        call("gh_concat_att_bwd", ptr(left), ptr(right), *_plan_args(plan), b, l, xl, dr, ha, heads, ptr(w1), ptr(w2), ptr(t),
              ptr(weights), ptr(g_att), ptr(g_w), ptr(de), ptr(dpre), ptr(du), ptr(dleft), ptr(dright), ptr(dw1),
              ptr(dw2), stream())
         if direct:
-            return dleft, dright, None, None, None
-        return dleft, dright, None, dw1, dw2
+            return dleft, dright, None, None, None, None
+        return dleft, dright, None, dw1, dw2, None
 
 
-def concat_att(left, right, mask, w1, w2):
-    return _ConcatAtt.apply(left, right, mask, w1, w2)
+def concat_att(left, right, mask, w1, w2, plan: "RaggedPlan" = None):
+    """plan: node-compact `right` (m_real, dr) / `mask` (m_real,); weights are returned compact (m_real, heads)."""
+    return _ConcatAtt.apply(left, right, mask, w1, w2, plan)
 
 
 # --------------------------------------------------------------------------- linear

@@ -27,6 +27,19 @@
  *                       the reference API hands over)
  *   keep[W]     uint64  optional GSL keep-set; refined edge (i,j) exists iff
  *                       bit(i,j) && (keep(i) || keep(j))    (wrapper.py:221-225)
+ *
+ * Node-compact row layout (optional; `goff` != NULL selects it, NULL keeps the reference's padded layout).
+ * The reference pads every evidence graph to R nodes and runs all of them through the GGNN cells
+ * (graph_based_semantic_structure.py:99-107); a padding node has no edges and is masked out of the attention
+ * (:180), so it never influences a real node's output or any gradient -- its only observable effect is that its
+ * score competes in GSL's top-k (wrapper.py:216-219).  In the compact layout the n graphs' REAL nodes are stored
+ * back to back and all padding nodes after them:
+ *   goff[n+1]   int32   goff[g] = first feature row of graph g's real nodes; m_real = goff[n]
+ *   node j <  n_g of graph g  ->  feature row goff[g] + j
+ *   node j >= n_g of graph g  ->  feature row m_real + (g*R - goff[g]) + (j - n_g)         (m_tot = n*R rows in all)
+ * Kernels that only matter for real nodes (second cell, attention, every backward) then run on the first m_real
+ * rows; the first cell's forward and the scorer still see all m_tot rows.  bits/dinv/vals/keep, scores and ids keep
+ * their padded [g][R] indexing.  `m_real` is passed by value, so the host must know it (sum of the node counts).
  */
 #ifndef GET_HIP_H
 #define GET_HIP_H
@@ -39,7 +52,7 @@ extern "C" {
 
 typedef void* gh_stream_t;
 
-#define GH_ABI_VERSION 1
+#define GH_ABI_VERSION 2
 
 int gh_abi_version(void);
 /* Thread-local message of the last failing call on this thread (never NULL). */
@@ -57,10 +70,18 @@ int gh_graph_build(const int32_t* tokens, const int32_t* lengths, int n_texts, i
 int gh_adj_pack_f64(const double* adj, int n, int r, uint64_t* bits, float* vals, gh_stream_t stream);
 int gh_adj_pack_f32(const float* adj, int n, int r, uint64_t* bits, float* vals, gh_stream_t stream);
 
+/* Node-compact layout plan from the node counts of gh_graph_build (device arrays):
+ *   goff[n+1] (see above); rowg[n*r] graph of every compact row; src[n*r] padded row index g*r+j of every compact
+ *   row (scatter/gather between the two layouts); cids[n*r] = node_ids[src[.]] (NULL ok: not written). */
+int gh_ragged_plan(const int32_t* n_nodes, const int32_t* node_ids, int n, int r, int32_t* goff, int32_t* rowg,
+                   int32_t* src, int32_t* cids, gh_stream_t stream);
+
 /* ---- aggregation  a = A_hat x : Models/BiDAF/wrapper.py:192 `adj.matmul(x)` ----
- * x,y [n][r][h].  transpose: use A^T (backward of the weighted mode); accumulate: y += . */
+ * x,y [n][r][h] (goff == NULL) or node-compact [m_real][h].  transpose: use A^T (backward of the weighted mode);
+ * accumulate: y += . */
 int gh_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
-            const float* x, float* y, int n, int r, int h, int transpose, int accumulate, gh_stream_t stream);
+            const int32_t* goff, int m_real, const float* x, float* y, int n, int r, int h, int transpose,
+            int accumulate, gh_stream_t stream);
 
 /* ---- weight packing: W[n_out][n_in] -> Wt[n_in][n_out] (k-major operand of the MFMA GEMMs) ---- */
 int gh_transpose(const float* w, float* wt, int rows, int cols, gh_stream_t stream);
@@ -77,8 +98,11 @@ int gh_transpose_batch(int n, const void* const* src_host, void* const* dst_host
  * Saved for backward (all [m][h]): xp, a, z, r, rx, hh.  out [m][h].
  * drop_p > 0: the cell's input dropout (wrapper.py:185-190) is applied inside the first GEMM's loader with a
  * stateless mask -- element (m,k) kept iff hash(drop_seed, m*din+k) >= drop_p*2^32, scaled by 1/(1-drop_p);
- * pass the same (drop_p, drop_seed) to the backward.  Needs din % 4 == 0 and h % 4 == 0. */
+ * pass the same (drop_p, drop_seed) to the backward.  Needs din % 4 == 0 and h % 4 == 0.
+ * goff != NULL: node-compact layout; the cell runs on the first m_rows rows (m_real <= m_rows <= n*r; rows beyond
+ * m_real are padding nodes: no neighbours).  goff == NULL: m_real/m_rows are ignored, m = n*r. */
 int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                     const int32_t* goff, int m_real, int m_rows,
                      const float* x, const int32_t* ids, int n, int r, int din, int h,
                      const float* wt_p, const float* wt_z0, const float* wt_z1, const float* wt_r0,
                      const float* wt_r1, const float* wt_h0, const float* wt_h1,
@@ -91,8 +115,11 @@ int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const float* vals,
  * Outputs: dx [m][din] (may be NULL: frozen embedding), and ACCUMULATED (+=) into
  * dw_p[h][din], dw_z0..dw_h1 [h][h], db_z[h], db_r[h], db_h[h]  (caller zeroes them, or hands the
  * parameters' own .grad buffers).  b?0 and b?1 share one gradient: db_z1/db_r1/db_h1 (NULL ok) receive
- * the same column sums, so both biases' .grad can be fed without a copy. */
+ * the same column sums, so both biases' .grad can be fed without a copy.
+ * goff != NULL: node-compact layout, the backward runs on the m_real real-node rows only (padding rows get and give
+ * no gradient; dx rows beyond m_real are not written). */
 int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                     const int32_t* goff, int m_real,
                      const float* x, const int32_t* ids, int n, int r, int din, int h,
                      const float* w_p, const float* w_z0, const float* w_z1, const float* w_r0,
                      const float* w_r1, const float* w_h0, const float* w_h1,
@@ -107,8 +134,9 @@ int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const float* vals,
  * feat [n][r][h]; w_p[h] = scorer proj.linear.weight; gate[12] = {wz0,bz0,wz1,bz1,wr0,br0,wr1,br1,
  * wh0,bh0,wh1,bh1} (the six 1x1 linears).  k = int(rate * r) computed by the caller.
  * Out: score[n][r], keep[n][W] (bit i set <=> node i among the k best; ties -> lower index).
- * drop_p/drop_seed: the scorer cell's own input dropout in training mode (same stateless mask as above). */
-int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const float* feat,
+ * drop_p/drop_seed: the scorer cell's own input dropout in training mode (same stateless mask as above).
+ * goff != NULL: feat is node-compact [n*r][h] INCLUDING the padding rows (they compete in the top-k). */
+int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const int32_t* goff, const float* feat,
                   const float* w_p, const float* gate, int n, int r, int h, int k,
                   float* score, uint64_t* keep, float drop_p, uint32_t drop_seed, gh_stream_t stream);
 /* GSL alone on given scores (GSL.forward on arbitrary score input). */
@@ -122,14 +150,18 @@ int gh_adj_unpack(const uint64_t* bits, const float* dinv, const float* vals, co
  * left [b][xl] (or NULL, xl = 0), right [b][l][dr], mask [b][l] float (0 = padded).
  * w1t = transpose of linear1.weight: [xl+dr][ha]; w2 = linear2.weight [heads][ha] (heads <= 8).
  * Saved: u [b][ha] (left branch, hoisted out of the per-token product), t [b*l][ha] (tanh), e [b*l][heads].
- * Out: weights [b][l][heads], attended [b][dr][heads]. */
-int gh_concat_att_fwd(const float* left, const float* right, const float* mask, int b, int l, int xl, int dr,
+ * Out: weights [b][l][heads], attended [b][dr][heads].
+ * goff/rowg != NULL (both): right, mask, t, e, weights are node-compact with m_real rows, pair g owning rows
+ * [goff[g], goff[g+1]) (at most l of them) and rowg[row] = g; softmax runs over the pair's real rows only. */
+int gh_concat_att_fwd(const float* left, const float* right, const float* mask, const int32_t* goff,
+                      const int32_t* rowg, int m_real, int b, int l, int xl, int dr,
                       int ha, int heads, const float* w1t, const float* w2,
                       float* u, float* t, float* e, float* weights, float* attended, gh_stream_t stream);
 /* Backward.  w1 = linear1.weight [ha][xl+dr] untransposed.  g_att [b][dr][heads], g_w [b][l][heads] or NULL.
  * Scratch: de [b*l][heads], dpre [b*l][ha], du [b][ha].
  * Out: dleft [b][xl] (NULL ok), dright [b][l][dr]; ACCUMULATED: dw1 [ha][xl+dr], dw2 [heads][ha]. */
-int gh_concat_att_bwd(const float* left, const float* right, int b, int l, int xl, int dr, int ha, int heads,
+int gh_concat_att_bwd(const float* left, const float* right, const int32_t* goff, int m_real, int b, int l, int xl,
+                      int dr, int ha, int heads,
                       const float* w1, const float* w2, const float* t, const float* weights,
                       const float* g_att, const float* g_w,
                       float* de, float* dpre, float* du,

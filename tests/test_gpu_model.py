@@ -53,6 +53,8 @@ def run_case(name, native_graphs=False, int32_inputs=False):
                                          torch.from_numpy(raw["evd_len"]).to(DEV), cfg.window)
         assert np.array_equal(q_ids.cpu().numpy(), inp["query"]) and np.array_equal(d_ids.cpu().numpy(), inp["doc_ids"])
         assert np.array_equal(q_n.cpu().numpy(), inp["query_lens"])
+        if native_graphs == "compact":     # node-compact fast path (ops.RaggedPlan): padding nodes skipped where inert
+            da = da.with_plan(ops.RaggedPlan(d_n, d_ids, int(inp["doc_lens"].sum()) if "doc_lens" in inp else int(d_n.sum().item())))
         kargs["query_adj"], kargs["docs_adj"] = qa, da
     if int32_inputs:       # the evaluation path hands int32 ids/lens (char_man_fitter_query_repr1.py:298-316)
         query, document = query.int(), document.int()
@@ -64,7 +66,7 @@ def run_case(name, native_graphs=False, int32_inputs=False):
 
 
 @pytest.mark.parametrize("name", list(MODEL_CASES))
-@pytest.mark.parametrize("native", [False, True])
+@pytest.mark.parametrize("native", [False, True, "compact"])
 def test_model_vs_golden(name, native):
     z, meta = load(f"g7_model_{name}.npz")
     cfg, model, inp, phi, ww, ew, loss = run_case(name, native_graphs=native)
@@ -149,7 +151,8 @@ def test_bench_shape_forward_backward_properties():
     assert float((phi[:4].detach().cpu() - phi_o).abs().max()) <= 1e-4
 
 
-def test_politifact_shaped_long_evidence_vs_oracle():
+@pytest.mark.parametrize("compact", [False, True])
+def test_politifact_shaped_long_evidence_vs_oracle(compact):
     """BASELINE configs[2] shape (L_right=200, 10 evidences/claim) at reduced width: full model, native
     graphs, HIP vs the CPU oracle (logits 1e-4, attention weights 1e-5, live gradients 1e-3)."""
     from get_amd import ops
@@ -161,8 +164,10 @@ def test_politifact_shaped_long_evidence_vs_oracle():
     raw = make_raw_batch(cfg, seed)
     inp = assemble_inputs(raw, cfg, O.convert_text)
     kargs = to_dev(reference_kargs(inp, torch, output_ranking=True))
-    da, d_ids, _ = ops.graph_build(torch.from_numpy(raw["evd_tokens"]).to(DEV), torch.from_numpy(raw["evd_len"]).to(DEV), cfg.window)
+    da, d_ids, d_n = ops.graph_build(torch.from_numpy(raw["evd_tokens"]).to(DEV), torch.from_numpy(raw["evd_len"]).to(DEV), cfg.window)
     assert da.words == 4 and np.array_equal(d_ids.cpu().numpy(), inp["doc_ids"])
+    if compact:
+        da = da.with_plan(ops.RaggedPlan(d_n, d_ids, int(d_n.sum().item())))
     kargs["docs_adj"] = da
     phi, (ww, ew) = model(torch.from_numpy(inp["query"]).to(DEV), torch.from_numpy(inp["document"]).to(DEV), **kargs)
     torch.nn.functional.cross_entropy(phi, torch.from_numpy(inp["labels"]).to(DEV)).backward()

@@ -391,3 +391,142 @@ def test_fused_dropout_matches_masked_oracle():
     assert maxerr(a1.detach().cpu(), a2.detach().cpu()) > 1e-3
     mod.train(False)
     assert maxerr(mod(padj, T(x)).detach().cpu(), mod(padj, T(x)).detach().cpu()) == 0.0
+
+
+# ---------------------------------------------------------------- node-compact row layout (ops.RaggedPlan)
+def _compact_fixture(rng, n=7, r=100, vocab=60, empty=True):
+    from get_amd import ops
+    toks, lens, ids, adj = cases.graphs(rng, n, r, 3, O.convert_text, vocab=vocab)
+    if empty:
+        lens[1] = 0                               # an empty text: no real node at all
+    toks[2] = np.arange(1000, 1000 + r); lens[2] = r  # all tokens distinct: no padding node at all
+    for i in (1, 2):
+        w, a, _ = O.convert_text([int(t) for t in toks[i]], r, int(lens[i]), 3)
+        ids[i], adj[i] = np.asarray(w), np.asarray(a)
+    padj, node_ids, n_nodes = ops.graph_build(T(toks), T(lens), 3)
+    nn = n_nodes.cpu().numpy()
+    plan = ops.RaggedPlan(n_nodes, node_ids, int(nn.sum()))
+    return toks, lens, ids, adj, padj, node_ids, nn, plan
+
+
+def test_compact_plan_maps():
+    rng = np.random.default_rng(51)
+    toks, lens, ids, adj, padj, node_ids, nn, plan = _compact_fixture(rng)
+    n, r = ids.shape
+    assert nn[1] == 0 and nn[2] == r
+    goff = plan.goff.cpu().numpy()
+    assert np.array_equal(goff, np.concatenate([[0], np.cumsum(nn)]))
+    src = plan.src.cpu().numpy()
+    assert np.array_equal(np.sort(src), np.arange(n * r))                 # a permutation of the padded rows
+    assert np.array_equal(plan.rowg.cpu().numpy(), src // r)
+    assert np.array_equal(plan.cids.cpu().numpy(), ids.reshape(-1)[src])
+    g, j = src // r, src % r
+    assert np.all(j[:plan.m_real] < nn[g[:plan.m_real]]) and np.all(j[plan.m_real:] >= nn[g[plan.m_real:]])
+    assert np.all(np.diff(src[:plan.m_real]) > 0) and np.all(np.diff(src[plan.m_real:]) > 0)
+    x = T(rng.standard_normal((n, r, 8)).astype(np.float32))
+    assert torch.equal(plan.to_padded(plan.from_padded(x)), x)
+
+
+@pytest.mark.parametrize("h", [300, 30])
+def test_compact_spmm_equals_padded(h):
+    from get_amd import ops
+    rng = np.random.default_rng(52)
+    toks, lens, ids, adj, padj, node_ids, nn, plan = _compact_fixture(rng)
+    n, r = ids.shape
+    x = T(rng.standard_normal((n, r, h)).astype(np.float32))
+    keep = ops.gsl_topk(T(rng.standard_normal((n, r)).astype(np.float32)), 60)
+    for a in (padj, padj.with_keep(keep)):
+        yp = ops.spmm(a, x)
+        yc = ops.spmm(a, plan.from_padded(x, plan.m_real), plan)
+        assert torch.equal(yc, plan.from_padded(yp, plan.m_real))           # same neighbours, same order: bit-exact
+
+
+def test_compact_cell_with_dropout_vs_oracle():
+    """Cell on the node-compact layout, training-mode dropout on: forward over ALL rows (padding rows included),
+    backward over the real rows; the stateless mask is indexed by the compact row."""
+    from get_amd import modules, ops
+    rng = np.random.default_rng(53)
+    toks, lens, ids, adj, padj, node_ids, nn, plan = _compact_fixture(rng)
+    n, r = ids.shape
+    d, h, p_drop, seed = 48, 64, 0.25, 99173
+    x = rng.standard_normal((n, r, d)).astype(np.float32)
+    prm = cases.cell_params(rng, d, h)
+    gw = rng.standard_normal((n, r, h)).astype(np.float32)
+    src = plan.src.cpu().numpy()
+    real = np.zeros(n * r, bool); real[src[:plan.m_real]] = True
+    gw.reshape(n * r, h)[~real] = 0.0                               # no consumer reads the padding rows' output
+    mod = modules.GGNN(d, h, dropout=p_drop)
+    _load_cell(mod, prm)
+    mod = mod.to(DEV)
+    keep_c = ops.dropout_mask_reference(seed, n * r, d, p_drop)      # indexed by compact row
+    keep = np.zeros_like(keep_c); keep[src] = keep_c
+    keep = keep.reshape(n, r, d)
+    xc = plan.from_padded(T(x)).requires_grad_(True)                # (m_tot, d)
+    out = ops.ggnn_cell(padj, xc, None, mod._params(), p_drop, seed, plan=plan, rows=plan.m_tot)
+    assert out.shape == (n * r, h)
+    (out * plan.from_padded(T(gw))).sum().backward()
+    po = {k: torch.from_numpy(v).requires_grad_(True) for k, v in prm.items()}
+    xo = torch.from_numpy(x).requires_grad_(True)
+    oo = O.ggnn_cell(torch.from_numpy(adj).float(), xo * torch.from_numpy(keep).float() / (1 - p_drop), po)
+    (oo * torch.from_numpy(gw)).sum().backward()
+    assert maxerr(plan.to_padded(out.detach()).cpu(), oo.detach()) <= 2e-5
+    dx = plan.to_padded(xc.grad).cpu()
+    assert maxerr(dx, xo.grad) <= 1e-3 * float(xo.grad.abs().max()) + 1e-6
+    assert float(xc.grad[plan.m_real:].abs().max()) == 0.0
+    for name, q in mod.named_parameters():
+        go = po[name].grad
+        assert maxerr(q.grad.cpu(), go) <= 1e-3 * float(go.abs().max()) + 1e-5, name
+    # real rows only (the second cell of GGNN_with_GSL): same numbers on the prefix
+    out_r = ops.ggnn_cell(padj, xc.detach(), None, mod._params(), p_drop, seed, plan=plan, rows=plan.m_real)
+    assert torch.equal(out_r, out.detach()[:plan.m_real])
+
+
+def test_compact_scorer_gsl_and_attention_equal_padded():
+    from get_amd import modules, ops
+    rng = np.random.default_rng(54)
+    toks, lens, ids, adj, padj, node_ids, nn, plan = _compact_fixture(rng)
+    n, r = ids.shape
+    h, heads = 64, 5
+    feat = T(rng.standard_normal((n, r, h)).astype(np.float32))
+    w_p = T(rng.standard_normal((1, h)).astype(np.float32) * 0.2)
+    gate = T(rng.standard_normal((12,)).astype(np.float32))
+    for drop in ((0.0, 0), ):
+        s_p, k_p = ops.scorer_gsl(padj, feat, w_p, gate, 60, *drop)
+        s_c, k_c = ops.scorer_gsl(padj, plan.from_padded(feat), w_p, gate, 60, *drop, plan=plan)
+        assert torch.equal(s_p, s_c) and torch.equal(k_p, k_c)
+    # training mode: the mask follows the compact row index, so compare against the padded kernel fed the
+    # already-masked features
+    p_drop, seed = 0.3, 4711
+    keep_c = torch.from_numpy(ops.dropout_mask_reference(seed, n * r, h, p_drop)).to(DEV)
+    fc = plan.from_padded(feat)
+    s_c, k_c = ops.scorer_gsl(padj, fc, w_p, gate, 60, p_drop, seed, plan=plan)
+    s_p, k_p = ops.scorer_gsl(padj, plan.to_padded(fc * keep_c / (1 - p_drop)), w_p, gate, 60)
+    assert maxerr(s_p.cpu(), s_c.cpu()) <= 1e-5
+    # attention: softmax over the real rows only == masked softmax over the padded rows.  An empty graph gives NaN
+    # in both layouts (softmax over nothing, two_branches_attention.py:144-146) ...
+    att = modules.ConcatNotEqualSelfAtt(2 * h, h, heads).to(DEV)
+    left = T(rng.standard_normal((n, h)).astype(np.float32))
+    a_p, _ = att(left, feat, node_ids >= 1)
+    a_c, _ = att(left, plan.from_padded(feat, plan.m_real), plan.cids[:plan.m_real] >= 1, plan=plan)
+    assert torch.isnan(a_p[1]).all() and torch.isnan(a_c[1]).all()
+    # ... so the gradient comparison uses a batch without one (NaN would spread into the weight gradients)
+    toks, lens, ids, adj, padj, node_ids, nn, plan = _compact_fixture(rng, empty=False)
+    mask = (node_ids >= 1)
+    ga = T(rng.standard_normal((n, h, heads)).astype(np.float32))
+    res = {}
+    for mode in ("padded", "compact"):
+        att.zero_grad()
+        l_ = left.clone().requires_grad_(True)
+        if mode == "padded":
+            r_ = feat.clone().requires_grad_(True)
+            a_, w_ = att(l_, r_, mask)
+        else:
+            r_ = plan.from_padded(feat, plan.m_real).requires_grad_(True)
+            a_, w_ = att(l_, r_, plan.cids[:plan.m_real] >= 1, plan=plan)
+        (a_ * ga).sum().backward()
+        dr = r_.grad if mode == "padded" else plan.to_padded(r_.grad)
+        wp = w_ if mode == "padded" else plan.to_padded(w_)
+        res[mode] = (a_.detach(), wp.detach(), l_.grad, dr, att.linear1.weight.grad.clone(), att.linear2.weight.grad.clone())
+    for i, (a, b) in enumerate(zip(res["padded"], res["compact"])):
+        scale = float(a.abs().max())
+        assert maxerr(a.cpu(), b.cpu()) <= 2e-6 * max(scale, 1.0) + 1e-6 * scale, i
