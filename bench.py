@@ -31,20 +31,31 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfm
 PEAK_HBM_GBPS = 8000.0           # HBM3E spec (6.3 TB/s achievable)
 
 
-def flops_per_pair(cfg: SynthConfig, nnz_per_graph: float) -> dict:
-    """Minimal-formulation FLOPs per claim-evidence pair (SURVEY.md 8(d) formulas as functions)."""
+def flops_per_pair(cfg: SynthConfig, nnz_per_graph: float, real_nodes: float = None) -> dict:
+    """Minimal-formulation FLOPs per claim-evidence pair (SURVEY.md 8(d) formulas as functions).
+    `fwd_bwd`: every layer on all R padded node rows (the reference's shape of the work).
+    `executed`: what the node-compact layout actually runs -- the first cell's forward and the scorer on R rows,
+    everything else on the `real_nodes` (mean unique tokens per evidence) rows that can influence a result."""
     R, D, H, hw = cfg.len_right, cfg.emb_dim, cfg.hidden, cfg.word_heads
 
-    def cell(din, dout, agg):
-        return 2 * R * din * dout + 12 * R * dout * dout + agg * dout
+    def cell(rows, din, dout, agg):
+        return 2 * rows * din * dout + 12 * rows * dout * dout + agg * dout
+
+    def att(rows):
+        return 2 * H * H + 2 * rows * H * H + 2 * rows * H * hw + 2 * rows * H * hw
 
     agg = 2 * nnz_per_graph
-    att = 2 * H * H + 2 * R * H * H + 2 * R * H * hw + 2 * R * H * hw
-    fwd = cell(D, H, agg) + cell(H, 1, agg) + cell(H, H, agg) + att
-    return {"fwd": fwd, "fwd_bwd": 3 * fwd - 2 * R * D * H}
+    fwd = cell(R, D, H, agg) + cell(R, H, 1, agg) + cell(R, H, H, agg) + att(R)
+    out = {"fwd": fwd, "fwd_bwd": 3 * fwd - 2 * R * D * H}
+    if real_nodes is not None:
+        n = real_nodes
+        fwd_x = cell(R, D, H, agg) + cell(R, H, 1, agg) + cell(n, H, H, agg) + att(n)
+        bwd_x = 2 * (cell(n, D, H, agg) + cell(n, H, H, agg) + att(n)) - 2 * n * D * H
+        out["executed"] = fwd_x + bwd_x
+    return out
 
 
-def build_workload(batch=32, n_evd=30, seed=20240229, device="cuda:0", cfg: SynthConfig = None, lr=1e-4):
+def build_workload(batch=32, n_evd=30, seed=20240229, device="cuda:0", cfg: SynthConfig = None, lr=1e-4, compact=None):
     """Model (random init, reference init scheme), a seeded synthetic batch resident on `device`, and
     the native-path kargs.  Also returns `oracle_slice(k)`: CPU-oracle logits of the first k claims."""
     from get_amd import modules, ops
@@ -56,7 +67,7 @@ def build_workload(batch=32, n_evd=30, seed=20240229, device="cuda:0", cfg: Synt
     from get_amd.batch import NativeBatch
     batch_obj = NativeBatch(raw["claim_tokens"], raw["claim_len"], raw["evd_tokens"], raw["evd_len"], raw["evd_counts"],
                             raw["doc_sources"], raw["query_sources"], raw["labels"], window=cfg.window,
-                            n_max=cfg.fixed_num_evidences, device=device)
+                            n_max=cfg.fixed_num_evidences, device=device, compact=compact)
     b1 = batch_obj.b1
     labels = batch_obj.labels
     # per-step device work that replaces the reference's host graph construction + H2D of dense float64
@@ -83,7 +94,8 @@ def build_workload(batch=32, n_evd=30, seed=20240229, device="cuda:0", cfg: Synt
         return dict(phi=phi.detach(), word_w=ww.detach(), inp=inp, params=p, cfg=sub_cfg)
 
     return dict(cfg=cfg, model=model, raw=raw, query=query, document=document, kargs=kargs, labels=labels, b1=b1,
-                make_inputs=make_inputs, oracle_slice=oracle_slice, nnz_per_graph=nnz)
+                make_inputs=make_inputs, oracle_slice=oracle_slice, nnz_per_graph=nnz, compact=batch_obj.compact,
+                m_real=batch_obj.m_real)
 
 
 def cpu_baseline(wl, budget_s=15.0, claims=2):
@@ -143,6 +155,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="claims per GPU")
     ap.add_argument("--n-evd", type=int, default=30, help="evidences per claim (<=0: ragged U[1,30])")
     ap.add_argument("--eval-mode", action="store_true", help="disable dropout (parity mode)")
+    ap.add_argument("--padded", action="store_true",
+                    help="run every layer on all R padded node rows (the reference's layout) instead of the node-compact one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -166,7 +180,8 @@ def main():
     from get_amd.dist import FlatTrainer
     _lib.load()
 
-    wl = build_workload(batch=args.batch, n_evd=args.n_evd, seed=20240229 + rank, device=device)
+    wl = build_workload(batch=args.batch, n_evd=args.n_evd, seed=20240229 + rank, device=device,
+                        compact=False if args.padded else None)
     model, cfg = wl["model"], wl["cfg"]
     if world > 1:      # identical replicas: broadcast rank 0's parameters
         for p in model.parameters():
@@ -214,7 +229,9 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
         value = total_pairs * args.steps / dt
-        fl = flops_per_pair(cfg, wl["nnz_per_graph"])
+        real_nodes = wl["m_real"] / max(wl["b1"], 1)
+        fl = flops_per_pair(cfg, wl["nnz_per_graph"], real_nodes if wl["compact"] else None)
+        fl_run = fl.get("executed", fl["fwd_bwd"])
         out = {
             "metric": "claim-evidence pairs/sec fwd+bwd (B=32, h=300)", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -226,10 +243,14 @@ def main():
                                    f"gsl_rate={cfg.gsl_rate}",
                        "step": "device graph build + forward + CE loss + backward + flat grad all-reduce + fused Adam",
                        "mode": "eval (dropout off)" if args.eval_mode else "train (dropout on)",
+                       "layout": (f"node-compact: {wl['m_real']} real-node rows of {wl['b1'] * cfg.len_right} padded rows "
+                                  f"({real_nodes:.1f} unique tokens per {cfg.len_right}-token evidence); padding nodes only "
+                                  "in the first cell's forward and the scorer") if wl["compact"]
+                                 else "padded: every layer on all R node rows (reference layout)",
                        "parallelism": f"dp{world}", "pairs_per_gpu": wl["b1"], "loss": float(loss.item())},
-            "path_tflops": {"flops_per_pair_fwd_bwd": fl["fwd_bwd"],
-                            "achieved_tflops_per_gpu": fl["fwd_bwd"] * value / world / 1e12,
-                            "frac_of_f32_mfma_peak": fl["fwd_bwd"] * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS},
+            "path_tflops": {"flops_per_pair_executed": fl_run, "flops_per_pair_padded_form": fl["fwd_bwd"],
+                            "achieved_tflops_per_gpu": fl_run * value / world / 1e12,
+                            "frac_of_f32_mfma_peak": fl_run * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS},
         }
         if prof is not None:
             kernels = {}

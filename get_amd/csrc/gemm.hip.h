@@ -49,6 +49,7 @@ struct Problem {
   float* out1;
   const float* in0; const float* in1;   // same leading dimension as C
   const float* u; const float* w2; float* e; int ldu; int R; int heads;
+  int seg0_rows;            // > 0: segment 0's A operand is all zero for rows >= seg0_rows (fast kernel skips it per tile)
   const int32_t* rowg;      // EPI_ATT: u row of output row m is rowg[m] when non-null (node-compact layout), else m / R
   long long split_stride;   // TN: element offset of K-chunk `ks`'s partial tile (0 = all chunks hit C, atomically)
   // stateless input dropout (wrapper.py:189-190): element (row, col) of the dropped matrix [rows][drop_ld] is kept

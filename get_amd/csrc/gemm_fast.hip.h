@@ -69,7 +69,10 @@ gemm_fast_kernel(const Launch L_byval) {
     if (kbeg >= kend) return;
   }
   const int nt0 = (kend - kbeg + BK - 1) / BK;
-  const int T = nt0 + (nseg > 1 ? (K1 + BK - 1) / BK : 0);
+  // row tiles that lie entirely at or beyond seg0_rows have an all-zero segment-0 operand (the aggregation of
+  // padding nodes in the node-compact layout): start at the first tile of segment 1
+  const int toff = (!TN && nseg > 1 && P.seg0_rows > 0 && m0 >= P.seg0_rows) ? nt0 : 0;
+  const int T = nt0 + (nseg > 1 ? (K1 + BK - 1) / BK : 0) - toff;
 
   // per-thread A slots
   unsigned a_off0[NA], a_off1[NA];
@@ -124,6 +127,7 @@ gemm_fast_kernel(const Launch L_byval) {
   struct TileAddr { const float* Ab; const float* Bb; int ldb, k0, klim; bool s1; };
   auto tile_addr = [&](int t) __attribute__((always_inline)) {
     TileAddr a;
+    t += toff;
     a.s1 = (!TN) && (t >= nt0);
     a.Ab = a.s1 ? A1 : A0;
     a.Bb = a.s1 ? B1 : B0;

@@ -43,7 +43,14 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
   double flops = 0.0;
   if (prof_enabled()) {
     for (int i = 0; i < L.nprob; ++i)
-      for (int j = 0; j < L.p[i].nseg; ++j) flops += 2.0 * L.p[i].M * L.p[i].N * (double)L.p[i].seg[j].K;
+      for (int j = 0; j < L.p[i].nseg; ++j) {
+        int rows = L.p[i].M;       // segment 0 is skipped by the row tiles at or beyond seg0_rows: do not count it
+        if (j == 0 && !tn && L.p[i].nseg > 1 && L.p[i].seg0_rows > 0) {
+          const int bm = 32 * WM, cut = ((L.p[i].seg0_rows + bm - 1) / bm) * bm;
+          if (cut < rows) rows = cut;
+        }
+        flops += 2.0 * rows * L.p[i].N * (double)L.p[i].seg[j].K;
+      }
     prof_begin(s);
   }
   const bool fast = fast_ok(L, tn);
@@ -366,6 +373,7 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
     Problem pr = gemm_problem(M, h, EPI_SIGMOID_R, rr, h, a, h, wt_r0, h, h);
     add_seg(pr, xp, h, wt_r1, h, h);
     pr.bias = b_r; pr.out1 = rx; pr.in0 = xp;
+    if (m_rows > m_real) pz.seg0_rows = pr.seg0_rows = (m_real > 0 ? m_real : 1);
     b.add(pz); b.add(pr);
     b.flush();
     GH_CHECK_HIP(b.err);
@@ -375,6 +383,7 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
     Problem ph = gemm_problem(M, h, EPI_TANH_H, hh, h, a, h, wt_h0, h, h);
     add_seg(ph, rx, h, wt_h1, h, h);
     ph.bias = b_h; ph.out1 = out; ph.in0 = z; ph.in1 = xp;
+    if (m_rows > m_real) ph.seg0_rows = (m_real > 0 ? m_real : 1);
     b.add(ph);
     b.flush();
     GH_CHECK_HIP(b.err);
@@ -467,7 +476,9 @@ extern "C" int gh_concat_att_fwd(const float* left, const float* right, const fl
   if (!goff) m_real = b * l;
   GH_REQUIRE(m_real >= 0 && m_real <= b * l, "concat_att_fwd: node-compact rows %d do not fit b*l=%d", m_real, b * l);
   const int M = m_real;
-  GH_REQUIRE(ha <= ((M >= 8192 && big_cfg() == 0) ? GH_BN_BIG : GH_BN_SMALL), "concat_att_fwd: attention hidden %d exceeds one column block", ha);
+  const bool one_block = ha <= ((M >= 8192 && big_cfg() == 0) ? GH_BN_BIG : GH_BN_SMALL);
+  GH_REQUIRE(one_block || (ha % 4 == 0 && al16(t) && al16(u) && al16(w2)),
+             "concat_att_fwd: attention hidden %d wider than one column block needs float4-shaped rows", ha);
   if (left && xl > 0) {  // u = W1[:, :xl] . left -- once per pair, not per token (two_branches_attention.py:137-140)
     Batch bt(false, b, s);
     bt.add(gemm_problem(b, ha, EPI_STORE, u, ha, left, xl, w1t, ha, xl));
@@ -481,9 +492,17 @@ extern "C" int gh_concat_att_fwd(const float* left, const float* right, const fl
     Batch bt(false, M, s);
     Problem p = gemm_problem(M, ha, EPI_ATT, t, ha, right, dr, w1t + (size_t)xl * ha, ha, dr);
     p.u = u; p.ldu = ha; p.R = l; p.w2 = w2; p.heads = heads; p.e = e; p.rowg = rowg;
-    bt.add(p);
+    if (!one_block) p.epi = EPI_STORE;     // wide hidden layer (h = 768): the head scores need whole rows, so the
+    bt.add(p);                             // tanh + W2 reduction runs as a row-per-wave pass over the stored product
     bt.flush();
     GH_CHECK_HIP(bt.err);
+    if (!one_block) {
+      FinishArgs F;
+      F.n = 1;
+      F.it[0] = FinishItem{t, 0, 1, M, ha, EPI_ATT, 0, ha, t, nullptr, u, w2, e, ha, l, heads, rowg};
+      hipLaunchKernelGGL(nt_finish_kernel, dim3((M + 3) / 4, 1), dim3(256), 0, s, F);
+      GH_LAUNCH_CHECK();
+    }
   }
   return launch_att_softmax_fwd(e, mask, right, goff, m_real, b, l, dr, heads, weights, attended, s);   // (:142-147)
 }

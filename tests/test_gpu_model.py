@@ -190,6 +190,48 @@ def test_politifact_shaped_long_evidence_vs_oracle(compact):
             assert err <= 1e-3 * float(go.abs().max()) + 1e-6, (k, err)
 
 
+@pytest.mark.parametrize("compact", [False, True])
+def test_h768_wide_hidden_vs_oracle(compact):
+    """BASELINE configs[4] shape in fp32 (h=768, 8 word heads, gnn_window=5, gsl_rate=0.8) at a reduced batch:
+    hidden layers wider than one GEMM column block (cells split into column blocks, the attention's tanh + head
+    scores run as a separate row pass).  HIP vs the CPU oracle: logits 1e-4, attention weights 1e-5, gradients 1e-3."""
+    from get_amd import ops
+    from get_amd.synth import SynthConfig
+    cfg = SynthConfig(batch=2, n_evd=4, hidden=768, word_heads=8, evd_heads=2, window=5, gsl_rate=0.8, vocab=900,
+                      n_article_src=40, n_claim_src=10)
+    seed = 768
+    model = build_model(cfg, seed)
+    raw = make_raw_batch(cfg, seed)
+    inp = assemble_inputs(raw, cfg, O.convert_text)
+    kargs = to_dev(reference_kargs(inp, torch, output_ranking=True))
+    da, d_ids, d_n = ops.graph_build(torch.from_numpy(raw["evd_tokens"]).to(DEV), torch.from_numpy(raw["evd_len"]).to(DEV), cfg.window)
+    if compact:
+        da = da.with_plan(ops.RaggedPlan(d_n, d_ids, int(d_n.sum().item())))
+    kargs["docs_adj"] = da
+    phi, (ww, ew) = model(torch.from_numpy(inp["query"]).to(DEV), torch.from_numpy(inp["document"]).to(DEV), **kargs)
+    torch.nn.functional.cross_entropy(phi, torch.from_numpy(inp["labels"]).to(DEV)).backward()
+    emb, art, clm = make_embeddings(cfg, seed)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    p = {k: T(v).requires_grad_(True) for k, v in make_state_dict(cfg, seed).items()}
+    p["embedding.weight"] = T(emb)
+    p["article_source_embs.weight"] = T(art).requires_grad_(True)
+    phi_o, ww_o, ew_o = O.model_forward(p, cfg.__dict__, T(inp["query"]), T(inp["document"]), T(inp["query_adj"]),
+                                        T(inp["doc_ids"]), T(inp["doc_adj"]), T(inp["query_lens"]), inp["evd_counts"],
+                                        T(inp["doc_sources"]), T(inp["query_sources"]))
+    O.cross_entropy(phi_o, T(inp["labels"])).backward()
+    assert float((phi.detach().cpu() - phi_o.detach()).abs().max()) <= 1e-4
+    assert float((ww.detach().cpu() - ww_o.detach()).abs().max()) <= 1e-5
+    assert float((ew.detach().cpu() - ew_o.detach()).abs().max()) <= 1e-5
+    n_checked = 0
+    for k, prm in model.named_parameters():
+        if k in p and p[k].grad is not None and prm.grad is not None:
+            go = p[k].grad
+            err = float((prm.grad.cpu() - go).abs().max())
+            assert err <= 1e-3 * float(go.abs().max()) + 1e-6, (k, err)
+            n_checked += 1
+    assert n_checked >= 40
+
+
 def test_ragged_realistic_batch_properties():
     """Evidence counts drawn U[1,30] (B1 not a multiple of any tile): weights sum to one, padded slots and
     padded nodes get exactly zero attention, gradients finite, logits equal the oracle on a slice."""
