@@ -299,7 +299,7 @@ def test_batched_predict_equals_per_claim_predict():
         one = mk(slice(b, b + 1), slice(offs[b], offs[b + 1]), raw["evd_counts"][b:b + 1], 1)
         q, d, k = one.inputs()
         p1, (w1, e1) = model.predict(q, d, **dict(k, output_ranking=True))
-        assert float((p1[0] - phi[b]).abs().max()) <= 1e-5
+        assert float((p1[0] - phi[b]).detach().abs().max()) <= 1e-5
         assert float((w1 - word_w[b]).abs().max()) <= 1e-6 and float((e1[0] - evd_w[b]).abs().max()) <= 1e-6
         assert torch.allclose(word_w[b].sum(1), torch.ones_like(word_w[b].sum(1)), atol=1e-5)
 
@@ -334,3 +334,51 @@ def test_trainer_checkpoint_resume_is_bit_identical():
     for (k1, p1), (k2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         if k1 in t1.live_names:
             assert torch.equal(p1.detach(), p2.detach()), k1
+
+
+def test_graph_cache_build_and_cached_batches_match_native_batch(tmp_path):
+    """the packed graph store built on the device equals the oracle's convert_text for every text
+    (ids / node counts bit-exact, adjacency values 1e-7), survives a save/load round trip, and a batch gathered
+    from it runs the model to the same logits as the per-step graph build of NativeBatch (both layouts)."""
+    from get_amd.batch import NativeBatch
+    from get_amd.graph_cache import CachedBatcher, GraphCache
+    from get_amd.synth import SynthConfig
+    cfg = SynthConfig(batch=5, n_evd=0, vocab=700, n_article_src=40, n_claim_src=10, evd_counts=[3, 30, 1, 7, 12])
+    seed = 99
+    model = build_model(cfg, seed)
+    raw = make_raw_batch(cfg, seed)
+    inp = assemble_inputs(raw, cfg, O.convert_text)
+    b1 = int(raw["evd_counts"].sum())
+    ckeys = [f"c{i}" for i in range(cfg.batch)]
+    ekeys = list(range(1000, 1000 + b1))
+    cc = GraphCache.build(ckeys, raw["claim_tokens"], raw["claim_len"], cfg.window, device=DEV)
+    ec = GraphCache.build(ekeys, raw["evd_tokens"], raw["evd_len"], cfg.window, device=DEV, chunk=16)   # several launches
+    assert np.array_equal(ec.node_ids.cpu().numpy(), inp["doc_ids"]) and np.array_equal(ec.n_nodes_host, inp["doc_lens"])
+    assert np.array_equal(cc.node_ids.cpu().numpy(), inp["query"]) and np.array_equal(cc.n_nodes_host, inp["query_lens"])
+    assert float((ec.dense(np.arange(b1)).cpu() - torch.from_numpy(inp["doc_adj"])).abs().max()) <= 1e-7
+    p = str(tmp_path / "evd_cache.npz")
+    ec.save(p)
+    ec = GraphCache.load(p, device=DEV)
+    rel, last = {}, 0
+    for q, c in zip(ckeys, raw["evd_counts"]):
+        rel[q] = ekeys[last:last + int(c)]
+        last += int(c)
+    src = torch.from_numpy(raw["doc_sources"]).to(DEV)
+    qsrc = torch.from_numpy(raw["query_sources"]).to(DEV)
+    nb = NativeBatch(raw["claim_tokens"], raw["claim_len"], raw["evd_tokens"], raw["evd_len"], raw["evd_counts"],
+                     raw["doc_sources"], raw["query_sources"], raw["labels"], window=cfg.window, n_max=cfg.fixed_num_evidences,
+                     device=DEV, compact=True)
+    q0, d0, k0 = nb.inputs()
+    phi0 = model(q0, d0, **k0)
+    for compact in (True, False):
+        bt = CachedBatcher(cc, ec, rel, n_max=cfg.fixed_num_evidences, compact=compact)
+        q1, d1, k1 = bt.inputs(ckeys, doc_sources=src, query_sources=qsrc)
+        assert torch.equal(q1, q0) and torch.equal(d1, d0)
+        phi1 = model(q1, d1, **k1)
+        assert float((phi1 - phi0).abs().max()) <= (0.0 if compact else 2e-6)
+    # a permuted sub-batch of claims equals the corresponding rows
+    bt = CachedBatcher(cc, ec, rel, n_max=cfg.fixed_num_evidences)
+    sel = [3, 1]
+    q2, d2, k2 = bt.inputs([ckeys[i] for i in sel], doc_sources=src[sel], query_sources=qsrc[sel])
+    phi2 = model(q2, d2, **k2)
+    assert float((phi2 - phi0[sel]).abs().max()) <= 2e-6
