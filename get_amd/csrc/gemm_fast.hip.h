@@ -15,13 +15,14 @@
 
 namespace gh {
 
-template <int WM, int WN, int NI, bool TN>
+// Tile = (16*MI*WM) x (16*NI*WN): WM x WN waves, each owning MI x NI MFMA tiles of 16x16.
+template <int WM, int WN, int NI, bool TN, int MI = 2>
 __global__ void __launch_bounds__(WM * WN * 64, 2)
 gemm_fast_kernel(const Launch L_byval) {
   (void)L_byval;
   const GH_KARG Launch& L = *(const GH_KARG Launch*)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int NTHR = WM * WN * 64;
-  constexpr int BM = 32 * WM, BN = 16 * NI * WN, BK = 16;
+  constexpr int BM = 16 * MI * WM, BN = 16 * NI * WN, BK = 16;
   // LDS pitches == 4 (mod 32) dwords: with the k-rows of one MFMA step taken as {s, s+4, s+8, s+12}
   // the two 16-lane halves of a ds_read_b32 group sit 16 banks apart (conflict-free fragment reads),
   // and rows stay 16-byte aligned so the B tile is written with ds_write_b128.
@@ -51,7 +52,7 @@ gemm_fast_kernel(const Launch L_byval) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int wrow = wm * 32, wcol = wn * 16 * NI;
+  const int wrow = wm * 16 * MI, wcol = wn * 16 * NI;
   const int l15 = lane & 15, q = lane >> 4;
 
   // ---- loop-invariant operand description, copied to registers once
@@ -96,6 +97,30 @@ gemm_fast_kernel(const Launch L_byval) {
       a_off1[j] = 0;
     }
   }
+  // TN mode loads through buffer descriptors: `buffer_load_dwordx4 v, voffset, rsrc, soffset offen` with a per-thread
+  // BYTE voffset fixed for the whole K loop (k-row within the tile, column) and a wave-uniform soffset that advances
+  // with the K tile -- no address VALU per tile; rows beyond the K chunk and invalid columns (OOB marker) come back
+  // as 0 from the hardware range check (record count = kend * ld * 4 bytes), so there are no selects either
+  // (TN GEMM 86.8 -> 93.0 TF).  In NT mode the same scheme costs more than it saves: selecting the segment's
+  // descriptor pushes the kernel over its SGPR budget (scratch traffic in the loop, 91 vs 98 TF), so NT keeps
+  // clamped global loads.
+  typedef __amdgpu_buffer_rsrc_t rsrc_t;
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned ta_vo[NA], tb_vo[NB];
+  if (TN) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int idx = tid + j * NTHR;
+      const int c = m0 + 4 * (idx % (BM / 4));
+      ta_vo[j] = ((idx < A4) && (c < M)) ? ((unsigned)(idx / (BM / 4)) * (unsigned)lda0 + (unsigned)c) * 4u : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int idx = tid + j * NTHR;
+      const int c = 4 * (idx % (BN / 4));
+      tb_vo[j] = ((idx < B4) && (c < N)) ? ((unsigned)(idx / (BN / 4)) * (unsigned)ldb0 + (unsigned)c) * 4u : OOB;
+    }
+  }
   // per-thread B slots: column offset and validity (row term added per tile)
   unsigned b_col[NB];
   bool b_ok[NB];
@@ -107,13 +132,13 @@ gemm_fast_kernel(const Launch L_byval) {
     b_col[j] = (unsigned)min(c, N - 4);
   }
 
-  f32x4 acc[2][NI];
+  f32x4 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int mi_cnt = min(2, (M - m0 - wrow + 15) / 16);
+  const int mi_cnt = min(MI, (M - m0 - wrow + 15) / 16);
   const int ni_cnt = min(NI, (N - wcol + 15) / 16);
 
   float4 ra[NA], rb[NB];
@@ -141,6 +166,17 @@ gemm_fast_kernel(const Launch L_byval) {
   // so they stay in flight under the MFMAs of the current tile
   auto load_tile = [&](int t) __attribute__((always_inline)) {
     const TileAddr a = tile_addr(t);
+    if (TN) {
+      const rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A0, 0, kend * lda0 * 4, 0x00020000);
+      const rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B0, 0, kend * ldb0 * 4, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < NA; ++j)
+        ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, ta_vo[j], a.k0 * lda0 * 4, 0));
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rB, tb_vo[j], a.k0 * ldb0 * 4, 0));
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int idx = tid + j * NTHR;
@@ -178,9 +214,7 @@ gemm_fast_kernel(const Launch L_byval) {
           as[(4 * kq + 3) * LDA + row] = v.w;
         } else {
           const int krow = idx / (BM / 4), c = 4 * (idx % (BM / 4));
-          const bool ok = a_ok[j] && (a.k0 + krow < a.klim);
-          const float4 v = ok ? ra[j] : zero4;
-          *reinterpret_cast<float4*>(as + krow * LDA + c) = v;
+          *reinterpret_cast<float4*>(as + krow * LDA + c) = ra[j];       // already zero where out of range
         }
       }
     }
@@ -189,7 +223,7 @@ gemm_fast_kernel(const Launch L_byval) {
       const int idx = tid + j * NTHR;
       if (idx < B4) {
         const int krow = idx / (BN / 4), c = 4 * (idx % (BN / 4));
-        const bool ok = b_ok[j] && (a.k0 + krow < a.klim);
+        const bool ok = TN || (b_ok[j] && (a.k0 + krow < a.klim));
         const float4 v = ok ? rb[j] : zero4;
         *reinterpret_cast<float4*>(bs + krow * LDB + c) = v;
       }
@@ -208,14 +242,14 @@ gemm_fast_kernel(const Launch L_byval) {
 #pragma unroll
     for (int s = S0; s < S0 + 2; ++s) {
       const int kr = s + kq;
-      float a[2], b[NI];
+      float a[MI], b[NI];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) a[mi] = as[kr * LDA + mi * 16];
+      for (int mi = 0; mi < MI; ++mi) a[mi] = as[kr * LDA + mi * 16];
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
         if (NV < 0 || ni < NV) b[ni] = bs[kr * LDB + ni * 16];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
+      for (int mi = 0; mi < MI; ++mi) {
         if (NV >= 0 || mi < mi_cnt) {
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
@@ -225,7 +259,7 @@ gemm_fast_kernel(const Launch L_byval) {
       }
     }
   };
-  const int path = (mi_cnt == 2 && ni_cnt == NI) ? 0 : ((mi_cnt == 2 && ni_cnt == NI - 1) ? 1 : 2);
+  const int path = (mi_cnt == MI && ni_cnt == NI) ? 0 : ((mi_cnt == MI && ni_cnt == NI - 1) ? 1 : 2);
 
   // Software pipeline, one barrier per K tile:
   //   registers hold tile t+1 (loaded one iteration ago, so HBM/L2 latency has a whole tile to hide);
@@ -257,8 +291,8 @@ gemm_fast_kernel(const Launch L_byval) {
     const float* U = P.u; const float* W2 = P.w2; float* E = P.e;
     const int ldu = P.ldu, R = P.R;
     const int32_t* rowg = P.rowg;
-    auto att_rows = [&](auto MI) __attribute__((always_inline)) {
-      constexpr int mi = decltype(MI)::value;
+    auto att_rows = [&](auto MIT) __attribute__((always_inline)) {
+      constexpr int mi = decltype(MIT)::value;
       const int lrow = wrow + mi * 16 + l15;
       const int row = m0 + lrow;
       float pe[8];
@@ -301,6 +335,8 @@ gemm_fast_kernel(const Launch L_byval) {
     };
     att_rows(std::integral_constant<int, 0>{});
     att_rows(std::integral_constant<int, 1>{});
+    if constexpr (MI > 2) { att_rows(std::integral_constant<int, 2>{}); att_rows(std::integral_constant<int, 3>{}); }
+    static_assert(MI == 2 || MI == 4, "MI is 2 or 4");
     if (WN > 1) {
       __syncthreads();
       for (int i = tid; i < BM * 8; i += NTHR) {
@@ -320,8 +356,8 @@ gemm_fast_kernel(const Launch L_byval) {
   const float* in0 = P.in0;
   const float* in1 = P.in1;
   const int accumulate = P.accumulate;
-  auto epi_rows = [&](auto MI) __attribute__((always_inline)) {
-    constexpr int mi = decltype(MI)::value;
+  auto epi_rows = [&](auto MIT) __attribute__((always_inline)) {
+    constexpr int mi = decltype(MIT)::value;
     const int row = m0 + wrow + mi * 16 + l15;
     const bool row_ok = (mi < mi_cnt) && (row < M);
 #pragma unroll
@@ -375,6 +411,7 @@ gemm_fast_kernel(const Launch L_byval) {
   };
   epi_rows(std::integral_constant<int, 0>{});
   epi_rows(std::integral_constant<int, 1>{});
+  if constexpr (MI > 2) { epi_rows(std::integral_constant<int, 2>{}); epi_rows(std::integral_constant<int, 3>{}); }
 }
 
 }  // namespace gh

@@ -20,6 +20,10 @@ static bool fast_ok(const Launch& L, bool tn) {
       if (!s.vecA || !s.vecB || s.gatherB || s.K < 4) return false;
       if (tn && s.gatherA) return false;
     }
+    if (tn) {   // TN mode addresses its operands through buffer descriptors: 31-bit byte offsets
+      const Seg& s = p.seg[0];
+      if (4.0 * (double)s.lda * (double)s.K >= 2147483648.0 || 4.0 * (double)s.ldb * (double)s.K >= 2147483648.0) return false;
+    }
     if (p.N % 4 || p.N < 4 || p.ldc % 4 || !al16(p.C)) return false;
     if (tn && (p.M % 4 || p.M < 4)) return false;
     if ((p.bias && !al16(p.bias)) || (p.out1 && !al16(p.out1)) || (p.in0 && !al16(p.in0)) || (p.in1 && !al16(p.in1)))
@@ -34,8 +38,14 @@ static bool wants_dropout(const Launch& L) {
   return false;
 }
 
-template <int WM, int WN, int NI>
-static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
+template <int WM, int WN, int NI, int MI = 2>
+static hipError_t launch_cfg(const Launch& L_in, bool tn, hipStream_t s) {
+  Launch L = L_in;
+  const bool fast = fast_ok(L, tn);
+  if (!fast && MI != 2 && !tn) {   // the generic kernel's row tile is 32*WM: recount the row tiles
+    L.m_tiles = 0;
+    for (int i = 0; i < L.nprob; ++i) { const int mt = (L.p[i].M + 32 * WM - 1) / (32 * WM); if (mt > L.m_tiles) L.m_tiles = mt; }
+  }
   const int n_outer = tn ? L.ksplit : L.m_tiles;
   const int n_inner = tn ? L.m_tiles * L.nprob : L.nprob * L.ksplit;
   const int grid = 8 * ((n_outer + 7) / 8) * n_inner;
@@ -46,18 +56,17 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
       for (int j = 0; j < L.p[i].nseg; ++j) {
         int rows = L.p[i].M;       // segment 0 is skipped by the row tiles at or beyond seg0_rows: do not count it
         if (j == 0 && !tn && L.p[i].nseg > 1 && L.p[i].seg0_rows > 0) {
-          const int bm = 32 * WM, cut = ((L.p[i].seg0_rows + bm - 1) / bm) * bm;
+          const int bm = 16 * MI * WM, cut = ((L.p[i].seg0_rows + bm - 1) / bm) * bm;
           if (cut < rows) rows = cut;
         }
         flops += 2.0 * rows * L.p[i].N * (double)L.p[i].seg[j].K;
       }
     prof_begin(s);
   }
-  const bool fast = fast_ok(L, tn);
   if (!fast && wants_dropout(L)) return hipErrorInvalidValue;     // fused dropout exists in the fast kernel only
   if (fast) {
-    if (tn) hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, true>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
-    else hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, false>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
+    if (tn) hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, true, 2>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
+    else hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, false, MI>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
   } else {
     if (tn) hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, true>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
     else hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, false>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
@@ -183,8 +192,8 @@ struct Batch {
 
   Batch(bool tn_, int rows_hint, hipStream_t s_) : tn(tn_), s(s_) {
     big = tn_ || rows_hint >= 8192;
-    bm = big ? (big_cfg() == 0 ? 128 : 64) : 32;
-    bn = big ? (big_cfg() == 0 ? GH_BN_BIG : (big_cfg() == 3 ? 160 : 320)) : GH_BN_SMALL;
+    bm = big ? (big_cfg() == 0 || ((big_cfg() == 4 || big_cfg() == 5) && !tn_) ? 128 : 64) : 32;
+    bn = big ? (big_cfg() == 0 ? GH_BN_BIG : (big_cfg() == 3 || (big_cfg() == 5 && !tn_) ? 160 : 320)) : GH_BN_SMALL;
     reset();
   }
   void reset() { L.nprob = 0; L.m_tiles = 0; L.ksplit = 1; L.kchunk = 0; k_total = 0; }
@@ -261,7 +270,9 @@ struct Batch {
   hipError_t launch_any() {
     return !big ? launch_cfg<1, 4, 5>(L, tn, s)
                 : (big_cfg() == 0 ? launch_cfg<4, 1, 19>(L, tn, s)
-                   : (big_cfg() == 3 ? launch_cfg<2, 2, 5>(L, tn, s) : launch_cfg<2, 2, 10>(L, tn, s)));
+                   : (big_cfg() == 3 ? launch_cfg<2, 2, 5>(L, tn, s)
+                      : (big_cfg() == 4 && !tn ? launch_cfg<2, 2, 10, 4>(L, tn, s)
+                         : (big_cfg() == 5 && !tn ? launch_cfg<4, 1, 10>(L, tn, s) : launch_cfg<2, 2, 10>(L, tn, s)))));
   }
 
   // Few-row NT GEMMs (evidence level, head): too few row tiles to fill 256 CUs, so split K across
