@@ -154,6 +154,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="claims per GPU")
     ap.add_argument("--n-evd", type=int, default=30, help="evidences per claim (<=0: ragged U[1,30])")
+    ap.add_argument("--len-right", type=int, default=100, help="evidence length R (configs[2]: 200)")
+    ap.add_argument("--hidden", type=int, default=300, help="hidden size H (configs[4]: 768, run in fp32)")
+    ap.add_argument("--word-heads", type=int, default=5)
+    ap.add_argument("--window", type=int, default=3, help="gnn_window")
+    ap.add_argument("--gsl-rate", type=float, default=0.6)
     ap.add_argument("--eval-mode", action="store_true", help="disable dropout (parity mode)")
     ap.add_argument("--padded", action="store_true",
                     help="run every layer on all R padded node rows (the reference's layout) instead of the node-compact one")
@@ -180,8 +185,9 @@ def main():
     from get_amd.dist import FlatTrainer
     _lib.load()
 
-    wl = build_workload(batch=args.batch, n_evd=args.n_evd, seed=20240229 + rank, device=device,
-                        compact=False if args.padded else None)
+    cfg_in = SynthConfig(batch=args.batch, n_evd=args.n_evd, len_right=args.len_right, hidden=args.hidden,
+                         word_heads=args.word_heads, window=args.window, gsl_rate=args.gsl_rate)
+    wl = build_workload(seed=20240229 + rank, device=device, cfg=cfg_in, compact=False if args.padded else None)
     model, cfg = wl["model"], wl["cfg"]
     if world > 1:      # identical replicas: broadcast rank 0's parameters
         for p in model.parameters():
@@ -236,7 +242,8 @@ def main():
             "metric": "claim-evidence pairs/sec fwd+bwd (B=32, h=300)", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: Snopes-shaped synthetic batch, "
+            "config": {"workload": ("BASELINE configs[1]: Snopes-shaped synthetic batch, " if (args.len_right, args.hidden, args.word_heads, args.window, args.gsl_rate) == (100, 300, 5, 3, 0.6)
+                                    else "non-default shape (see flags): synthetic batch, ") +
                                    f"B={cfg.batch} claims x {args.n_evd if args.n_evd > 0 else 'U[1,30]'} evidences per GPU "
                                    f"(B1={wl['b1']} pairs), L_left={cfg.len_left}, L_right={cfg.len_right}, D=H={cfg.hidden}, "
                                    f"{cfg.word_heads} word heads / {cfg.evd_heads} evidence heads, gnn_window={cfg.window}, "

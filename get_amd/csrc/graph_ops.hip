@@ -360,7 +360,9 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   const int V = v4 ? 4 : 1;
   const int hv = h / V;
   // slab: <= 32 float4 (or 128 scalars) per row, as even as possible
-  const int slab_max = v4 ? 32 : 128;
+  // (sized so that a workgroup's slab stays under ~48 KB of LDS: three workgroups per CU also at R = 200)
+  const int lds_cap = (48 * 1024) / (r * (v4 ? 16 : 4));
+  const int slab_max = v4 ? (lds_cap < 32 ? (lds_cap < 4 ? 4 : lds_cap) : 32) : (lds_cap < 128 ? (lds_cap < 16 ? 16 : lds_cap) : 128);
   const int nslab = (hv + slab_max - 1) / slab_max;
   const int slab = (hv + nslab - 1) / nslab;
   const size_t lds = ((((size_t)r * slab * V) + 3) & ~(size_t)3) * 4 + (size_t)r * W * 8 + (size_t)r * 4;
