@@ -211,8 +211,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # Live roofline: inside the timed region only the dominant kernel (the 64x320 NT/NN GEMM, row "gemm_big") is
+    # bracketed with HIP events -- instrumenting all ~100 launches of a step costs ~0.4 ms of queue bubbles per step.
+    # The per-kernel table (`kernels`) comes from PROFILE_EXTRA_STEPS extra, untimed steps after the timed region.
+    DOMINANT = "gemm_big"
     if not args.no_profile:
-        _lib.profile_enable(True)
+        _lib.profile_enable(True, only=[DOMINANT])
         _lib.profile_collect()
     barrier()
     t0 = time.perf_counter()
@@ -220,8 +224,14 @@ def main():
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    prof = None
+    prof = prof_dom = None
+    PROFILE_EXTRA_STEPS = 5
     if not args.no_profile:
+        prof_dom = _lib.profile_collect()[DOMINANT]
+        _lib.profile_enable(True)                       # every instrumented kernel, outside the timed region
+        for _ in range(PROFILE_EXTRA_STEPS):
+            step()
+        torch.cuda.synchronize()
         prof = _lib.profile_collect()
         _lib.profile_enable(False)
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -264,9 +274,9 @@ def main():
             for name, r in prof.items():
                 if r["launches"] == 0:
                     continue
-                per_step = r["ms"] / args.steps
+                per_step = r["ms"] / PROFILE_EXTRA_STEPS
                 rate = r["work"] / (r["ms"] * 1e-3) if r["ms"] > 0 else 0.0
-                entry = {"ms_per_step": per_step, "launches_per_step": r["launches"] / args.steps,
+                entry = {"ms_per_step": per_step, "launches_per_step": r["launches"] / PROFILE_EXTRA_STEPS,
                          "avg_launch_ms": r["ms"] / r["launches"]}
                 if name.startswith("gemm"):
                     entry.update(bound="mfma", achieved_tflops=rate / 1e12, frac=rate / 1e12 / PEAK_F32_MFMA_TFLOPS)
@@ -274,7 +284,10 @@ def main():
                     entry.update(bound="hbm", achieved_gbps=rate / 1e9, frac=rate / 1e9 / PEAK_HBM_GBPS)
                 kernels[name] = entry
             dom = max((k for k in kernels if k.startswith("gemm")), key=lambda k: kernels[k]["ms_per_step"])
-            d = kernels[dom]
+            assert dom == DOMINANT, f"dominant kernel is {dom}, the timed region instrumented {DOMINANT}"
+            rate = prof_dom["work"] / (prof_dom["ms"] * 1e-3)
+            d = {"achieved_tflops": rate / 1e12, "frac": rate / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                 "avg_launch_ms": prof_dom["ms"] / prof_dom["launches"], "launches_per_step": prof_dom["launches"] / args.steps}
             traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[dom]
@@ -284,7 +297,10 @@ def main():
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["achieved_tflops"],
                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": d["frac"], "traffic": traffic,
                                "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_per_step"],
-                               "alg_flops_per_launch": prof[dom]["work"] / prof[dom]["launches"]}
+                               "alg_flops_per_launch": prof_dom["work"] / prof_dom["launches"],
+                               "measured": f"HIP events around every {dom} launch of the {args.steps} timed steps"}
+            out["kernels_note"] = (f"per-kernel table from {PROFILE_EXTRA_STEPS} extra untimed steps with every library "
+                                   "kernel bracketed by HIP events (costs ~0.4 ms/step, so it stays out of the timed region)")
             out["kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline:
             model.train(False)

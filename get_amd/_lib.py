@@ -48,6 +48,7 @@ SIGNATURES = {
     "gh_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     "gh_set_workspace": [_P, _L],
     "gh_profile_enable": [_I],
+    "gh_profile_select": [_U],
     "gh_profile_collect": [_P, _I],
 }
 
@@ -55,7 +56,10 @@ PROFILE_ROWS = ["gemm_big", "gemm_big_tn", "gemm_small", "gemm_small_tn", "spmm"
                 "graph_build", "att_softmax_fwd", "att_softmax_bwd", "att_dpre", "gate_bwd_pre", "colsum", "adam"]
 
 
-def profile_enable(on: bool):
+def profile_enable(on: bool, only=None):
+    """Turn the per-launch HIP-event timing on/off; `only` = iterable of PROFILE_ROWS names to instrument (default all)."""
+    mask = 0xFFFFFFFF if only is None else sum(1 << PROFILE_ROWS.index(n) for n in only)
+    call("gh_profile_select", mask)
     call("gh_profile_enable", 1 if on else 0)
 
 

@@ -39,7 +39,7 @@ enum ProfTag : int {
   PROF_GATE_BWD_PRE, PROF_COLSUM, PROF_ADAM, PROF_NTAGS
 };
 bool prof_enabled();
-void prof_begin(hipStream_t s);
+void prof_begin(hipStream_t s, int tag);   // events are recorded only for tags selected by gh_profile_select
 void prof_end(int tag, double work, hipStream_t s);
 
 // internal launchers implemented in graph_ops.hip / misc_ops.hip, used by the fused entry points

@@ -61,7 +61,7 @@ static hipError_t launch_cfg(const Launch& L_in, bool tn, hipStream_t s) {
         }
         flops += 2.0 * rows * L.p[i].N * (double)L.p[i].seg[j].K;
       }
-    prof_begin(s);
+    prof_begin(s, (WM * WN == 4 && WN != 4 ? PROF_GEMM_BIG : PROF_GEMM_SMALL) + (tn ? 1 : 0));
   }
   if (!fast && wants_dropout(L)) return hipErrorInvalidValue;     // fused dropout exists in the fast kernel only
   if (fast) {

@@ -376,7 +376,7 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   // ~8K waves in flight their sliding-window working set (~49 MB) thrashes the 32 MB of L2 (hit rate 32 %).
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("GH_SPMM_VARIANT"); variant = e ? atoi(e) : 0; }
-  prof_begin(s);
+  prof_begin(s, PROF_SPMM);
   if (v4 && variant == 2 && h / 4 <= 128 && !goff) {
     constexpr int RPW = 5;
     const int wpg = (r + RPW - 1) / RPW;
@@ -546,7 +546,7 @@ extern "C" int gh_graph_build(const int32_t* tokens, const int32_t* lengths, int
   GH_REQUIRE(fixed_length > 0 && fixed_length <= MAX_R, "graph_build: fixed_length %d not in [1,%d]", fixed_length, MAX_R);
   GH_REQUIRE(window >= 1, "graph_build: window %d < 1", window);
   if (n_texts <= 0) return 0;
-  prof_begin((hipStream_t)stream);
+  prof_begin((hipStream_t)stream, PROF_GRAPH_BUILD);
   hipLaunchKernelGGL(graph_build_kernel, dim3(n_texts), dim3(256), 0, (hipStream_t)stream, tokens, lengths,
                      fixed_length, window, node_ids, n_nodes, bits, dinv);
   prof_end(PROF_GRAPH_BUILD, (double)n_texts * (12.0 * fixed_length + 8.0 * fixed_length * words_for(fixed_length) + 8.0),
@@ -604,7 +604,7 @@ extern "C" int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const floa
   GH_REQUIRE(r > 0 && r <= MAX_R, "scorer_gsl: r=%d not in [1,%d]", r, MAX_R);
   GH_REQUIRE(vals || dinv, "scorer_gsl: need dinv or vals");
   if (n <= 0) return 0;
-  prof_begin((hipStream_t)stream);
+  prof_begin((hipStream_t)stream, PROF_SCORER_GSL);
   GH_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "scorer_gsl: dropout p=%f not in [0,1)", drop_p);
   const double th = (double)drop_p * 4294967296.0;
   const unsigned thresh = drop_p > 0.f ? (th >= 4294967295.0 ? 4294967295u : (unsigned)th) : 0u;

@@ -21,6 +21,7 @@ void set_error(const char* fmt, ...) {
 // ---------------------------------------------------------------------------- event profiler
 struct ProfRec { hipEvent_t a, b; int tag; double work; };
 static bool g_prof_on = false;
+static unsigned g_prof_mask = 0xFFFFFFFFu;     // bit t set: kernels with tag t are instrumented (gh_profile_select)
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
 static hipEvent_t g_prof_cur = nullptr;
@@ -32,8 +33,9 @@ static hipEvent_t prof_event() {
   return e;
 }
 bool prof_enabled() { return g_prof_on; }
-void prof_begin(hipStream_t s) {
-  if (!g_prof_on) return;
+void prof_begin(hipStream_t s, int tag) {
+  g_prof_cur = nullptr;
+  if (!g_prof_on || !((g_prof_mask >> tag) & 1u)) return;
   g_prof_cur = prof_event();
   if (g_prof_cur) (void)hipEventRecord(g_prof_cur, s);
 }
@@ -123,7 +125,7 @@ int launch_gate_bwd_pre(const float* g, const float* z, const float* hh, const f
   if (count % 4 == 0 && (al & 15) == 0) {
     const size_t n4 = count / 4;
     const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-    prof_begin(s);
+    prof_begin(s, PROF_GATE_BWD_PRE);
     hipLaunchKernelGGL(gate_bwd_pre_kernel, dim3(grid), dim3(256), 0, s, (const float4*)g, (const float4*)z,
                        (const float4*)hh, (const float4*)xp, (float4*)dhp, (float4*)dzp, (float4*)dxp, n4);
     prof_end(PROF_GATE_BWD_PRE, 7.0 * 4.0 * (double)count, s);
@@ -230,7 +232,7 @@ int launch_colsum3(const float* a, const float* b, const float* c, float* oa, fl
     const int n4 = h / 4;
     const int RL = (256 / n4) > 0 ? (256 / n4) : 1;
     const int threads = ((n4 * RL + 63) / 64) * 64;
-    prof_begin(s);
+    prof_begin(s, PROF_COLSUM);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(threads), (size_t)3 * RL * h * sizeof(float), s, a, b, c,
                        g_cs_ws, m, h, RL);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((3 * h + 63) / 64), dim3(256), 0, s, g_cs_ws, nblk, h, oa, ob, oc, oa2, ob2, oc2);
@@ -238,7 +240,7 @@ int launch_colsum3(const float* a, const float* b, const float* c, float* oa, fl
     GH_LAUNCH_CHECK();
     return 0;
   }
-  prof_begin(s);
+  prof_begin(s, PROF_COLSUM);
   hipLaunchKernelGGL(colsum_kernel, dim3((m + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, s, a, b, c, oa, ob, oc, oa2, ob2, oc2, m, h);
   prof_end(PROF_COLSUM, bytes, s);
   GH_LAUNCH_CHECK();
@@ -361,7 +363,7 @@ int launch_att_softmax_fwd(const float* e, const float* mask, const float* right
   GH_REQUIRE(dr % 4 == 0 && (reinterpret_cast<uintptr_t>(right) & 15) == 0, "att_softmax_fwd: right rows must be float4-shaped (dr=%d)", dr);
   const size_t lds = ((size_t)l * heads + 4 * 64 * 4 * heads) * 4;
   GH_REQUIRE(lds <= 64 * 1024, "att_softmax_fwd: sequence %d x heads %d too large", l, heads);
-  prof_begin(s);
+  prof_begin(s, PROF_ATT_SOFTMAX_FWD);
   hipLaunchKernelGGL(att_softmax_fwd_kernel, dim3(b, (dr / 4 + 63) / 64), dim3(256), lds, s, e, mask, right, goff, l, dr,
                      heads, weights, attended);
   const double rows = goff ? (double)m_real : (double)b * l;
@@ -434,7 +436,7 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
   GH_REQUIRE(lds <= 160 * 1024, "att_softmax_bwd: %zu B of LDS needed", lds);
   static bool attr = false;
   if (!attr && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)att_softmax_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  prof_begin(s);
+  prof_begin(s, PROF_ATT_SOFTMAX_BWD);
   hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(b), dim3(256), lds, s, right, weights, g_att, g_w, goff, l, dr, heads, de,
                      dright);
   const double rows = goff ? (double)m_real : (double)b * l;
@@ -506,7 +508,7 @@ int launch_att_dpre(const float* de, const float* w2, const float* t, const int3
   const int RL = (256 / n4) > 0 ? (256 / n4) : 1;
   const int threads = ((n4 * RL + 63) / 64) * 64;
   const size_t lds = (size_t)RL * (1 + heads) * n4 * 16;
-  prof_begin(s);
+  prof_begin(s, PROF_ATT_DPRE);
   hipLaunchKernelGGL(att_dpre_kernel, dim3(b), dim3(threads), lds, s, de, w2, t, goff, l, ha, heads, RL, dpre, du, dw2_part);
   const double rows = goff ? (double)m_real : (double)b * l;
   prof_end(PROF_ATT_DPRE, 4.0 * (2.0 * rows * ha + rows * heads + (double)b * ha), s);
@@ -627,6 +629,11 @@ extern "C" int gh_profile_enable(int on) {
   return 0;
 }
 // out[PROF_NTAGS][3] = {total ms, total work, launches}; waits for the recorded events, then resets.
+extern "C" int gh_profile_select(uint32_t tag_mask) {
+  g_prof_mask = tag_mask;
+  return 0;
+}
+
 extern "C" int gh_profile_collect(double* out, int rows) {
   GH_REQUIRE(rows >= PROF_NTAGS, "profile_collect: need %d rows", (int)PROF_NTAGS);
   for (int i = 0; i < rows * 3; ++i) out[i] = 0.0;
@@ -729,7 +736,7 @@ extern "C" int gh_adam_step(float* p, const float* g, float* m, float* v, int64_
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const int grid = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
-  prof_begin((hipStream_t)stream);
+  prof_begin((hipStream_t)stream, PROF_ADAM);
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)count, lr, beta1,
                      beta2, eps, weight_decay, bc1, (float)sqrt(bc2), grad_scale);
   prof_end(PROF_ADAM, 28.0 * (double)count, (hipStream_t)stream);

@@ -207,6 +207,10 @@ int gh_adam_step(float* p, const float* g, float* m, float* v, int64_t count, fl
  * 6 graph_build, 7 att_softmax_fwd, 8 att_softmax_bwd, 9 att_dpre, 10 gate_bwd_pre, 11 colsum, 12 adam */
 #define GH_PROFILE_ROWS 13
 int gh_profile_enable(int on);
+/* Restrict the instrumentation to the rows whose bit is set in tag_mask (default: all).  Two events per launch cost
+ * ~1.5 us of queue bubbles each, ~0.4 ms per bench step when every kernel is instrumented: bench.py times the step
+ * with only the dominant kernel's row selected and collects the full table in an extra, untimed pass. */
+int gh_profile_select(uint32_t tag_mask);
 int gh_profile_collect(double* out_host, int rows);
 
 #ifdef __cplusplus
