@@ -98,6 +98,32 @@ def build_workload(batch=32, n_evd=30, seed=20240229, device="cuda:0", cfg: Synt
                 m_real=batch_obj.m_real)
 
 
+def box_reference(device):
+    """Measured ceilings of THIS box, next to the datasheet peaks: a plain device copy (HBM read +
+    write bytes per second) and the vendor BLAS fp32 GEMM rate at 8192^3 (torch.mm -> hipBLASLt/rocBLAS)."""
+    x = torch.empty(256 << 20, device=device, dtype=torch.float32)      # 1 GiB
+    y = torch.empty_like(x)
+    a = torch.randn(8192, 8192, device=device)
+    b = torch.randn(8192, 8192, device=device)
+    c = torch.empty(8192, 8192, device=device)
+
+    def timed(fn, reps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    t_copy = timed(lambda: y.copy_(x), 10)
+    t_mm = timed(lambda: torch.mm(a, b, out=c), 5)
+    return {"copy_gbps": 2.0 * x.numel() * 4 / t_copy / 1e9, "blas_sgemm_8192_tflops": 2.0 * 8192 ** 3 / t_mm / 1e12}
+
+
 def cpu_baseline(wl, budget_s=15.0, claims=2):
     """The CPU oracle (a port of the reference's PyTorch path) timed on this host's cores on a bounded
     sample: forward + backward of the first `claims` claims of the same batch, repeated for ~budget_s."""
@@ -302,6 +328,8 @@ def main():
             out["kernels_note"] = (f"per-kernel table from {PROFILE_EXTRA_STEPS} extra untimed steps with every library "
                                    "kernel bracketed by HIP events (costs ~0.4 ms/step, so it stays out of the timed region)")
             out["kernels"] = kernels
+        if not args.no_profile:
+            out["box_reference"] = box_reference(device)
         if world == 1 and not args.no_cpu_baseline:
             model.train(False)
             with torch.no_grad():
