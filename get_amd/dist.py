@@ -15,6 +15,11 @@ import torch
 import torch.distributed as dist
 
 DEAD_PREFIXES = ("bilstm.", "query_bilstm.", "trans.", "ggnn_with_gsl.word_scorer1.")
+# Parameters whose gradients are final only at the very end of the backward pass (the first evidence cell, the claim
+# branch and the claim-source table, which autograd schedules after it).  Everything else -- head, both attentions,
+# the article-source table and the second evidence cell, 76 % of the bucket -- is final once the gradient w.r.t. the
+# first cell's output exists, so its share of the all-reduce can run underneath the rest of the backward.
+LATE_PREFIXES = ("ggnn_with_gsl.feat_prop1.", "ggnn4claim_1.", "claim_source_embs.")
 
 
 def live_parameters(model: torch.nn.Module):
@@ -35,11 +40,16 @@ class FlatTrainer:
     live parameter are views into them, so autograd accumulates straight into the all-reduce bucket."""
 
     def __init__(self, model: torch.nn.Module, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 process_group=None):
+                 process_group=None, late_prefixes: Sequence[str] = LATE_PREFIXES):
         self.model = model
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.group = process_group
         live = live_parameters(model)
+        # bucket order: early-final gradients first, late ones at the end (one contiguous range each)
+        late_prefixes = tuple(late_prefixes)
+        live = [x for x in live if not x[0].startswith(late_prefixes)] + [x for x in live if x[0].startswith(late_prefixes)]
+        self.n_early = sum(p.numel() for n, p in live if not n.startswith(late_prefixes))
+        self._early_work = None
         self.live_names: List[str] = [n for n, _ in live]
         self.params = [p for _, p in live]
         total = sum(p.numel() for p in self.params)
@@ -83,15 +93,37 @@ class FlatTrainer:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def zero_grad(self):
+        assert self._early_work is None, "zero_grad() while an all-reduce is in flight (call step() / allreduce() first)"
         self.flat_g.zero_()
         for p, gv in zip(self.params, self._views):
             if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
                 p.grad = gv                      # re-attach if something replaced the view
 
+    def allreduce_early_async(self):
+        """Start the all-reduce of the early-final part of the bucket (call it once those gradients are complete in
+        stream order, e.g. from the hook ``attach_overlap`` installs).  No-op for a single rank or when already started."""
+        if self.world > 1 and self._early_work is None and 0 < self.n_early < self.numel:
+            self._early_work = dist.all_reduce(self.flat_g[:self.n_early], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def allreduce(self):
-        """One all-reduce(sum) of the whole gradient bucket (RCCL over xGMI on GPUs, gloo in CPU tests)."""
+        """All-reduce(sum) of the gradient bucket (RCCL over xGMI on GPUs, gloo in CPU tests): the whole bucket in one
+        collective, or -- when the early part is already in flight -- a wait on it plus the late remainder."""
         if self.world > 1:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+            if self._early_work is not None:
+                self._early_work.wait()
+                self._early_work = None
+                dist.all_reduce(self.flat_g[self.n_early:], op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+
+    def attach_overlap(self, module=None):
+        """Overlap the early part of the all-reduce with the tail of the backward pass: the module that owns the
+        first evidence cell (``model.ggnn_with_gsl``) calls ``grad_milestone_hook`` when the gradient w.r.t. that
+        cell's output has been produced, i.e. when every early gradient is final."""
+        module = module if module is not None else getattr(self.model, "ggnn_with_gsl", None)
+        if module is None:
+            raise ValueError("attach_overlap: no module with a grad_milestone_hook slot")
+        module.grad_milestone_hook = self.allreduce_early_async
 
     def step(self):
         """all-reduce + fused Adam on the flat bucket (gradient averaged over ranks inside the kernel)."""

@@ -129,6 +129,17 @@ class GGNN_with_GSL(nn.Module):
         self.feat_prop2 = GGNN(hidden_dim, output_dim, dropout)
         self.last_score = None     # observables of the last forward (scores, keep words) for analysis/tests
         self.last_keep = None
+        # called (no arguments) during backward as soon as the gradient w.r.t. the first cell's output exists: from
+        # then on only the first cell's own gradients are still to come (dist.FlatTrainer.attach_overlap)
+        self.grad_milestone_hook = None
+
+    def _milestone(self, feat):
+        hook = self.grad_milestone_hook
+        if hook is not None and feat.requires_grad:
+            def fire(g, _hook=hook):
+                _hook()
+                return g
+            feat.register_hook(fire)
 
     def _gate12(self):
         s = self.word_scorer1
@@ -150,6 +161,7 @@ class GGNN_with_GSL(nn.Module):
     def forward(self, adj, feat):
         adj = ops.as_packed(adj)
         feat = self.feat_prop1(adj, feat)
+        self._milestone(feat)
         adj_refined = self._refine(adj, feat)
         return self.feat_prop2(adj_refined, feat)
 
@@ -160,9 +172,11 @@ class GGNN_with_GSL(nn.Module):
         adj = ops.as_packed(adj)
         if plan is None:
             feat = self.feat_prop1.forward_ids(adj, embedding, ids)
+            self._milestone(feat)
             adj_refined = self._refine(adj, feat)
             return self.feat_prop2(adj_refined, feat)
         feat = self.feat_prop1.forward_ids(adj, embedding, ids, plan=plan, rows=plan.m_tot)
+        self._milestone(feat)
         adj_refined = self._refine(adj, feat, plan)
         return self.feat_prop2(adj_refined, feat, plan=plan, rows=plan.m_real)
 

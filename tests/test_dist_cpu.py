@@ -59,6 +59,70 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+class Toy2(torch.nn.Module):
+    """late(x) -> h -> early(h): in backward `early` is final when the gradient w.r.t. h exists."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(1)
+        self.late = torch.nn.Linear(6, 5)
+        self.early = torch.nn.Linear(5, 3)
+        self.grad_milestone_hook = None
+
+    def forward(self, x):
+        h = torch.tanh(self.late(x))
+        if self.grad_milestone_hook is not None:
+            hook = self.grad_milestone_hook
+            h.register_hook(lambda g: (hook(), g)[1])
+        return self.early(h)
+
+
+def _worker_overlap(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = Toy2()
+    tr = FlatTrainer(model, late_prefixes=("late.",))
+    assert tr.live_names == ["early.weight", "early.bias", "late.weight", "late.bias"]      # early-final first
+    assert tr.n_early == 5 * 3 + 3
+    tr.attach_overlap(model)
+    torch.manual_seed(321)
+    x = torch.randn(8, 6)
+    y = torch.randint(0, 3, (8,))
+    idx = list(shard_claims(8, rank, world))
+    fired = []
+    orig = tr.allreduce_early_async
+    model.grad_milestone_hook = lambda: (fired.append(model.late.weight.grad.abs().sum().item()), orig())
+    for _ in range(2):                                   # two steps: the in-flight handle is consumed and re-armed
+        tr.zero_grad()
+        torch.nn.functional.cross_entropy(model(x[idx]), y[idx]).backward()
+        assert tr._early_work is not None                # started from inside backward ...
+        tr.allreduce()
+        assert tr._early_work is None
+    assert fired == [0.0, 0.0]                           # ... before the late gradients existed
+    g = tr.flat_g / world
+    if rank == 0:
+        ref = Toy2()
+        torch.nn.functional.cross_entropy(ref(x), y).backward()
+        exp = torch.cat([ref.early.weight.grad.reshape(-1), ref.early.bias.grad.reshape(-1),
+                         ref.late.weight.grad.reshape(-1), ref.late.bias.grad.reshape(-1)])
+        out.put(float((g - exp).abs().max()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_allreduce_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlap, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) <= 1e-6
+
+
 def test_two_rank_flat_allreduce_matches_single_process():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -382,3 +382,35 @@ def test_graph_cache_build_and_cached_batches_match_native_batch(tmp_path):
     q2, d2, k2 = bt.inputs([ckeys[i] for i in sel], doc_sources=src[sel], query_sources=qsrc[sel])
     phi2 = model(q2, d2, **k2)
     assert float((phi2 - phi0[sel]).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("name", ["small", "small_claimsrc"])
+def test_early_gradients_are_final_at_the_milestone(name):
+    """dist.FlatTrainer overlaps the all-reduce of the 'early' bucket range with the rest of the backward pass; that is
+    only legal if every early gradient is complete when the milestone hook fires (autograd's execution order).
+    Snapshot the range inside the hook and compare it with the final bucket, in both row layouts."""
+    from get_amd import ops
+    from get_amd.dist import FlatTrainer, LATE_PREFIXES
+    cfg, seed = MODEL_CASES[name]
+    model = build_model(cfg, seed).train(True)
+    tr = FlatTrainer(model)
+    assert 0 < tr.n_early < tr.numel
+    assert all(n.startswith(LATE_PREFIXES) for n in tr.live_names[len([n for n in tr.live_names if not n.startswith(LATE_PREFIXES)]):])
+    raw = make_raw_batch(cfg, seed)
+    inp = assemble_inputs(raw, cfg, O.convert_text)
+    labels = torch.from_numpy(inp["labels"]).to(DEV)
+    for compact in (False, True):
+        kargs = to_dev(reference_kargs(inp, torch))
+        da, d_ids, d_n = ops.graph_build(torch.from_numpy(raw["evd_tokens"]).to(DEV), torch.from_numpy(raw["evd_len"]).to(DEV), cfg.window)
+        if compact:
+            da = da.with_plan(ops.RaggedPlan(d_n, d_ids, int(d_n.sum().item())))
+        kargs["docs_adj"] = da
+        snaps = []
+        model.ggnn_with_gsl.grad_milestone_hook = lambda: snaps.append(tr.flat_g[:tr.n_early].clone())
+        tr.zero_grad()
+        phi = model(torch.from_numpy(inp["query"]).to(DEV), torch.from_numpy(inp["document"]).to(DEV), **kargs)
+        torch.nn.functional.cross_entropy(phi, labels).backward()
+        assert len(snaps) == 1
+        assert torch.equal(snaps[0], tr.flat_g[:tr.n_early]), f"an early gradient changed after the milestone (compact={compact})"
+        assert float(tr.flat_g[:tr.n_early].abs().sum()) > 0 and float(tr.flat_g[tr.n_early:].abs().sum()) > 0
+    model.ggnn_with_gsl.grad_milestone_hook = None
