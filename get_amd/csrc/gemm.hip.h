@@ -52,6 +52,9 @@ struct Problem {
   int seg0_rows;            // > 0: segment 0's A operand is all zero for rows >= seg0_rows (fast kernel skips it per tile)
   const int32_t* rowg;      // EPI_ATT: u row of output row m is rowg[m] when non-null (node-compact layout), else m / R
   long long split_stride;   // TN: element offset of K-chunk `ks`'s partial tile (0 = all chunks hit C, atomically)
+  // TN: when non-null, the column sums of the A operand over this workgroup's K chunk (= the bias gradient that
+  // belongs to this weight gradient) are written to colsum[ks * colsum_stride + column]; fast kernel only
+  float* colsum; long long colsum_stride;
   // stateless input dropout (wrapper.py:189-190): element (row, col) of the dropped matrix [rows][drop_ld] is kept
   // iff hash(seed, row*drop_ld + col) >= drop_thresh and then scaled by drop_scale = 1/(1-p).
   // drop_mode: 0 off, 1 = A of segment 0 (NT), 3 = C in the EPI_STORE epilogue (gradient w.r.t. the dropped

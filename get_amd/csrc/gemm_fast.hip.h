@@ -143,6 +143,8 @@ gemm_fast_kernel(const Launch L_byval) {
 
   float4 ra[NA], rb[NB];
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 csum = zero4;                          // TN: running column sums of this thread's A slots (bias gradient)
+  float* const colsum = TN ? P.colsum : nullptr;
   const int drop_mode = P.drop_mode;
   const unsigned drop_seed = P.drop_seed, drop_thresh = P.drop_thresh;
   const float drop_scale = P.drop_scale;
@@ -215,6 +217,7 @@ gemm_fast_kernel(const Launch L_byval) {
         } else {
           const int krow = idx / (BM / 4), c = 4 * (idx % (BM / 4));
           *reinterpret_cast<float4*>(as + krow * LDA + c) = ra[j];       // already zero where out of range
+          if (colsum) { csum.x += ra[j].x; csum.y += ra[j].y; csum.z += ra[j].z; csum.w += ra[j].w; }
         }
       }
     }
@@ -279,6 +282,22 @@ gemm_fast_kernel(const Launch L_byval) {
     else if (path == 1) compute(t & 1, std::integral_constant<int, NI - 1>{}, std::integral_constant<int, 1>{});
     else compute(t & 1, std::integral_constant<int, -1>{}, std::integral_constant<int, 1>{});
     __syncthreads();
+  }
+
+  if (TN && colsum) {
+    // every A tile passed through store_tile exactly once: fold the 16 k-rows of each 4-column group (LDS is free
+    // after the loop's last barrier) and write this K chunk's partial bias gradient
+    constexpr int CG = BM / 4;
+    float4* red = reinterpret_cast<float4*>(smem);
+    if (tid < A4) red[tid] = csum;
+    __syncthreads();
+    if (tid < CG) {
+      float4 v = zero4;
+#pragma unroll
+      for (int r = 0; r < A4 / CG; ++r) { const float4 x = red[r * CG + tid]; v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w; }
+      const int c = m0 + 4 * tid;
+      if (c < M) *reinterpret_cast<float4*>(colsum + (size_t)ks * (size_t)P.colsum_stride + c) = v;
+    }
   }
 
   // -------------------------------------------------------------------- epilogue (16-byte vector accesses)

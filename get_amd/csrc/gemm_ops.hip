@@ -189,6 +189,12 @@ struct Batch {
   int bm, bn;
   hipError_t err = hipSuccess;
   int k_total = 0;
+  // TN: bias gradients fused into the weight-gradient launch (Problem::colsum): per problem up to two outputs that
+  // receive (+=) the column sums of the A operand.  colsum_fused tells the caller whether that happened.
+  float* cs_out[GH_MAX_PROBLEMS] = {nullptr};
+  float* cs_out2[GH_MAX_PROBLEMS] = {nullptr};
+  bool colsum_fused = false;
+  void want_colsum(float* o, float* o2) { if (L.nprob > 0) { cs_out[L.nprob - 1] = o; cs_out2[L.nprob - 1] = o2; } }
 
   Batch(bool tn_, int rows_hint, hipStream_t s_) : tn(tn_), s(s_) {
     big = tn_ || rows_hint >= 8192;
@@ -196,7 +202,10 @@ struct Batch {
     bn = big ? (big_cfg() == 0 ? GH_BN_BIG : (big_cfg() == 3 || (big_cfg() == 5 && !tn_) ? 160 : 320)) : GH_BN_SMALL;
     reset();
   }
-  void reset() { L.nprob = 0; L.m_tiles = 0; L.ksplit = 1; L.kchunk = 0; k_total = 0; }
+  void reset() {
+    L.nprob = 0; L.m_tiles = 0; L.ksplit = 1; L.kchunk = 0; k_total = 0;
+    for (int i = 0; i < GH_MAX_PROBLEMS; ++i) cs_out[i] = cs_out2[i] = nullptr;
+  }
 
   void add(const Problem& p) {
     if (p.epi == EPI_ATT && p.N > bn) { err = hipErrorInvalidValue; return; }
@@ -236,10 +245,13 @@ struct Batch {
       // partial tiles -> workspace when it is big enough and every output is float4-shaped
       size_t need = 0;
       bool ws_ok = g_ws != nullptr && L.ksplit > 1;
+      bool any_cs = false;
       for (int i = 0; i < L.nprob && ws_ok; ++i) {
         if (L.p[i].N % 4) ws_ok = false;
         need += (size_t)L.ksplit * L.p[i].M * L.p[i].N * sizeof(float);
+        if (cs_out[i]) { need += (size_t)L.ksplit * L.p[i].M * sizeof(float); any_cs = true; }
       }
+      if (any_cs && !(ws_ok && need <= g_ws_bytes && fast_ok(L, true))) any_cs = false;   // caller runs the column-sum kernels
       if (ws_ok && need <= g_ws_bytes) {
         ReduceArgs R;
         R.n = L.nprob;
@@ -252,9 +264,25 @@ struct Batch {
           w += (size_t)L.ksplit * q.M * q.N;
           if (q.M * (q.N / 4) > max_elems) max_elems = q.M * (q.N / 4);
         }
+        ReduceArgs RC;          // bias-gradient partials [ksplit][M] behind the tiles, summed into one or two outputs
+        RC.n = 0;
+        int max_cs = 0;
+        for (int i = 0; i < L.nprob && any_cs; ++i) {
+          Problem& q = L.p[i];
+          if (!cs_out[i]) continue;
+          q.colsum = w; q.colsum_stride = q.M;
+          RC.it[RC.n++] = ReduceItem{w, cs_out[i], 1, q.M, q.M, L.ksplit, (long long)q.M};
+          if (cs_out2[i] && RC.n < GH_MAX_PROBLEMS) RC.it[RC.n++] = ReduceItem{w, cs_out2[i], 1, q.M, q.M, L.ksplit, (long long)q.M};
+          w += (size_t)L.ksplit * q.M;
+          if (q.M / 4 > max_cs) max_cs = q.M / 4;
+        }
         hipError_t e = launch_any();
         if (e != hipSuccess) err = e;
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((max_elems + 255) / 256, R.n), dim3(256), 0, s, R);
+        if (RC.n > 0) {
+          hipLaunchKernelGGL(reduce_partials_kernel, dim3((max_cs + 255) / 256, RC.n), dim3(256), 0, s, RC);
+          colsum_fused = true;
+        }
         e = hipGetLastError();
         if (e != hipSuccess) err = e;
         reset();
@@ -452,13 +480,16 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
     b.flush();
     GH_CHECK_HIP(b.err);
   }
-  {  // weight gradients: G^T X over the m = n*r rows, split-K with fp32 atomics
+  {  // weight gradients: G^T X over the M rows, split-K partial tiles + reduce.  The bias gradients are the column
+     // sums of dzp / drp / dhp: they ride along with the first GEMM that streams each of them (no separate
+     // column-sum pass over 3 x M x h values) whenever the launch takes the workspace path.
     Batch b(true, M, s);
-    b.add(tn_problem(h, h, dw_z0, h, dzp, h, a, h, M));
+    const bool cs = (h % 4 == 0) && (h <= 320);
+    b.add(tn_problem(h, h, dw_z0, h, dzp, h, a, h, M));  if (cs) b.want_colsum(db_z, db_z1);
     b.add(tn_problem(h, h, dw_z1, h, dzp, h, xp, h, M));
-    b.add(tn_problem(h, h, dw_r0, h, drp, h, a, h, M));
+    b.add(tn_problem(h, h, dw_r0, h, drp, h, a, h, M));  if (cs) b.want_colsum(db_r, db_r1);
     b.add(tn_problem(h, h, dw_r1, h, drp, h, xp, h, M));
-    b.add(tn_problem(h, h, dw_h0, h, dhp, h, a, h, M));
+    b.add(tn_problem(h, h, dw_h0, h, dhp, h, a, h, M));  if (cs) b.want_colsum(db_h, db_h1);
     b.add(tn_problem(h, h, dw_h1, h, dhp, h, rx, h, M));
     if ((ids || drop_p > 0.f) && din <= h) {
       // operand rows materialised once into the (now free) `da` scratch -- embedding gather and/or the forward's
@@ -471,6 +502,7 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
     }
     b.flush();
     GH_CHECK_HIP(b.err);
+    if (b.colsum_fused) return 0;
   }
   return launch_colsum3(dzp, drp, dhp, db_z, db_r, db_h, M, h, s, db_z1, db_r1, db_h1);
 }

@@ -48,13 +48,18 @@ class FlatTrainer:
         # bucket order: early-final gradients first, late ones at the end (one contiguous range each)
         late_prefixes = tuple(late_prefixes)
         live = [x for x in live if not x[0].startswith(late_prefixes)] + [x for x in live if x[0].startswith(late_prefixes)]
-        self.n_early = sum(p.numel() for n, p in live if not n.startswith(late_prefixes))
         self._early_work = None
         self.live_names: List[str] = [n for n, _ in live]
         self.params = [p for _, p in live]
-        total = sum(p.numel() for p in self.params)
+        # every parameter starts on a 256-byte boundary of the flat buffers: the kernels take weights and gradients
+        # straight from these views and need 16-byte aligned rows (a 2-element bias would otherwise shift everything
+        # behind it onto the slow, scalar-load GEMM path); the padding elements stay zero under Adam
+        ALIGN = 64
+        slot = lambda p: (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        total = sum(slot(p) for p in self.params)
+        self.n_early = sum(slot(p) for n, p in live if not n.startswith(late_prefixes))
         dev = self.params[0].device
-        self.flat_p = torch.empty(total, device=dev, dtype=torch.float32)
+        self.flat_p = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_m = torch.zeros(total, device=dev, dtype=torch.float32)
         self.flat_v = torch.zeros(total, device=dev, dtype=torch.float32)
@@ -68,7 +73,7 @@ class FlatTrainer:
             p.grad = gv
             p._gh_direct_grad = True          # kernels may accumulate straight into this view (ops._direct)
             self._views.append(gv)
-            off += n
+            off += slot(p)
         self.numel = total
         self.t = 0
         # matrices whose transposed copy the forward GEMMs consume (everything but embedding tables)

@@ -143,10 +143,10 @@ class GGNN_with_GSL(nn.Module):
 
     def _gate12(self):
         s = self.word_scorer1
-        parts = []
+        srcs = []
         for m in (s.linearz0, s.linearz1, s.linearr0, s.linearr1, s.linearh0, s.linearh1):
-            parts += [m.linear.weight.reshape(1), m.linear.bias.reshape(1)]
-        return torch.cat(parts)
+            srcs += [m.linear.weight, m.linear.bias]
+        return ops.derived("gate12", tuple(srcs), lambda: torch.cat([t.detach().reshape(1) for t in srcs]))
 
     def _refine(self, adj: PackedAdj, feat, plan=None):
         s = self.word_scorer1

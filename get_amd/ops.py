@@ -22,6 +22,7 @@ def bump_weight_epoch():
     global _WEIGHT_EPOCH
     _WEIGHT_EPOCH += 1
     _WT_CACHE.clear()
+    _DERIVED_CACHE.clear()
 
 
 def _direct(p) -> bool:
@@ -57,6 +58,27 @@ def transposed(w: torch.Tensor) -> torch.Tensor:
             del _WT_CACHE[k]
     _WT_CACHE[key] = (weakref.ref(w), w.data_ptr(), w._version, _WEIGHT_EPOCH, wt)
     return wt
+
+
+_DERIVED_CACHE: dict = {}
+
+
+def derived(tag: str, tensors, fn):
+    """Small per-parameter-set cache for values derived from weights (bias sums, packed scalar gates): recomputed only
+    when one of the source tensors was replaced, modified in place (``_version``) or the weight epoch moved on (the
+    fused optimiser updates parameters through raw pointers).  Saves a dozen tiny elementwise launches per step."""
+    key = (tag,) + tuple(id(t) for t in tensors)
+    sig = tuple((t.data_ptr(), t._version) for t in tensors) + (_WEIGHT_EPOCH,)
+    hit = _DERIVED_CACHE.get(key)
+    if hit is not None and hit[0] == sig and all(r() is t for r, t in zip(hit[1], tensors)):
+        return hit[2]
+    with torch.no_grad():
+        val = fn()
+    if len(_DERIVED_CACHE) > 512:
+        for k in [k for k, v in _DERIVED_CACHE.items() if any(r() is None for r in v[1])]:
+            del _DERIVED_CACHE[k]
+    _DERIVED_CACHE[key] = (sig, tuple(weakref.ref(t) for t in tensors), val)
+    return val
 
 
 def refresh_transposes(weights):
@@ -250,9 +272,8 @@ class _GGNNCell(torch.autograd.Function):
         dev = x.device
         ws = [_f32(w.detach()) for w in (w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1)]
         wts = [transposed(w) for w in (w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1)]
-        b_z = _f32((b_z0 + b_z1).detach())
-        b_r = _f32((b_r0 + b_r1).detach())
-        b_h = _f32((b_h0 + b_h1).detach())
+        b_z, b_r, b_h = derived("cell_bias", (b_z0, b_z1, b_r0, b_r1, b_h0, b_h1), lambda: tuple(
+            _f32(u.detach() + v.detach()) for u, v in ((b_z0, b_z1), (b_r0, b_r1), (b_h0, b_h1))))
         buf = torch.empty((7, m, h), device=dev, dtype=torch.float32)
         xp, a, z, rr, rx, hh, out = buf.unbind(0)
         call("gh_ggnn_cell_fwd", *adj._args(), *_plan_args(plan), m, ptr(x), ptr(ids), n, r, din, h,

@@ -49,7 +49,7 @@ def _worker(rank, world, port, out):
     loss.backward()
     assert model.live.weight.grad.data_ptr() == tr.flat_g.data_ptr()        # autograd wrote into the bucket
     tr.allreduce()
-    g = tr.flat_g / world
+    g = torch.cat([v.reshape(-1) for v in tr._views]) / world
     if rank == 0:
         ref = Toy()
         torch.nn.functional.cross_entropy(ref(x), y).backward()
@@ -83,7 +83,8 @@ def _worker_overlap(rank, world, port, out):
     model = Toy2()
     tr = FlatTrainer(model, late_prefixes=("late.",))
     assert tr.live_names == ["early.weight", "early.bias", "late.weight", "late.bias"]      # early-final first
-    assert tr.n_early == 5 * 3 + 3
+    assert tr.n_early == 64 + 64 and tr.numel == 4 * 64          # every parameter owns a 256-byte aligned slot
+    assert all(v.data_ptr() % 256 == tr.flat_g.data_ptr() % 256 for v in tr._views)
     tr.attach_overlap(model)
     torch.manual_seed(321)
     x = torch.randn(8, 6)
@@ -99,7 +100,7 @@ def _worker_overlap(rank, world, port, out):
         tr.allreduce()
         assert tr._early_work is None
     assert fired == [0.0, 0.0]                           # ... before the late gradients existed
-    g = tr.flat_g / world
+    g = torch.cat([v.reshape(-1) for v in tr._views]) / world
     if rank == 0:
         ref = Toy2()
         torch.nn.functional.cross_entropy(ref(x), y).backward()
