@@ -50,6 +50,7 @@ SIGNATURES = {
     "gh_profile_enable": [_I],
     "gh_profile_select": [_U],
     "gh_profile_collect": [_P, _I],
+    "gh_gemm_path_counters": [_P, _I],
 }
 
 PROFILE_ROWS = ["gemm_big", "gemm_big_tn", "gemm_small", "gemm_small_tn", "spmm", "scorer_gsl",
@@ -69,6 +70,13 @@ def profile_collect() -> dict:
     call("gh_profile_collect", ctypes.cast(buf, ctypes.c_void_p), len(PROFILE_ROWS))
     return {name: {"ms": buf[3 * i], "work": buf[3 * i + 1], "launches": int(buf[3 * i + 2])}
             for i, name in enumerate(PROFILE_ROWS)}
+
+def gemm_path_counters(reset: bool = False) -> dict:
+    """{"fast", "generic", "generic_large"} GEMM launch counts since the last reset (see include/get_hip.h)."""
+    buf = (ctypes.c_int64 * 3)()
+    call("gh_gemm_path_counters", ctypes.cast(buf, ctypes.c_void_p), 1 if reset else 0)
+    return {"fast": int(buf[0]), "generic": int(buf[1]), "generic_large": int(buf[2])}
+
 
 _lib = None
 

@@ -38,10 +38,22 @@ static bool wants_dropout(const Launch& L) {
   return false;
 }
 
+// launches since the last reset: {fast kernel, generic kernel, generic kernel with >= 1 GFLOP of work}.  The generic
+// kernel is the correctness net for odd shapes and unaligned operands; a LARGE GEMM landing on it is a performance
+// bug upstream (e.g. a misaligned parameter view), which tests assert against through gh_gemm_path_counters.
+static long long g_path_counts[3] = {0, 0, 0};
+
 template <int WM, int WN, int NI, int MI = 2>
 static hipError_t launch_cfg(const Launch& L_in, bool tn, hipStream_t s) {
   Launch L = L_in;
   const bool fast = fast_ok(L, tn);
+  {
+    double fl = 0.0;
+    for (int i = 0; i < L.nprob; ++i)
+      for (int j = 0; j < L.p[i].nseg; ++j) fl += 2.0 * L.p[i].M * L.p[i].N * (double)L.p[i].seg[j].K;
+    g_path_counts[fast ? 0 : 1] += 1;
+    if (!fast && fl >= 1e9) g_path_counts[2] += 1;
+  }
   if (!fast && MI != 2 && !tn) {   // the generic kernel's row tile is 32*WM: recount the row tiles
     L.m_tiles = 0;
     for (int i = 0; i < L.nprob; ++i) { const int mt = (L.p[i].M + 32 * WM - 1) / (32 * WM); if (mt > L.m_tiles) L.m_tiles = mt; }
@@ -605,6 +617,13 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, const in
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }
+  return 0;
+}
+
+extern "C" int gh_gemm_path_counters(int64_t* out_host, int reset) {
+  if (out_host)
+    for (int i = 0; i < 3; ++i) out_host[i] = g_path_counts[i];
+  if (reset) g_path_counts[0] = g_path_counts[1] = g_path_counts[2] = 0;
   return 0;
 }
 

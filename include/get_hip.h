@@ -213,6 +213,11 @@ int gh_profile_enable(int on);
 int gh_profile_select(uint32_t tag_mask);
 int gh_profile_collect(double* out_host, int rows);
 
+/* GEMM launches since the last reset: out_host[0] on the float4 fast kernel, [1] on the generic (scalar-guarded) kernel,
+ * [2] on the generic kernel with >= 1 GFLOP of work -- the last one should stay 0 in a healthy training step (a large
+ * GEMM only falls back when an operand is misaligned or oddly shaped). */
+int gh_gemm_path_counters(int64_t* out_host, int reset);
+
 #ifdef __cplusplus
 }
 #endif

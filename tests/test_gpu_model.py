@@ -414,3 +414,25 @@ def test_early_gradients_are_final_at_the_milestone(name):
         assert torch.equal(snaps[0], tr.flat_g[:tr.n_early]), f"an early gradient changed after the milestone (compact={compact})"
         assert float(tr.flat_g[:tr.n_early].abs().sum()) > 0 and float(tr.flat_g[tr.n_early:].abs().sum()) > 0
     model.ggnn_with_gsl.grad_milestone_hook = None
+
+
+def test_training_step_keeps_large_gemms_on_the_fast_kernel():
+    """Performance guard: with the flat-bucket trainer (parameters and gradients are views into flat buffers) no GEMM
+    with >= 1 GFLOP of work may fall back to the generic scalar-load kernel -- that only happens when an operand view
+    is misaligned (a 2-element bias once shifted a whole parameter group off its 16-byte alignment)."""
+    from bench import build_workload
+    from get_amd import _lib
+    from get_amd.dist import FlatTrainer
+    wl = build_workload(batch=8, n_evd=30, seed=5, device=DEV)
+    model = wl["model"].train(True)
+    tr = FlatTrainer(model)
+    assert all(p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0 for p in tr.params)
+    for _ in range(2):
+        tr.zero_grad()
+        q, d, k = wl["make_inputs"]()
+        _lib.gemm_path_counters(reset=True)
+        torch.nn.functional.cross_entropy(model(q, d, **k), wl["labels"]).backward()
+        c = _lib.gemm_path_counters()
+        tr.step()
+    assert c["fast"] >= 30, c
+    assert c["generic_large"] == 0, c
