@@ -246,7 +246,10 @@ struct Batch {
     if (L.nprob == 0 || err != hipSuccess) { reset(); return; }
     if (tn) {
       const int n_inner = L.m_tiles * L.nprob;
-      int ks = (1536 + n_inner - 1) / n_inner;   // two resident rounds of 256 CUs x 3 workgroups (one round measured 20 % slower)
+      static int target = -1;
+      if (target < 0) { const char* e = getenv("GH_TN_SPLIT_TARGET"); target = e ? atoi(e) : 2304; }
+      int ks = (target + n_inner - 1) / n_inner;   // three resident rounds of 256 CUs x 3 workgroups (measured on the bench step: 1152 -> 2.06 ms,
+                                                   // 1536 -> 1.95, 2304 -> 1.86, 3072 -> 1.84 but more partials to reduce; one round 20 % slower)
       const int ks_max = (k_total / 256 > 1) ? k_total / 256 : 1;
       if (ks > ks_max) ks = ks_max;
       if (ks < 1) ks = 1;
