@@ -436,3 +436,24 @@ def test_training_step_keeps_large_gemms_on_the_fast_kernel():
         tr.step()
     assert c["fast"] >= 30, c
     assert c["generic_large"] == 0, c
+
+
+def test_training_loop_overfits_a_small_batch():
+    """End-to-end sanity of the training path beyond single-step parity: native batches, node-compact layout, training
+    mode with the fused dropout, flat-bucket Adam -- 60 steps on one small batch must drive the loss down."""
+    from bench import build_workload
+    from get_amd.dist import FlatTrainer
+    torch.manual_seed(7)
+    wl = build_workload(batch=6, n_evd=0, seed=13, device=DEV)
+    model = wl["model"].train(True)
+    tr = FlatTrainer(model, lr=1e-3, weight_decay=0.0)
+    losses = []
+    for _ in range(60):
+        tr.zero_grad()
+        q, d, k = wl["make_inputs"]()
+        loss = torch.nn.functional.cross_entropy(model(q, d, **k), wl["labels"])
+        loss.backward()
+        tr.step()
+        losses.append(float(loss.item()))
+    assert all(np.isfinite(losses))
+    assert np.mean(losses[-5:]) < 0.35 * np.mean(losses[:3]), losses[::6]
