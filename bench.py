@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 from get_amd.synth import SynthConfig, make_embeddings, make_raw_batch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, spec
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # same guide: dense bf16 MFMA (the opt-in --gemm-mode bf16 prices gemm_big against this)
 PEAK_HBM_GBPS = 8000.0           # HBM3E spec (6.3 TB/s achievable)
 
 
@@ -185,6 +186,8 @@ def main():
     ap.add_argument("--word-heads", type=int, default=5)
     ap.add_argument("--window", type=int, default=3, help="gnn_window")
     ap.add_argument("--gsl-rate", type=float, default=0.6)
+    ap.add_argument("--gemm-mode", choices=["fp32", "bf16"], default="fp32",
+                    help="bf16: opt-in bf16-operand MFMA in the big NT/NN GEMMs (configs[4]); the headline metric is fp32")
     ap.add_argument("--eval-mode", action="store_true", help="disable dropout (parity mode)")
     ap.add_argument("--padded", action="store_true",
                     help="run every layer on all R padded node rows (the reference's layout) instead of the node-compact one")
@@ -217,6 +220,7 @@ def main():
     from get_amd import _lib
     from get_amd.dist import FlatTrainer
     _lib.load()
+    _lib.set_gemm_mode(args.gemm_mode)
 
     cfg_in = SynthConfig(batch=args.batch, n_evd=args.n_evd, len_right=args.len_right, hidden=args.hidden,
                          word_heads=args.word_heads, window=args.window, gsl_rate=args.gsl_rate)
@@ -286,7 +290,9 @@ def main():
         out = {
             "metric": "claim-evidence pairs/sec fwd+bwd (B=32, h=300)", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.gemm_mode == "fp32" else "bf16 operands / f32 accumulate in the big NT GEMMs, f32 elsewhere",
+            "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: Snopes-shaped synthetic batch, " if (args.len_right, args.hidden, args.word_heads, args.window, args.gsl_rate) == (100, 300, 5, 3, 0.6)
                                     else "non-default shape (see flags): synthetic batch, ") +
                                    f"B={cfg.batch} claims x {args.n_evd if args.n_evd > 0 else 'U[1,30]'} evidences per GPU "
@@ -314,7 +320,8 @@ def main():
                 entry = {"ms_per_step": per_step, "launches_per_step": r["launches"] / PROFILE_EXTRA_STEPS,
                          "avg_launch_ms": r["ms"] / r["launches"]}
                 if name.startswith("gemm"):
-                    entry.update(bound="mfma", achieved_tflops=rate / 1e12, frac=rate / 1e12 / PEAK_F32_MFMA_TFLOPS)
+                    pk = PEAK_BF16_MFMA_TFLOPS if (args.gemm_mode == "bf16" and name == "gemm_big") else PEAK_F32_MFMA_TFLOPS
+                    entry.update(bound="mfma", achieved_tflops=rate / 1e12, frac=rate / 1e12 / pk)
                 else:
                     entry.update(bound="hbm", achieved_gbps=rate / 1e9, frac=rate / 1e9 / PEAK_HBM_GBPS)
                 kernels[name] = entry
@@ -324,7 +331,8 @@ def main():
                 dom_note = f"{dom} takes more time per step than {DOMINANT} at this shape; the live roofline below is {DOMINANT}'s"
                 dom = DOMINANT
             rate = prof_dom["work"] / (prof_dom["ms"] * 1e-3)
-            d = {"achieved_tflops": rate / 1e12, "frac": rate / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            dom_peak = PEAK_BF16_MFMA_TFLOPS if args.gemm_mode == "bf16" else PEAK_F32_MFMA_TFLOPS
+            d = {"achieved_tflops": rate / 1e12, "frac": rate / 1e12 / dom_peak,
                  "avg_launch_ms": prof_dom["ms"] / prof_dom["launches"], "launches_per_step": prof_dom["launches"] / args.steps}
             traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
             try:
@@ -333,7 +341,7 @@ def main():
             except Exception:
                 pass
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["achieved_tflops"],
-                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": d["frac"], "traffic": traffic,
+                               "peak": dom_peak, "unit": "TFLOP/s", "frac": d["frac"], "traffic": traffic,
                                "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_per_step"],
                                "alg_flops_per_launch": prof_dom["work"] / prof_dom["launches"],
                                "measured": f"HIP events around every {dom} launch of the {args.steps} timed steps"}

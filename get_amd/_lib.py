@@ -51,6 +51,7 @@ SIGNATURES = {
     "gh_profile_select": [_U],
     "gh_profile_collect": [_P, _I],
     "gh_gemm_path_counters": [_P, _I],
+    "gh_set_gemm_mode": [_I],
 }
 
 PROFILE_ROWS = ["gemm_big", "gemm_big_tn", "gemm_small", "gemm_small_tn", "spmm", "scorer_gsl",
@@ -70,6 +71,11 @@ def profile_collect() -> dict:
     call("gh_profile_collect", ctypes.cast(buf, ctypes.c_void_p), len(PROFILE_ROWS))
     return {name: {"ms": buf[3 * i], "work": buf[3 * i + 1], "launches": int(buf[3 * i + 2])}
             for i, name in enumerate(PROFILE_ROWS)}
+
+def set_gemm_mode(mode: str):
+    """"fp32" (default, exact fp32 MFMA) or "bf16" (bf16 operands / fp32 accumulate in the big NT/NN GEMMs)."""
+    call("gh_set_gemm_mode", {"fp32": 0, "bf16": 1}[mode])
+
 
 def gemm_path_counters(reset: bool = False) -> dict:
     """{"fast", "generic", "generic_large"} GEMM launch counts since the last reset (see include/get_hip.h)."""

@@ -16,9 +16,21 @@
 namespace gh {
 
 // Tile = (16*MI*WM) x (16*NI*WN): WM x WN waves, each owning MI x NI MFMA tiles of 16x16.
-template <int WM, int WN, int NI, bool TN, int MI = 2>
+// BF (NT/NN mode only): operands are rounded to bf16 when they are staged in LDS and multiplied with
+// v_mfma_f32_16x16x16_bf16 (fp32 accumulate, everything outside the tile stays fp32) -- the opt-in path for
+// BASELINE configs[4] ("h=768 bf16 ... MFMA projections"); the default and every parity claim are fp32.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));     // v_cvt_pk_bf16_f32 (RNE)
+}
+
+template <int WM, int WN, int NI, bool TN, int MI = 2, bool BF = false>
 __global__ void __launch_bounds__(WM * WN * 64, 2)
 gemm_fast_kernel(const Launch L_byval) {
+  static_assert(!(BF && TN), "the bf16 variant exists for the NT/NN mode only");
   (void)L_byval;
   const GH_KARG Launch& L = *(const GH_KARG Launch*)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int NTHR = WM * WN * 64;
@@ -32,6 +44,15 @@ gemm_fast_kernel(const Launch L_byval) {
   __shared__ float smem[2 * BK * LDA + 2 * BK * LDB];
   float* As = smem;
   float* Bs = smem + 2 * BK * LDA;
+  // BF layout: [row][16 k as bf16] resp. [col][16 k as bf16] with a 40-byte pitch (10 dwords: the 8-byte fragment
+  // reads of a half wave spread over all 32 banks exactly twice = the 2-cycle optimum); one MFMA covers the K tile
+  constexpr int PB8 = 40;
+  unsigned char* As8 = reinterpret_cast<unsigned char*>(smem);
+  unsigned char* Bs8 = As8 + 2 * BM * PB8;
+  static_assert(!BF || (2 * BM * PB8 + 2 * BN * PB8 <= (int)sizeof(float) * (2 * BK * LDA + 2 * BK * LDB)), "LDS");
+  constexpr int BF4 = BN * 4;                                    // BF: B slots = (column, group of 4 k)
+  constexpr int NBF = (BF4 + NTHR - 1) / NTHR;
+  static_assert(!BF || NBF <= NB, "the bf16 B loader reuses the fp32 prefetch registers");
 
   // NT launches may also be split over K (few-row GEMMs): inner = (k-chunk, problem)
   const int n_inner = TN ? L.m_tiles * L.nprob : L.nprob * L.ksplit;
@@ -187,6 +208,23 @@ gemm_fast_kernel(const Launch L_byval) {
       else off = (unsigned)min(a.k0 + idx / (BM / 4), a.klim - 1) * (unsigned)lda0 + a_off0[j];
       ra[j] = *reinterpret_cast<const float4*>(a.Ab + off);
     }
+    if (BF) {
+      // B is k-major in memory but the bf16 MFMA wants 4 consecutive k per lane: four coalesced dword loads (64 lanes
+      // = 64 consecutive columns of one k row) per slot instead of one 16-byte load along n
+#pragma unroll
+      for (int j = 0; j < NBF; ++j) {
+        const int idx = tid + j * NTHR;
+        const int kq = min(idx / BN, 3), n = min(idx % BN, N - 1);
+        const float* bp = a.Bb + n;
+        float4 v;
+        v.x = bp[(unsigned)min(a.k0 + 4 * kq + 0, a.klim - 1) * (unsigned)a.ldb];
+        v.y = bp[(unsigned)min(a.k0 + 4 * kq + 1, a.klim - 1) * (unsigned)a.ldb];
+        v.z = bp[(unsigned)min(a.k0 + 4 * kq + 2, a.klim - 1) * (unsigned)a.ldb];
+        v.w = bp[(unsigned)min(a.k0 + 4 * kq + 3, a.klim - 1) * (unsigned)a.ldb];
+        rb[j] = v;
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int idx = tid + j * NTHR;
@@ -210,16 +248,37 @@ gemm_fast_kernel(const Launch L_byval) {
           float4 v = ok ? ra[j] : zero4;
           if (drop_mode == 1 && !a.s1)
             v = drop4(v, drop_seed, (unsigned)(m0 + row) * (unsigned)drop_ld + (unsigned)(a.k0 + 4 * kq), drop_thresh, drop_scale);
-          as[(4 * kq + 0) * LDA + row] = v.x;
-          as[(4 * kq + 1) * LDA + row] = v.y;
-          as[(4 * kq + 2) * LDA + row] = v.z;
-          as[(4 * kq + 3) * LDA + row] = v.w;
+          if (BF) {
+            *reinterpret_cast<uint2*>(As8 + (buf * BM + row) * PB8 + kq * 8) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+          } else {
+            as[(4 * kq + 0) * LDA + row] = v.x;
+            as[(4 * kq + 1) * LDA + row] = v.y;
+            as[(4 * kq + 2) * LDA + row] = v.z;
+            as[(4 * kq + 3) * LDA + row] = v.w;
+          }
         } else {
           const int krow = idx / (BM / 4), c = 4 * (idx % (BM / 4));
           *reinterpret_cast<float4*>(as + krow * LDA + c) = ra[j];       // already zero where out of range
           if (colsum) { csum.x += ra[j].x; csum.y += ra[j].y; csum.z += ra[j].z; csum.w += ra[j].w; }
         }
       }
+    }
+    if (BF) {
+#pragma unroll
+      for (int j = 0; j < NBF; ++j) {
+        const int idx = tid + j * NTHR;
+        if (idx < BF4) {
+          const int kq = idx / BN, n = idx % BN;
+          const bool nok = n < N;
+          float4 v = rb[j];
+          v.x = (nok && a.k0 + 4 * kq + 0 < a.klim) ? v.x : 0.f;
+          v.y = (nok && a.k0 + 4 * kq + 1 < a.klim) ? v.y : 0.f;
+          v.z = (nok && a.k0 + 4 * kq + 2 < a.klim) ? v.z : 0.f;
+          v.w = (nok && a.k0 + 4 * kq + 3 < a.klim) ? v.w : 0.f;
+          *reinterpret_cast<uint2*>(Bs8 + (buf * BN + n) * PB8 + kq * 8) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
+        }
+      }
+      return;
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -239,6 +298,28 @@ gemm_fast_kernel(const Launch L_byval) {
   auto compute = [&](int buf, auto NVT, auto HALFT) __attribute__((always_inline)) {
     constexpr int NV = decltype(NVT)::value;
     constexpr int S0 = decltype(HALFT)::value * 2;      // k-steps {0,1} or {2,3} of the tile
+    if constexpr (BF) {
+      // one MFMA spans the whole 16-deep K tile: the first half of the tile does the lower MI/2 row tiles, the
+      // second half the upper ones (the LDS refill still sits between them)
+      constexpr int H = decltype(HALFT)::value;
+      const unsigned char* as8 = As8 + (buf * BM + wrow + l15) * PB8 + q * 8;
+      const unsigned char* bs8 = Bs8 + (buf * BN + wcol + l15) * PB8 + q * 8;
+      s16x4_t bfr[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        if (NV < 0 || ni < NV) bfr[ni] = __builtin_bit_cast(s16x4_t, *reinterpret_cast<const uint2*>(bs8 + ni * 16 * PB8));
+#pragma unroll
+      for (int mi = H * (MI / 2); mi < (H + 1) * (MI / 2); ++mi) {
+        const s16x4_t afr = __builtin_bit_cast(s16x4_t, *reinterpret_cast<const uint2*>(as8 + mi * 16 * PB8));
+        if (NV >= 0 || mi < mi_cnt) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            if ((NV >= 0 && ni < NV) || (NV < 0 && ni < ni_cnt))
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bfr[ni], afr, acc[mi][ni], 0, 0, 0);
+        }
+      }
+      return;
+    }
     const float* as = As + buf * BK * LDA + wrow + l15;
     const float* bs = Bs + buf * BK * LDB + wcol + l15;
     const int kq = 4 * q;

@@ -42,6 +42,7 @@ static bool wants_dropout(const Launch& L) {
 // kernel is the correctness net for odd shapes and unaligned operands; a LARGE GEMM landing on it is a performance
 // bug upstream (e.g. a misaligned parameter view), which tests assert against through gh_gemm_path_counters.
 static long long g_path_counts[3] = {0, 0, 0};
+static int g_gemm_mode = 0;       // 0: fp32 MFMA everywhere (default); 1: bf16 MFMA in the big-tile NT/NN GEMMs (gh_set_gemm_mode)
 
 template <int WM, int WN, int NI, int MI = 2>
 static hipError_t launch_cfg(const Launch& L_in, bool tn, hipStream_t s) {
@@ -78,7 +79,10 @@ static hipError_t launch_cfg(const Launch& L_in, bool tn, hipStream_t s) {
   if (!fast && wants_dropout(L)) return hipErrorInvalidValue;     // fused dropout exists in the fast kernel only
   if (fast) {
     if (tn) hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, true, 2>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
-    else hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, false, MI>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
+    else if (g_gemm_mode == 1 && WM == 2 && WN == 2 && NI == 10 && MI == 2) {
+      if constexpr (WM == 2 && WN == 2 && NI == 10 && MI == 2)
+        hipLaunchKernelGGL((gemm_fast_kernel<2, 2, 10, false, 2, true>), dim3(grid), dim3(256), 0, s, L);
+    } else hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, false, MI>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
   } else {
     if (tn) hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, true>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
     else hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, false>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
@@ -620,6 +624,12 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, const in
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }
+  return 0;
+}
+
+extern "C" int gh_set_gemm_mode(int mode) {
+  GH_REQUIRE(mode == 0 || mode == 1, "set_gemm_mode: %d is not 0 (fp32) or 1 (bf16 operands in the big NT/NN GEMMs)", mode);
+  g_gemm_mode = mode;
   return 0;
 }
 

@@ -232,6 +232,40 @@ def test_h768_wide_hidden_vs_oracle(compact):
     assert n_checked >= 40
 
 
+def test_h768_bf16_gemm_mode_tracks_the_fp32_oracle():
+    """BASELINE configs[4] ("h=768 bf16"): with gh_set_gemm_mode(1) the big projections run on bf16 MFMA.  At a batch
+    large enough to take that path the logits must track the fp32 oracle to bf16 accuracy, the attention weights
+    still sum to one, and switching back restores the fp32 result bit for bit."""
+    from get_amd import _lib, ops
+    from get_amd.synth import SynthConfig
+    cfg = SynthConfig(batch=3, n_evd=30, hidden=768, word_heads=8, evd_heads=2, window=5, gsl_rate=0.8, vocab=900,
+                      n_article_src=40, n_claim_src=10)
+    seed = 769
+    model = build_model(cfg, seed)
+    raw = make_raw_batch(cfg, seed)
+    inp = assemble_inputs(raw, cfg, O.convert_text)
+    kargs = to_dev(reference_kargs(inp, torch, output_ranking=True))
+    da, d_ids, d_n = ops.graph_build(torch.from_numpy(raw["evd_tokens"]).to(DEV), torch.from_numpy(raw["evd_len"]).to(DEV), cfg.window)
+    kargs["docs_adj"] = da.with_plan(ops.RaggedPlan(d_n, d_ids, int(d_n.sum().item())))
+    assert 90 * 100 >= 8192                                  # B1 * R rows: the big-tile GEMM configuration is in play
+    q, d = torch.from_numpy(inp["query"]).to(DEV), torch.from_numpy(inp["document"]).to(DEV)
+    with torch.no_grad():
+        phi32, (ww32, _) = model(q, d, **kargs)
+        _lib.set_gemm_mode("bf16")
+        try:
+            _lib.gemm_path_counters(reset=True)
+            phi16, (ww16, ew16) = model(q, d, **kargs)
+        finally:
+            _lib.set_gemm_mode("fp32")
+        phi32b, _ = model(q, d, **kargs)
+    assert torch.equal(phi32, phi32b)
+    diff = float((phi16 - phi32).abs().max())
+    assert 1e-6 < diff <= 5e-2 * max(1.0, float(phi32.abs().max())), diff
+    assert float((ww16 - ww32).abs().max()) <= 2e-2
+    assert torch.allclose(ww16.sum(1), torch.ones_like(ww16.sum(1)), atol=1e-5)
+    assert torch.allclose(ew16.sum(1), torch.ones_like(ew16.sum(1)), atol=1e-5)
+
+
 def test_ragged_realistic_batch_properties():
     """Evidence counts drawn U[1,30] (B1 not a multiple of any tile): weights sum to one, padded slots and
     padded nodes get exactly zero attention, gradients finite, logits equal the oracle on a slice."""

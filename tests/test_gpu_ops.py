@@ -530,3 +530,36 @@ def test_compact_scorer_gsl_and_attention_equal_padded():
     for i, (a, b) in enumerate(zip(res["padded"], res["compact"])):
         scale = float(a.abs().max())
         assert maxerr(a.cpu(), b.cpu()) <= 2e-6 * max(scale, 1.0) + 1e-6 * scale, i
+
+
+# ---------------------------------------------------------------- opt-in bf16 operand mode of the big NT/NN GEMMs
+@pytest.fixture
+def bf16_mode():
+    from get_amd import _lib
+    _lib.set_gemm_mode("bf16")
+    yield
+    _lib.set_gemm_mode("fp32")
+
+
+@pytest.mark.parametrize("m,k,n", [(9000, 300, 300), (8200, 768, 768), (12345, 64, 48)])
+def test_bf16_mode_linear_matches_bf16_rounded_reference(bf16_mode, m, k, n):
+    """gh_set_gemm_mode(1): operands rounded to bf16 (RNE) in LDS, fp32 accumulate.  Against the same rounding done on
+    the host the result must agree to fp32 summation noise; weight gradients stay exact fp32."""
+    from get_amd import ops
+    rng = np.random.default_rng(m)
+    x = T(rng.standard_normal((m, k)).astype(np.float32), grad=True)
+    w = T((rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32), grad=True)
+    b = T(rng.standard_normal((n,)).astype(np.float32), grad=True)
+    g = T(rng.standard_normal((m, n)).astype(np.float32))
+    y = ops.linear(x, w, b)
+    (y * g).sum().backward()
+    r = lambda t: t.detach().bfloat16().float()
+    ref = r(x) @ r(w).t() + b.detach()
+    assert maxerr(y.detach().cpu(), ref.cpu()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    dx_ref = r(g) @ r(w)
+    assert maxerr(x.grad.cpu(), dx_ref.cpu()) <= 2e-5 * max(1.0, float(dx_ref.abs().max()))
+    dw_ref = g.t() @ x.detach()                                  # TN stays fp32
+    assert maxerr(w.grad.cpu(), dw_ref.cpu()) <= 1e-3 * float(dw_ref.abs().max())
+    # and the mode really is different from fp32
+    full = x.detach() @ w.detach().t() + b.detach()
+    assert maxerr(y.detach().cpu(), full.cpu()) > 1e-4

@@ -13,6 +13,8 @@ from get_amd._lib import call, ptr, stream  # noqa: E402
 
 def bench(m, k, n, reps=20, mode="fwd"):
     dev = "cuda:0"
+    if os.environ.get("GEMM_MODE") == "bf16":
+        _lib.set_gemm_mode("bf16")
     x = torch.randn(m, k, device=dev)
     w = torch.randn(n, k, device=dev) / k ** 0.5
     wt = w.t().contiguous()
@@ -42,7 +44,10 @@ def bench(m, k, n, reps=20, mode="fwd"):
     ms = e0.elapsed_time(e1) / reps
     tf = 2.0 * m * k * n / ms / 1e9
     if mode == "fwd":
-        ref = x @ w.t() + b
+        if os.environ.get("GEMM_MODE") == "bf16":       # compare against the same operand rounding
+            ref = x.bfloat16().float() @ w.bfloat16().float().t() + b
+        else:
+            ref = x @ w.t() + b
         err = float((y - ref).abs().max())
     else:
         err = float("nan")
