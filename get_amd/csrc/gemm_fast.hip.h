@@ -16,7 +16,7 @@
 namespace gh {
 
 // Tile = (16*MI*WM) x (16*NI*WN): WM x WN waves, each owning MI x NI MFMA tiles of 16x16.
-// BF (NT/NN mode only): operands are rounded to bf16 when they are staged in LDS and multiplied with
+// BF: operands are rounded to bf16 when they are staged in LDS and multiplied with
 // v_mfma_f32_16x16x16_bf16 (fp32 accumulate, everything outside the tile stays fp32) -- the opt-in path for
 // BASELINE configs[4] ("h=768 bf16 ... MFMA projections"); the default and every parity claim are fp32.
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -30,7 +30,7 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 template <int WM, int WN, int NI, bool TN, int MI = 2, bool BF = false>
 __global__ void __launch_bounds__(WM * WN * 64, 2)
 gemm_fast_kernel(const Launch L_byval) {
-  static_assert(!(BF && TN), "the bf16 variant exists for the NT/NN mode only");
+
   (void)L_byval;
   const GH_KARG Launch& L = *(const GH_KARG Launch*)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int NTHR = WM * WN * 64;
@@ -189,7 +189,22 @@ gemm_fast_kernel(const Launch L_byval) {
   // so they stay in flight under the MFMAs of the current tile
   auto load_tile = [&](int t) __attribute__((always_inline)) {
     const TileAddr a = tile_addr(t);
-    if (TN) {
+    if (TN && BF) {
+      // both operands are k-major ([k][i], [k][j]); a lane needs 4 consecutive k of one column: four coalesced dword
+      // loads per slot (64 lanes = 64 consecutive columns of one k row), clamped addresses, masked when stored
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int idx = tid + j * NTHR;
+        const int kq = min(idx / BM, 3), col = min(m0 + idx % BM, M - 1);
+        const float* ap = A0 + col;
+        float4 v;
+        v.x = ap[(unsigned)min(a.k0 + 4 * kq + 0, a.klim - 1) * (unsigned)lda0];
+        v.y = ap[(unsigned)min(a.k0 + 4 * kq + 1, a.klim - 1) * (unsigned)lda0];
+        v.z = ap[(unsigned)min(a.k0 + 4 * kq + 2, a.klim - 1) * (unsigned)lda0];
+        v.w = ap[(unsigned)min(a.k0 + 4 * kq + 3, a.klim - 1) * (unsigned)lda0];
+        ra[j] = v;
+      }
+    } else if (TN) {
       const rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A0, 0, kend * lda0 * 4, 0x00020000);
       const rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B0, 0, kend * ldb0 * 4, 0x00020000);
 #pragma unroll
@@ -200,6 +215,7 @@ gemm_fast_kernel(const Launch L_byval) {
         rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rB, tb_vo[j], a.k0 * ldb0 * 4, 0));
       return;
     }
+    if (!TN) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int idx = tid + j * NTHR;
@@ -207,6 +223,7 @@ gemm_fast_kernel(const Launch L_byval) {
       if (!TN) off = (a.s1 ? a_off1[j] : a_off0[j]) + (unsigned)min(a.k0 + 4 * (idx & 3), a.klim - 4);
       else off = (unsigned)min(a.k0 + idx / (BM / 4), a.klim - 1) * (unsigned)lda0 + a_off0[j];
       ra[j] = *reinterpret_cast<const float4*>(a.Ab + off);
+    }
     }
     if (BF) {
       // B is k-major in memory but the bf16 MFMA wants 4 consecutive k per lane: four coalesced dword loads (64 lanes
@@ -256,6 +273,15 @@ gemm_fast_kernel(const Launch L_byval) {
             as[(4 * kq + 2) * LDA + row] = v.z;
             as[(4 * kq + 3) * LDA + row] = v.w;
           }
+        } else if (BF) {
+          const int kq = idx / BM, i = idx % BM;
+          const bool iok = m0 + i < M;
+          float4 v = ra[j];
+          v.x = (iok && a.k0 + 4 * kq + 0 < a.klim) ? v.x : 0.f;
+          v.y = (iok && a.k0 + 4 * kq + 1 < a.klim) ? v.y : 0.f;
+          v.z = (iok && a.k0 + 4 * kq + 2 < a.klim) ? v.z : 0.f;
+          v.w = (iok && a.k0 + 4 * kq + 3 < a.klim) ? v.w : 0.f;
+          *reinterpret_cast<uint2*>(As8 + (buf * BM + i) * PB8 + kq * 8) = make_uint2(pack_bf16(v.x, v.y), pack_bf16(v.z, v.w));
         } else {
           const int krow = idx / (BM / 4), c = 4 * (idx % (BM / 4));
           *reinterpret_cast<float4*>(as + krow * LDA + c) = ra[j];       // already zero where out of range

@@ -78,7 +78,10 @@ static hipError_t launch_cfg(const Launch& L_in, bool tn, hipStream_t s) {
   }
   if (!fast && wants_dropout(L)) return hipErrorInvalidValue;     // fused dropout exists in the fast kernel only
   if (fast) {
-    if (tn) hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, true, 2>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
+    if (tn && g_gemm_mode == 1 && WM == 2 && WN == 2 && NI == 10) {
+      if constexpr (WM == 2 && WN == 2 && NI == 10)
+        hipLaunchKernelGGL((gemm_fast_kernel<2, 2, 10, true, 2, true>), dim3(grid), dim3(256), 0, s, L);
+    } else if (tn) hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, true, 2>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
     else if (g_gemm_mode == 1 && WM == 2 && WN == 2 && NI == 10 && MI == 2) {
       if constexpr (WM == 2 && WN == 2 && NI == 10 && MI == 2)
         hipLaunchKernelGGL((gemm_fast_kernel<2, 2, 10, false, 2, true>), dim3(grid), dim3(256), 0, s, L);
@@ -270,7 +273,7 @@ struct Batch {
         need += (size_t)L.ksplit * L.p[i].M * L.p[i].N * sizeof(float);
         if (cs_out[i]) { need += (size_t)L.ksplit * L.p[i].M * sizeof(float); any_cs = true; }
       }
-      if (any_cs && !(ws_ok && need <= g_ws_bytes && fast_ok(L, true))) any_cs = false;   // caller runs the column-sum kernels
+      if (any_cs && !(ws_ok && need <= g_ws_bytes && fast_ok(L, true) && g_gemm_mode == 0)) any_cs = false;   // caller runs the column-sum kernels
       if (ws_ok && need <= g_ws_bytes) {
         ReduceArgs R;
         R.n = L.nprob;

@@ -169,9 +169,9 @@ int gh_concat_att_bwd(const float* left, const float* right, const int32_t* goff
 
 /* ---- GEMM arithmetic mode (process-wide, default 0) ----
  * 0: exact fp32 MFMA everywhere -- the mode every parity claim and the headline benchmark are made in.
- * 1: the big-tile NT/NN GEMMs (cell gates, dX, attention projections: everything with >= 8192 rows) round their
- *    operands to bf16 while staging them in LDS and use v_mfma_f32_16x16x16_bf16 with fp32 accumulation; storage,
- *    epilogues, weight gradients and all small GEMMs stay fp32.  For BASELINE configs[4] ("h=768 bf16"); results then
+ * 1: the big-tile GEMMs (cell gates, dX, attention projections with >= 8192 rows, and the split-K weight gradients)
+ *    round their operands to bf16 while staging them in LDS and use v_mfma_f32_16x16x16_bf16 with fp32 accumulation;
+ *    storage, epilogues, bias gradients and all small GEMMs stay fp32.  For BASELINE configs[4] ("h=768 bf16"); results then
  *    match the fp32 oracle to bf16 accuracy only (~1e-2 relative on logits). */
 int gh_set_gemm_mode(int mode);
 

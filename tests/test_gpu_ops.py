@@ -544,7 +544,7 @@ def bf16_mode():
 @pytest.mark.parametrize("m,k,n", [(9000, 300, 300), (8200, 768, 768), (12345, 64, 48)])
 def test_bf16_mode_linear_matches_bf16_rounded_reference(bf16_mode, m, k, n):
     """gh_set_gemm_mode(1): operands rounded to bf16 (RNE) in LDS, fp32 accumulate.  Against the same rounding done on
-    the host the result must agree to fp32 summation noise; weight gradients stay exact fp32."""
+    the host the result must agree to fp32 summation noise (forward, input gradient and weight gradient)."""
     from get_amd import ops
     rng = np.random.default_rng(m)
     x = T(rng.standard_normal((m, k)).astype(np.float32), grad=True)
@@ -558,8 +558,8 @@ def test_bf16_mode_linear_matches_bf16_rounded_reference(bf16_mode, m, k, n):
     assert maxerr(y.detach().cpu(), ref.cpu()) <= 2e-5 * max(1.0, float(ref.abs().max()))
     dx_ref = r(g) @ r(w)
     assert maxerr(x.grad.cpu(), dx_ref.cpu()) <= 2e-5 * max(1.0, float(dx_ref.abs().max()))
-    dw_ref = g.t() @ x.detach()                                  # TN stays fp32
-    assert maxerr(w.grad.cpu(), dw_ref.cpu()) <= 1e-3 * float(dw_ref.abs().max())
+    dw_ref = r(g).t() @ r(x)                                     # the weight-gradient GEMM rounds its operands too
+    assert maxerr(w.grad.cpu(), dw_ref.cpu()) <= 1e-4 * float(dw_ref.abs().max())
     # and the mode really is different from fp32
     full = x.detach() @ w.detach().t() + b.detach()
     assert maxerr(y.detach().cpu(), full.cpu()) > 1e-4
