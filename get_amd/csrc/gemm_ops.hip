@@ -541,7 +541,7 @@ extern "C" int gh_concat_att_fwd(const float* left, const float* right, const fl
   if (!goff) m_real = b * l;
   GH_REQUIRE(m_real >= 0 && m_real <= b * l, "concat_att_fwd: node-compact rows %d do not fit b*l=%d", m_real, b * l);
   const int M = m_real;
-  const bool one_block = ha <= ((M >= 8192 && big_cfg() == 0) ? GH_BN_BIG : GH_BN_SMALL);
+  const bool one_block = ha <= Batch(false, M, s).bn;      // column block of the tile configuration this launch will use
   GH_REQUIRE(one_block || (ha % 4 == 0 && al16(t) && al16(u) && al16(w2)),
              "concat_att_fwd: attention hidden %d wider than one column block needs float4-shaped rows", ha);
   if (left && xl > 0) {  // u = W1[:, :xl] . left -- once per pair, not per token (two_branches_attention.py:137-140)
