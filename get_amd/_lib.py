@@ -31,7 +31,7 @@ SIGNATURES = {
     "gh_transpose_batch": [_I, _P, _P, _P, _P, _P],
     "gh_ggnn_cell_fwd": [_P] * 5 + [_I, _I] + [_P] * 2 + [_I] * 4 + [_P] * 10 + [_P] * 7 + [_F, _U, _P],
     "gh_ggnn_cell_bwd": [_P] * 5 + [_I] + [_P] * 2 + [_I] * 4 + [_P] * 7 + [_P] * 7 + [_P] * 5 + [_P] * 14 + [_F, _U, _P],
-    "gh_scorer_gsl": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _U, _P],
+    "gh_scorer_gsl": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _U, _P],
     "gh_gsl_topk": [_P, _I, _I, _I, _P, _P],
     "gh_adj_unpack": [_P, _P, _P, _P, _I, _I, _P, _P],
     "gh_concat_att_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],

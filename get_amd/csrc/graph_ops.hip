@@ -463,7 +463,7 @@ __device__ __forceinline__ void topk_keep(const float* ss, int R, int k, uint64_
 __global__ void __launch_bounds__(256)
 scorer_gsl_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
                   const int32_t* __restrict__ goff, const float* __restrict__ feat, const float* __restrict__ w_p,
-                  const float* __restrict__ gate, int R, int H, int k, float* __restrict__ score, uint64_t* __restrict__ keep, unsigned drop_thresh,
+                  const float* __restrict__ gate, int R, int H, int k, int pads_collapsed, float* __restrict__ score, uint64_t* __restrict__ keep, unsigned drop_thresh,
                   float drop_scale, unsigned drop_seed) {
   __shared__ float xs[MAX_R];
   __shared__ float ss[MAX_R];
@@ -474,13 +474,15 @@ scorer_gsl_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ d
   // nodes still compete in the top-k with their own (bias- and dropout-driven) scores, as in wrapper.py:216-219.
   const int row0 = goff ? goff[g] : g * R;
   const int NR = goff ? goff[g + 1] - row0 : R;
-  const int pad0 = goff ? goff[gridDim.x] + g * R - row0 - NR : row0;
+  // pads_collapsed (evaluation mode: no dropout, so every padding row of the batch is the same vector): all padding
+  // nodes read the single representative row goff[n]
+  const int pad0 = goff ? goff[gridDim.x] + (pads_collapsed ? 0 : g * R - row0 - NR) : row0;
   // x_j = feat_j . w_p   (proj, no bias)
   const bool v4 = (H % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat) & 15) == 0) && ((reinterpret_cast<uintptr_t>(w_p) & 15) == 0);
 #pragma unroll 4
   for (int j = wave; j < R; j += 4) {
     float acc = 0.f;
-    const unsigned frow = (unsigned)(j < NR ? row0 + j : pad0 + j);
+    const unsigned frow = (unsigned)(j < NR ? row0 + j : (pads_collapsed ? pad0 : pad0 + j));
     const float* fg = feat + (size_t)frow * H;
     if (v4) {
       const float4* fr = reinterpret_cast<const float4*>(fg);
@@ -599,17 +601,18 @@ extern "C" int gh_spmm(const uint64_t* bits, const float* dinv, const float* val
 }
 
 extern "C" int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const int32_t* goff,
-                             const float* feat, const float* w_p, const float* gate, int n, int r, int h, int k, float* score,
+                             int pads_collapsed, const float* feat, const float* w_p, const float* gate, int n, int r, int h, int k, float* score,
                              uint64_t* keep, float drop_p, uint32_t drop_seed, gh_stream_t stream) {
   GH_REQUIRE(r > 0 && r <= MAX_R, "scorer_gsl: r=%d not in [1,%d]", r, MAX_R);
   GH_REQUIRE(vals || dinv, "scorer_gsl: need dinv or vals");
   if (n <= 0) return 0;
   prof_begin((hipStream_t)stream, PROF_SCORER_GSL);
   GH_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "scorer_gsl: dropout p=%f not in [0,1)", drop_p);
+  GH_REQUIRE(!(pads_collapsed && drop_p > 0.f), "scorer_gsl: collapsed padding rows are an evaluation-mode layout (no dropout)");
   const double th = (double)drop_p * 4294967296.0;
   const unsigned thresh = drop_p > 0.f ? (th >= 4294967295.0 ? 4294967295u : (unsigned)th) : 0u;
   hipLaunchKernelGGL(scorer_gsl_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, bits, dinv, vals, goff, feat,
-                     w_p, gate, r, h, k, score, keep, thresh, 1.0f / (1.0f - drop_p), drop_seed);
+                     w_p, gate, r, h, k, (goff && pads_collapsed) ? 1 : 0, score, keep, thresh, 1.0f / (1.0f - drop_p), drop_seed);
   prof_end(PROF_SCORER_GSL, (double)n * (4.0 * r * h + 8.0 * r * words_for(r) + 8.0 * r + 8.0 * words_for(r)),
            (hipStream_t)stream);
   GH_LAUNCH_CHECK();

@@ -148,13 +148,14 @@ class GGNN_with_GSL(nn.Module):
             srcs += [m.linear.weight, m.linear.bias]
         return ops.derived("gate12", tuple(srcs), lambda: torch.cat([t.detach().reshape(1) for t in srcs]))
 
-    def _refine(self, adj: PackedAdj, feat, plan=None):
+    def _refine(self, adj: PackedAdj, feat, plan=None, collapsed=False):
         s = self.word_scorer1
         drop_p, seed = 0.0, 0
         if hasattr(s, "dropout") and self.training and s.dropout.p > 0:
             drop_p, seed = float(s.dropout.p), ops.new_dropout_seed()   # word_scorer1's own input dropout (wrapper.py:189-190)
         k = int(self.gsl1.rate * adj.r)
-        score, keep = ops.scorer_gsl(adj, feat, s.proj.linear.weight, self._gate12(), k, drop_p, seed, plan=plan)
+        score, keep = ops.scorer_gsl(adj, feat, s.proj.linear.weight, self._gate12(), k, drop_p, seed, plan=plan,
+                                     collapsed=collapsed)
         self.last_score, self.last_keep = score, keep
         return adj.with_keep(keep)
 
@@ -175,9 +176,13 @@ class GGNN_with_GSL(nn.Module):
             self._milestone(feat)
             adj_refined = self._refine(adj, feat)
             return self.feat_prop2(adj_refined, feat)
-        feat = self.feat_prop1.forward_ids(adj, embedding, ids, plan=plan, rows=plan.m_tot)
+        # without dropout (evaluation) every padding row of the batch is the same vector: the first cell then runs on
+        # the real rows plus ONE representative padding row instead of all n*R rows
+        collapsed = not self.training
+        rows = min(plan.m_real + 1, plan.m_tot) if collapsed else plan.m_tot
+        feat = self.feat_prop1.forward_ids(adj, embedding, ids, plan=plan, rows=rows)
         self._milestone(feat)
-        adj_refined = self._refine(adj, feat, plan)
+        adj_refined = self._refine(adj, feat, plan, collapsed)
         return self.feat_prop2(adj_refined, feat, plan=plan, rows=plan.m_real)
 
 

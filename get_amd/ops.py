@@ -376,13 +376,15 @@ def dropout_mask_reference(seed: int, rows: int, cols: int, p: float):
 # --------------------------------------------------------------------------- word scorer + GSL (no gradient)
 @torch.no_grad()
 def scorer_gsl(adj: PackedAdj, feat: torch.Tensor, w_p, gate12: torch.Tensor, k: int, drop_p: float = 0.0,
-               drop_seed: int = 0, plan: "RaggedPlan" = None):
+               drop_seed: int = 0, plan: "RaggedPlan" = None, collapsed: bool = False):
     """GGNN(h->1) score of every node and the top-k keep set (wrapper.py:167-168, :215-219).
     feat: (N,R,H), or node-compact (N*R, H) incl. the padding rows when `plan` is given.
     Returns (score (N,R) fp32, keep (N,W) int64 bit words) -- both in padded node indexing."""
     feat = _f32(feat.detach())
     if plan is not None:
-        assert feat.dim() == 2 and feat.shape[0] == plan.m_tot, "the scorer needs every row (padding nodes compete in top-k)"
+        need = min(plan.m_real + 1, plan.m_tot) if collapsed else plan.m_tot
+        assert feat.dim() == 2 and feat.shape[0] == need, "the scorer needs the padding rows too (they compete in top-k)"
+        assert not (collapsed and drop_p > 0.0), "collapsed padding rows are an evaluation-mode layout"
         n, r, h = plan.n, plan.r, feat.shape[1]
     else:
         n, r, h = feat.shape
@@ -390,7 +392,8 @@ def scorer_gsl(adj: PackedAdj, feat: torch.Tensor, w_p, gate12: torch.Tensor, k:
     keep = torch.empty((n, adj.words), device=feat.device, dtype=torch.int64)
     w_p = _f32(w_p.detach().reshape(-1))
     gate12 = _f32(gate12.detach())
-    call("gh_scorer_gsl", ptr(adj.bits), ptr(adj.dinv), ptr(adj.vals), _plan_args(plan)[0], ptr(feat), ptr(w_p), ptr(gate12), n, r, h,
+    call("gh_scorer_gsl", ptr(adj.bits), ptr(adj.dinv), ptr(adj.vals), _plan_args(plan)[0], 1 if (collapsed and plan is not None) else 0,
+         ptr(feat), ptr(w_p), ptr(gate12), n, r, h,
          int(k), ptr(score), ptr(keep), float(drop_p), int(drop_seed), stream())
     return score, keep
 

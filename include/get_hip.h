@@ -135,9 +135,11 @@ int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const float* vals,
  * wh0,bh0,wh1,bh1} (the six 1x1 linears).  k = int(rate * r) computed by the caller.
  * Out: score[n][r], keep[n][W] (bit i set <=> node i among the k best; ties -> lower index).
  * drop_p/drop_seed: the scorer cell's own input dropout in training mode (same stateless mask as above).
- * goff != NULL: feat is node-compact [n*r][h] INCLUDING the padding rows (they compete in the top-k). */
-int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const int32_t* goff, const float* feat,
-                  const float* w_p, const float* gate, int n, int r, int h, int k,
+ * goff != NULL: feat is node-compact [n*r][h] INCLUDING the padding rows (they compete in the top-k).
+ * pads_collapsed (with goff, drop_p == 0 only): without dropout all padding rows of a batch are identical, so feat
+ * holds just ONE of them, at row goff[n] (feat is [goff[n] + 1][h]); every padding node scores with that row. */
+int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const int32_t* goff, int pads_collapsed,
+                  const float* feat, const float* w_p, const float* gate, int n, int r, int h, int k,
                   float* score, uint64_t* keep, float drop_p, uint32_t drop_seed, gh_stream_t stream);
 /* GSL alone on given scores (GSL.forward on arbitrary score input). */
 int gh_gsl_topk(const float* score, int n, int r, int k, uint64_t* keep, gh_stream_t stream);
