@@ -52,7 +52,7 @@ extern "C" {
 
 typedef void* gh_stream_t;
 
-#define GH_ABI_VERSION 2
+#define GH_ABI_VERSION 3
 
 int gh_abi_version(void);
 /* Thread-local message of the last failing call on this thread (never NULL). */
