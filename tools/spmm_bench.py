@@ -37,7 +37,7 @@ for name, toks in (("zipf", make_tokens(rng, n, r, 20000, r, r)[0]),
     adj, _, _ = ops.graph_build(torch.from_numpy(toks).to(dev), torch.from_numpy(lens).to(dev), 3)
     nnz = float(torch.count_nonzero(adj.to_dense())) / n
     deg = adj.to_dense().ne(0).sum(-1).max().item()
-    ms = timeit(lambda: _lib.call("gh_spmm", *adj._args(), x.data_ptr(), y.data_ptr(), n, r, h, 0, 0, _lib.stream()))
+    ms = timeit(lambda: _lib.call("gh_spmm", *adj._args(), None, 0, x.data_ptr(), y.data_ptr(), n, r, h, 0, 0, _lib.stream()))
     print(f"{name:9s} nnz/graph {nnz:7.1f} max degree {deg:3d}: {ms*1e3:7.1f} us  {2*n*r*h*4/ms/1e6:7.1f} GB/s")
 ms = timeit(lambda: y.copy_(x))
 print(f"copy      {ms*1e3:7.1f} us  {2*n*r*h*4/ms/1e6:7.1f} GB/s")
