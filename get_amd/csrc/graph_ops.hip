@@ -360,8 +360,10 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   const int V = v4 ? 4 : 1;
   const int hv = h / V;
   // slab: <= 32 float4 (or 128 scalars) per row, as even as possible
-  // (sized so that a workgroup's slab stays under ~48 KB of LDS: three workgroups per CU also at R = 200)
-  const int lds_cap = (48 * 1024) / (r * (v4 ? 16 : 4));
+  // (sized so that a workgroup's slab stays under ~32 KB of LDS: four to five workgroups per CU, also at R = 200)
+  static int cap_kb = -1;
+  if (cap_kb < 0) { const char* e = getenv("GH_SPMM_SLAB_KB"); cap_kb = e ? atoi(e) : 32; }   // measured per step: 48 KB -> 0.314 ms, 32 -> 0.288, 24 -> 0.294, 16 -> 0.344 (R = 100); R = 200: 0.60 -> 0.43
+  const int lds_cap = (cap_kb * 1024) / (r * (v4 ? 16 : 4));
   const int slab_max = v4 ? (lds_cap < 32 ? (lds_cap < 4 ? 4 : lds_cap) : 32) : (lds_cap < 128 ? (lds_cap < 16 ? 16 : lds_cap) : 128);
   const int nslab = (hv + slab_max - 1) / slab_max;
   const int slab = (hv + nslab - 1) / nslab;
