@@ -49,6 +49,7 @@ class FlatTrainer:
         late_prefixes = tuple(late_prefixes)
         live = [x for x in live if not x[0].startswith(late_prefixes)] + [x for x in live if x[0].startswith(late_prefixes)]
         self._early_work = None
+        self._overlap_ok = True
         self.live_names: List[str] = [n for n, _ in live]
         self.params = [p for _, p in live]
         # every parameter starts on a 256-byte boundary of the flat buffers: the kernels take weights and gradients
@@ -107,8 +108,15 @@ class FlatTrainer:
     def allreduce_early_async(self):
         """Start the all-reduce of the early-final part of the bucket (call it once those gradients are complete in
         stream order, e.g. from the hook ``attach_overlap`` installs).  No-op for a single rank or when already started."""
-        if self.world > 1 and self._early_work is None and 0 < self.n_early < self.numel:
-            self._early_work = dist.all_reduce(self.flat_g[:self.n_early], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.world > 1 and self._early_work is None and 0 < self.n_early < self.numel and self._overlap_ok:
+            try:
+                self._early_work = dist.all_reduce(self.flat_g[:self.n_early], op=dist.ReduceOp.SUM, group=self.group,
+                                                   async_op=True)
+            except Exception as e:      # a backend without async collectives: keep training with the single all-reduce
+                self._overlap_ok = False
+                self._early_work = None
+                import warnings
+                warnings.warn(f"get_amd: overlapped all-reduce disabled ({e!r}); falling back to one all-reduce per step")
 
     def allreduce(self):
         """All-reduce(sum) of the gradient bucket (RCCL over xGMI on GPUs, gloo in CPU tests): the whole bucket in one
