@@ -128,6 +128,14 @@ gemm_fast_kernel(const Launch L_byval) {
   typedef __amdgpu_buffer_rsrc_t rsrc_t;
   constexpr unsigned OOB = 0x80000000u;
   unsigned ta_vo[NA], tb_vo[NB];
+  if (!TN && !BF) {          // NT B operand through a per-tile descriptor (both K segments share ldb -- host-checked)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int idx = tid + j * NTHR;
+      const int c = 4 * (idx % (BN / 4));
+      tb_vo[j] = ((idx < B4) && (c < N)) ? ((unsigned)(idx / (BN / 4)) * (unsigned)ldb0 + (unsigned)c) * 4u : OOB;
+    }
+  }
   if (TN) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
@@ -177,11 +185,15 @@ gemm_fast_kernel(const Launch L_byval) {
     TileAddr a;
     t += toff;
     a.s1 = (!TN) && (t >= nt0);
-    a.Ab = a.s1 ? A1 : A0;
-    a.Bb = a.s1 ? B1 : B0;
-    a.ldb = a.s1 ? ldb1 : ldb0;
+    // blended with bit operations on purpose: with plain selects the compiler parks the two candidates in a scratch
+    // array and indexes it inside the loop
+    const unsigned long long m64 = 0ull - (unsigned long long)(a.s1 ? 1 : 0);
+    const unsigned m32 = (unsigned)m64;
+    a.Ab = (const float*)((unsigned long long)A0 ^ (((unsigned long long)A0 ^ (unsigned long long)A1) & m64));
+    a.Bb = (const float*)((unsigned long long)B0 ^ (((unsigned long long)B0 ^ (unsigned long long)B1) & m64));
+    a.ldb = (int)((unsigned)ldb0 ^ (((unsigned)ldb0 ^ (unsigned)ldb1) & m32));
     a.k0 = a.s1 ? (t - nt0) * BK : kbeg + t * BK;
-    a.klim = a.s1 ? K1 : kend;
+    a.klim = (int)((unsigned)kend ^ (((unsigned)kend ^ (unsigned)K1) & m32));
     return a;
   };
 
@@ -242,11 +254,12 @@ gemm_fast_kernel(const Launch L_byval) {
       }
       return;
     }
+    {
+      const rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.Bb, 0, a.klim * ldb0 * 4, 0x00020000);
+      const int so = a.k0 * ldb0 * 4;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int idx = tid + j * NTHR;
-      const unsigned off = (unsigned)min(a.k0 + idx / (BN / 4), a.klim - 1) * (unsigned)a.ldb + b_col[j];
-      rb[j] = *reinterpret_cast<const float4*>(a.Bb + off);
+      for (int j = 0; j < NB; ++j)
+        rb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rB, tb_vo[j], so, 0));
     }
   };
 
@@ -311,7 +324,7 @@ gemm_fast_kernel(const Launch L_byval) {
       const int idx = tid + j * NTHR;
       if (idx < B4) {
         const int krow = idx / (BN / 4), c = 4 * (idx % (BN / 4));
-        const bool ok = TN || (b_ok[j] && (a.k0 + krow < a.klim));
+        const bool ok = true;            // out-of-range rows / columns were zero-filled by the buffer range check
         const float4 v = ok ? rb[j] : zero4;
         *reinterpret_cast<float4*>(bs + krow * LDB + c) = v;
       }

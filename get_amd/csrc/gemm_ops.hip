@@ -20,6 +20,11 @@ static bool fast_ok(const Launch& L, bool tn) {
       if (!s.vecA || !s.vecB || s.gatherB || s.K < 4) return false;
       if (tn && s.gatherA) return false;
     }
+    if (!tn) {  // the B operand is addressed through a buffer descriptor: one ldb for both K segments, 31-bit byte offsets
+      if (p.nseg > 1 && p.seg[0].ldb != p.seg[1].ldb) return false;
+      for (int j = 0; j < p.nseg; ++j)
+        if (4.0 * (double)p.seg[j].ldb * (double)p.seg[j].K >= 2147483648.0) return false;
+    }
     if (tn) {   // TN mode addresses its operands through buffer descriptors: 31-bit byte offsets
       const Seg& s = p.seg[0];
       if (4.0 * (double)s.lda * (double)s.K >= 2147483648.0 || 4.0 * (double)s.ldb * (double)s.K >= 2147483648.0) return false;
