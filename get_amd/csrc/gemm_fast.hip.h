@@ -109,8 +109,8 @@ gemm_fast_kernel(const Launch L_byval) {
       int s0 = gmc, s1 = gmc;
       if (P.seg[0].gatherA) s0 = P.seg[0].gatherA[gmc];          // embedding row id, read once per row
       if (nseg > 1 && P.seg[1].gatherA) s1 = P.seg[1].gatherA[gmc];
-      a_off0[j] = (unsigned)s0 * (unsigned)lda0;
-      a_off1[j] = (unsigned)s1 * (unsigned)lda1;
+      a_off0[j] = a_ok[j] ? (unsigned)s0 * (unsigned)lda0 * 4u : 0x80000000u;      // BYTE offsets; invalid rows read zeros
+      a_off1[j] = a_ok[j] ? (unsigned)s1 * (unsigned)lda1 * 4u : 0x80000000u;
     } else {
       const int c = m0 + 4 * (idx % (BM / 4));
       a_ok[j] = (idx < A4) && (c < M);
@@ -231,10 +231,13 @@ gemm_fast_kernel(const Launch L_byval) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int idx = tid + j * NTHR;
-      unsigned off;
-      if (!TN) off = (a.s1 ? a_off1[j] : a_off0[j]) + (unsigned)min(a.k0 + 4 * (idx & 3), a.klim - 4);
-      else off = (unsigned)min(a.k0 + idx / (BM / 4), a.klim - 1) * (unsigned)lda0 + a_off0[j];
-      ra[j] = *reinterpret_cast<const float4*>(a.Ab + off);
+      // rows may be gathered (embedding table), so the record count is generous; invalid rows carry the OOB marker,
+      // the k tail is clamped here and masked when stored
+      const rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.Ab, 0, (int)0x7fffffff, 0x00020000);
+      const unsigned m32a = 0u - (unsigned)(a.s1 ? 1 : 0);
+      const unsigned rowoff = a_off0[j] ^ ((a_off0[j] ^ a_off1[j]) & m32a);
+      const unsigned vo = rowoff + 4u * (unsigned)min(a.k0 + 4 * (idx & 3), a.klim - 4);
+      ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, vo, 0, 0));
     }
     }
     if (BF) {
@@ -274,7 +277,7 @@ gemm_fast_kernel(const Launch L_byval) {
       if (idx < A4) {
         if (!TN) {
           const int row = idx >> 2, kq = idx & 3;
-          const bool ok = a_ok[j] && (a.k0 + 4 * kq < a.klim);
+          const bool ok = a.k0 + 4 * kq < a.klim;          // invalid rows already came back as zeros
           float4 v = ok ? ra[j] : zero4;
           if (drop_mode == 1 && !a.s1)
             v = drop4(v, drop_seed, (unsigned)(m0 + row) * (unsigned)drop_ld + (unsigned)(a.k0 + 4 * kq), drop_thresh, drop_scale);

@@ -22,8 +22,10 @@ static bool fast_ok(const Launch& L, bool tn) {
     }
     if (!tn) {  // the B operand is addressed through a buffer descriptor: one ldb for both K segments, 31-bit byte offsets
       if (p.nseg > 1 && p.seg[0].ldb != p.seg[1].ldb) return false;
-      for (int j = 0; j < p.nseg; ++j)
+      for (int j = 0; j < p.nseg; ++j) {
         if (4.0 * (double)p.seg[j].ldb * (double)p.seg[j].K >= 2147483648.0) return false;
+        if (!p.seg[j].gatherA && 4.0 * (double)p.seg[j].lda * (double)p.M >= 2147483648.0) return false;   // (gathered tables: < 2 GB by contract)
+      }
     }
     if (tn) {   // TN mode addresses its operands through buffer descriptors: 31-bit byte offsets
       const Seg& s = p.seg[0];
