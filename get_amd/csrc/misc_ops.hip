@@ -380,13 +380,14 @@ att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict_
                        const int32_t* __restrict__ goff, int Lmax, int Dr, int C,
                        float* __restrict__ de, float* __restrict__ dright) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-  float* ga = reinterpret_cast<float*>(dsm);   // [Dr][C]
+  float* ga = reinterpret_cast<float*>(dsm);   // [C][Dr]: head-major, so a lane's four g values are one 16-byte read and
+                                               // consecutive lanes hit consecutive banks ([Dr][C] was an 8-way conflict)
   float* ws = ga + (size_t)Dr * C;             // [Lmax][C]
   float* dw = ws + (size_t)Lmax * C;           // [Lmax][C]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = goff ? goff[b] : b * Lmax;
   const int L = goff ? goff[b + 1] - row0 : Lmax;
-  for (int i = tid; i < Dr * C; i += 256) ga[i] = g_att[(size_t)b * Dr * C + i];
+  for (int i = tid; i < Dr * C; i += 256) ga[(i % C) * Dr + i / C] = g_att[(size_t)b * Dr * C + i];
   for (int i = tid; i < L * C; i += 256) ws[i] = weights[(size_t)row0 * C + i];
   __syncthreads();
   const int D4 = Dr / 4;
@@ -400,11 +401,11 @@ att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict_
     for (int d4 = lane; d4 < D4; d4 += 64) {
       const float4 rv = rr[d4];
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float* g4 = ga + (size_t)d4 * 4 * C;
 #pragma unroll
       for (int c = 0; c < 8; ++c)
         if (c < C) {
-          const float g0 = g4[c], g1 = g4[C + c], g2 = g4[2 * C + c], g3 = g4[3 * C + c];
+          const float4 gq = reinterpret_cast<const float4*>(ga + (size_t)c * Dr)[d4];
+          const float g0 = gq.x, g1 = gq.y, g2 = gq.z, g3 = gq.w;
           acc.x += wl[c] * g0; acc.y += wl[c] * g1; acc.z += wl[c] * g2; acc.w += wl[c] * g3;
           part[c] += rv.x * g0 + rv.y * g1 + rv.z * g2 + rv.w * g3;
         }
