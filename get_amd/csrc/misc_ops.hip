@@ -391,31 +391,47 @@ att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict_
   for (int i = tid; i < L * C; i += 256) ws[i] = weights[(size_t)row0 * C + i];
   __syncthreads();
   const int D4 = Dr / 4;
-#pragma unroll 2
-  for (int l = wave; l < L; l += 4) {
-    float part[8], wl[8];
+  // two rows per wave in flight: both rows' loads are issued before either is consumed (a wave walks ~16 rows
+  // one after the other, so the kernel is bound by the memory latency per row, not by bandwidth)
+  for (int l = wave; l < L; l += 8) {
+    const int lb = l + 4;
+    const bool has_b = lb < L;
+    const int lbc = has_b ? lb : l;
+    float pa[8], pb[8], wa[8], wb[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { part[c] = 0.f; wl[c] = (c < C) ? ws[l * C + c] : 0.f; }
-    const float4* rr = reinterpret_cast<const float4*>(right + ((size_t)row0 + l) * Dr);
-    float4* dr_ = reinterpret_cast<float4*>(dright + ((size_t)row0 + l) * Dr);
+    for (int c = 0; c < 8; ++c) {
+      pa[c] = 0.f; pb[c] = 0.f;
+      wa[c] = (c < C) ? ws[l * C + c] : 0.f;
+      wb[c] = (c < C) ? ws[lbc * C + c] : 0.f;
+    }
+    const float4* ra_ = reinterpret_cast<const float4*>(right + ((size_t)row0 + l) * Dr);
+    const float4* rb_ = reinterpret_cast<const float4*>(right + ((size_t)row0 + lbc) * Dr);
+    float4* da_ = reinterpret_cast<float4*>(dright + ((size_t)row0 + l) * Dr);
+    float4* db_ = reinterpret_cast<float4*>(dright + ((size_t)row0 + lbc) * Dr);
     for (int d4 = lane; d4 < D4; d4 += 64) {
-      const float4 rv = rr[d4];
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 rva = ra_[d4];
+      const float4 rvb = rb_[d4];
+      float4 aa = make_float4(0.f, 0.f, 0.f, 0.f), ab = aa;
 #pragma unroll
       for (int c = 0; c < 8; ++c)
         if (c < C) {
           const float4 gq = reinterpret_cast<const float4*>(ga + (size_t)c * Dr)[d4];
-          const float g0 = gq.x, g1 = gq.y, g2 = gq.z, g3 = gq.w;
-          acc.x += wl[c] * g0; acc.y += wl[c] * g1; acc.z += wl[c] * g2; acc.w += wl[c] * g3;
-          part[c] += rv.x * g0 + rv.y * g1 + rv.z * g2 + rv.w * g3;
+          aa.x += wa[c] * gq.x; aa.y += wa[c] * gq.y; aa.z += wa[c] * gq.z; aa.w += wa[c] * gq.w;
+          ab.x += wb[c] * gq.x; ab.y += wb[c] * gq.y; ab.z += wb[c] * gq.z; ab.w += wb[c] * gq.w;
+          pa[c] += rva.x * gq.x + rva.y * gq.y + rva.z * gq.z + rva.w * gq.w;
+          pb[c] += rvb.x * gq.x + rvb.y * gq.y + rvb.z * gq.z + rvb.w * gq.w;
         }
-      dr_[d4] = acc;
+      da_[d4] = aa;
+      if (has_b) db_[d4] = ab;
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      float v = part[c];
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-      if (lane == 0 && c < C) dw[l * C + c] = v + (g_w ? g_w[((size_t)row0 + l) * C + c] : 0.f);
+      float va = pa[c], vb = pb[c];
+      for (int o = 32; o > 0; o >>= 1) { va += __shfl_xor(va, o); vb += __shfl_xor(vb, o); }
+      if (lane == 0 && c < C) {
+        dw[l * C + c] = va + (g_w ? g_w[((size_t)row0 + l) * C + c] : 0.f);
+        if (has_b) dw[lb * C + c] = vb + (g_w ? g_w[((size_t)row0 + lb) * C + c] : 0.f);
+      }
     }
   }
   __syncthreads();
