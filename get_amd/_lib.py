@@ -11,14 +11,15 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libget_hip.so")
+# GET_AMD_LIB: load another build of the same ABI instead (A/B runs of kernel variants on one box)
+LIB_PATH = os.environ.get("GET_AMD_LIB") or os.path.join(_HERE, "lib", "libget_hip.so")
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
 _L = ctypes.c_int64
 _U = ctypes.c_uint32
-ABI_VERSION = 3          # GH_ABI_VERSION of include/get_hip.h
+ABI_VERSION = 4          # GH_ABI_VERSION of include/get_hip.h
 
 # name -> argtypes (mirrors include/get_hip.h; tests/test_abi.py checks the two agree)
 SIGNATURES = {
@@ -29,9 +30,9 @@ SIGNATURES = {
     "gh_spmm": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "gh_transpose": [_P, _P, _I, _I, _P],
     "gh_transpose_batch": [_I, _P, _P, _P, _P, _P],
-    "gh_ggnn_cell_fwd": [_P] * 5 + [_I, _I] + [_P] * 2 + [_I] * 4 + [_P] * 10 + [_P] * 7 + [_F, _U, _P],
+    "gh_ggnn_cell_fwd": [_P] * 5 + [_I, _I] + [_P] * 2 + [_I] * 4 + [_P] * 10 + [_P] * 7 + [_F, _U, _P, _P, _F, _U, _P],
     "gh_ggnn_cell_bwd": [_P] * 5 + [_I] + [_P] * 2 + [_I] * 4 + [_P] * 7 + [_P] * 7 + [_P] * 5 + [_P] * 14 + [_F, _U, _P],
-    "gh_scorer_gsl": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _U, _P],
+    "gh_scorer_gsl": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _U, _P],
     "gh_gsl_topk": [_P, _I, _I, _I, _P, _P],
     "gh_adj_unpack": [_P, _P, _P, _P, _I, _I, _P, _P],
     "gh_concat_att_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -1,9 +1,11 @@
 // Grouped fp32 MFMA GEMM for gfx950 (v_mfma_f32_16x16x4_f32: exact fp32, 64 FLOP/clk/SIMD).
 //
 // One launch runs up to GH_MAX_PROBLEMS problems that share their row space, each
-//     C_p[M][N_p] = epilogue_p( sum_seg  A_seg[M][K_seg] . B_seg[K_seg][N_p] )
-// with up to two K-segments (so [a | x] . [W0 | W1]^T needs no concatenated copy) and B always
-// k-major (weights are pre-transposed once per step).  TN mode (weight gradients) computes
+//     C_p[M][N_p] = epilogue_p( sum_seg  A_seg[M][K_seg] . B_seg[N_p][K_seg]^T )
+// with up to two K-segments (so [a | x] . [W0 | W1]^T needs no concatenated copy); NT mode takes B as
+// [N][ldb] (the weight as PyTorch stores it; dX products take the cached transpose).  This file is the generic,
+// scalar-guarded kernel (odd shapes, unaligned operands); the fast paths are gemm_nt.hip.h (NT) and
+// gemm_fast.hip.h (TN).  TN mode (weight gradients) computes
 //     C_p[I][J] += sum_m A[m][I]^T B[m][J]          (split over m, fp32 atomics).
 //
 // Tiling: workgroup = WM x WN waves, wave tile = 32 x (16*NI), K tile = 16.
@@ -70,6 +72,7 @@ struct Launch {
   int m_tiles;   // max over problems of ceil(M / BM)
   int ksplit;    // TN: number of K chunks (1 otherwise)
   int kchunk;    // TN: rows per chunk, multiple of 16
+  int dbg;       // measurement only (GH_DBG): bit 0 = skip the epilogue, bit 1 = skip the K loop
 };
 
 __host__ __device__ __forceinline__ unsigned drop_hash(unsigned seed, unsigned idx) {
@@ -196,10 +199,18 @@ gemm_kernel(const Launch L_byval) {
       if (idx < B4) {
         const int krow = idx / (BN / 4), n = 4 * (idx % (BN / 4)), gk = k0 + krow;
         if (gk < klim && n < N) {
-          const int srow = S.gatherB ? S.gatherB[gk] : gk;
-          const float* p = S.B + (size_t)srow * S.ldb + n;
-          if (S.vecB) v = *reinterpret_cast<const float4*>(p);
-          else { v.x = p[0]; if (n + 1 < N) v.y = p[1]; if (n + 2 < N) v.z = p[2]; if (n + 3 < N) v.w = p[3]; }
+          if (!TN) {        // NT: B is [N][ldb], contraction-contiguous (the weight as stored); element (k, n) = B[n][k]
+            const float* p = S.B + (size_t)n * S.ldb + gk;
+            v.x = p[0];
+            if (n + 1 < N) v.y = p[(size_t)S.ldb];
+            if (n + 2 < N) v.z = p[2 * (size_t)S.ldb];
+            if (n + 3 < N) v.w = p[3 * (size_t)S.ldb];
+          } else {
+            const int srow = S.gatherB ? S.gatherB[gk] : gk;
+            const float* p = S.B + (size_t)srow * S.ldb + n;
+            if (S.vecB) v = *reinterpret_cast<const float4*>(p);
+            else { v.x = p[0]; if (n + 1 < N) v.y = p[1]; if (n + 2 < N) v.z = p[2]; if (n + 3 < N) v.w = p[3]; }
+          }
         }
       }
       rb[j] = v;
@@ -393,6 +404,14 @@ inline Seg make_seg(const float* A, int lda, const float* B, int ldb, int K, int
   s.K = K;
   return s;
 }
+// NT: A [M][lda] (rows optionally gathered), B [N][ldb]; both rows hold the K contraction values contiguously
+inline Seg make_seg_nt(const float* A, int lda, const float* B, int ldb, int K, const int32_t* gatherA = nullptr) {
+  Seg s;
+  s.A = A; s.lda = lda; s.gatherA = gatherA; s.vecA = vec_ok(A, lda, K);
+  s.B = B; s.ldb = ldb; s.gatherB = nullptr; s.vecB = vec_ok(B, ldb, K);
+  s.K = K;
+  return s;
+}
 inline Seg make_seg_tn(const float* A, int lda, int I, const float* B, int ldb, int J, int K,
                        const int32_t* gatherA = nullptr, const int32_t* gatherB = nullptr) {
   Seg s;
@@ -409,9 +428,6 @@ inline Problem make_problem(int M, int N, int epi, float* C, int ldc) {
   return p;
 }
 
-// max N of one column block per configuration
-constexpr int GH_BN_BIG = 304;    // (4,1,19)
-constexpr int GH_BN_SMALL = 320;  // (1,4,5)
 
 hipError_t launch_gemm(Launch& L, bool tn, hipStream_t stream);
 

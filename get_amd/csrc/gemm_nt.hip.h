@@ -1,0 +1,388 @@
+// Grouped fp32 MFMA GEMM, "NT" form, for gfx950:   C_p[M][N_p] = epilogue_p( sum_seg A_seg[M][K_seg] . B_seg[N_p][K_seg]^T )
+// Same problem descriptors as gemm.hip.h; BOTH operands are contraction-contiguous (A row-major activations,
+// B = the weight as PyTorch stores it, [n_out][n_in]; the backward's dX = G.W takes the cached transpose).
+//
+// Preconditions (checked by the host, otherwise the generic kernel in gemm.hip.h runs): every operand row 16-byte
+// aligned, K a multiple of 4, byte offsets below 2^31.
+//
+// Design (measured against the register-staged 64x320 kernel it replaces, tools/glds_proto.hip):
+//   * operands go HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass, no
+//     address VALU -- a K tile costs a wave 6 DMA instructions + a dozen SALU;
+//   * LDS image per operand is [row][16 k]: 64-byte rows of four 16-byte chunks, chunk slot XOR-swizzled with
+//     {0,2,3,1}[(row>>2)&3] so that a ds_read_b128 of 16 rows x 4 k-quads is bank-conflict free.  The DMA writes
+//     LDS linearly (wave base + lane*16), so the swizzle is applied on the SOURCE side: lane L fetches the chunk
+//     that belongs at linear position L;
+//   * one ds_read_b128 = the fragment of ALL four k-steps of the K tile for one 16-row MFMA tile (k = 4q + s is
+//     lane q's element for step s), i.e. 12 LDS reads per K tile and wave instead of 48;
+//   * fragments are software-pipelined across the per-tile barrier: the last half of tile t-1's MFMAs is issued
+//     after the barrier, underneath the LDS reads of tile t;
+//   * epilogues run on whole rows: the accumulator tile is staged through LDS (two passes of 16 rows per wave row)
+//     and every epilogue stream (gate inputs, outputs) is read/written as contiguous runs of a row -- fragment-shaped
+//     epilogue accesses (16 rows x 64 B per instruction) ran the same streams at 3.8 TB/s, whole rows at 6.7 TB/s;
+//     row reductions (attention head scores, the GSL scorer's projection) re-read the finished rows from LDS.
+#pragma once
+#include "gemm.hip.h"
+
+namespace gh {
+
+__device__ __forceinline__ int nt_swz(int j) { return (0x78 >> (2 * j)) & 3; }     // {0,2,3,1}
+
+template <int WM, int WN, int NI, int MI = 2>
+__global__ void __launch_bounds__(WM * WN * 64, 3)
+gemm_nt_kernel(const Launch L_byval) {
+  (void)L_byval;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const GH_KARG Launch& L = *(const GH_KARG Launch*)__builtin_amdgcn_kernarg_segment_ptr();
+  typedef __amdgpu_buffer_rsrc_t rsrc_t;
+  constexpr int NW = WM * WN, NTHR = NW * 64;
+  constexpr int BM = 16 * MI * WM, BN = 16 * NI * WN, BK = 16;
+  constexpr int NAI = BM / 16, NBI = BN / 16;                      // DMA instructions per K tile (1 KiB each)
+  constexpr int SA = (NAI + NW - 1) / NW, SB = (NBI + NW - 1) / NW; // ... per wave
+  constexpr int STAGE = (BM + BN) * 64;
+  constexpr int EP_PITCH = BN + 4;                                 // floats: 16-byte rows, 8 consecutive rows cover all banks
+  constexpr int EP_BYTES = 16 * WM * EP_PITCH * 4 + NW * 64 * 16;  // staged rows + row-reduction partials
+  constexpr int SMEM = 2 * STAGE > EP_BYTES ? 2 * STAGE : EP_BYTES;
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int NH = NI / 2;                                       // B fragment batches: X = tiles [0,NH), Y = [NH,NI)
+  static_assert(MI == 2, "two 16-row tiles per wave");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+
+  // ---- XCD-aware work decode (as gemm.hip.h): the problems of one row tile run back to back on one XCD
+  const int n_inner = L.nprob * L.ksplit;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int m_tile = xcd + 8 * (slot / n_inner);
+  const int inner = slot % n_inner;
+  if (m_tile >= L.m_tiles) return;
+  const int prob = inner % L.nprob;
+  const int ks = inner / L.nprob;
+  const bool split = L.ksplit > 1;
+  const GH_KARG Problem& P = L.p[prob];
+  const int M = P.M, N = P.N;
+  const int m0 = m_tile * BM;
+  if (m0 >= M) return;
+
+  // measurement switches: static wave priority per workgroup class, so that co-resident workgroups drift out of phase
+  if (L.dbg & 4) {
+    const int cls = ((bid >> 3) >> 5) % 3;
+    if (cls == 0) __builtin_amdgcn_s_setprio(2); else if (cls == 1) __builtin_amdgcn_s_setprio(1);
+  } else if (L.dbg & 8) {
+    const int cls = (bid >> 3) % 3;
+    if (cls == 0) __builtin_amdgcn_s_setprio(2); else if (cls == 1) __builtin_amdgcn_s_setprio(1);
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int wrow = wm * 16 * MI, wcol = wn * 16 * NI;
+  const int l15 = lane & 15, q = lane >> 4;
+
+  const int nseg = P.nseg;
+  const float* A0 = P.seg[0].A; const float* B0 = P.seg[0].B;
+  const int lda0 = P.seg[0].lda, ldb0 = P.seg[0].ldb, K0 = P.seg[0].K;
+  const float* A1 = nseg > 1 ? P.seg[1].A : A0; const float* B1 = nseg > 1 ? P.seg[1].B : B0;
+  const int lda1 = nseg > 1 ? P.seg[1].lda : lda0, ldb1 = nseg > 1 ? P.seg[1].ldb : ldb0;
+  const int K1 = nseg > 1 ? P.seg[1].K : 0;
+  int kbeg = 0, kend = K0;
+  if (split) {
+    kbeg = ks * L.kchunk;
+    kend = min(K0, kbeg + L.kchunk);
+    if (kbeg >= kend) return;
+  }
+  const int nt0 = (kend - kbeg + BK - 1) / BK;
+  // row tiles entirely at or beyond seg0_rows have an all-zero segment-0 operand (the aggregation of padding nodes in
+  // the node-compact layout): start at the first tile of segment 1
+  const int toff = (nseg > 1 && P.seg0_rows > 0 && m0 >= P.seg0_rows) ? nt0 : 0;
+  const int T = (L.dbg & 2) ? 1 : nt0 + (nseg > 1 ? (K1 + BK - 1) / BK : 0) - toff;
+
+  // ---- DMA slots of this wave: lane L of instruction i fills linear chunk 64 i + L = (row 16 i + L/4, slot L%4)
+  const int drow = lane >> 2;
+  const int dkq = (lane & 3) ^ nt_swz((lane >> 4) & 3);          // logical k-quad stored at this lane's slot
+  unsigned a_vo0[SA], a_vo1[SA], b_vo0[SB], b_vo1[SB];
+#pragma unroll
+  for (int j = 0; j < SA; ++j) {
+    const int ia = wave + NW * j;
+    const int gm = m0 + 16 * ia + drow;
+    const bool ok = (NW * (j + 1) <= NAI || ia < NAI) && gm < M;
+    const int gmc = min(gm, M - 1);
+    int s0 = gmc, s1 = gmc;
+    if (P.seg[0].gatherA) s0 = P.seg[0].gatherA[gmc];              // embedding row id, read once per row
+    if (nseg > 1 && P.seg[1].gatherA) s1 = P.seg[1].gatherA[gmc];
+    a_vo0[j] = ok ? (unsigned)s0 * (unsigned)lda0 * 4u + (unsigned)dkq * 16u : OOB;
+    a_vo1[j] = ok ? (unsigned)s1 * (unsigned)lda1 * 4u + (unsigned)dkq * 16u : OOB;
+  }
+#pragma unroll
+  for (int j = 0; j < SB; ++j) {
+    const int ib = wave + NW * j;
+    const int n = 16 * ib + drow;
+    const bool ok = (NW * (j + 1) <= NBI || ib < NBI) && n < N;
+    b_vo0[j] = ok ? (unsigned)n * (unsigned)ldb0 * 4u + (unsigned)dkq * 16u : OOB;
+    b_vo1[j] = ok ? (unsigned)n * (unsigned)ldb1 * 4u + (unsigned)dkq * 16u : OOB;
+  }
+
+  const int drop_mode = P.drop_mode;
+  const unsigned drop_seed = P.drop_seed, drop_thresh = P.drop_thresh;
+  const float drop_scale = P.drop_scale;
+  const int drop_ld = P.drop_ld;
+
+  // one K tile: 16 k of BM rows of A and BN rows of B.  Invalid rows and k-quads at or beyond the segment's K carry
+  // the out-of-range marker, for which the buffer range check returns 0 -> zeros land in LDS.
+  auto dma_tile = [&](int t, int st) __attribute__((always_inline)) {
+    const int tt = t + toff;
+    const bool s1 = tt >= nt0;
+    const float* Ab = s1 ? A1 : A0;
+    const float* Bb = s1 ? B1 : B0;
+    const int k0 = s1 ? (tt - nt0) * BK : kbeg + tt * BK;
+    const int klim = s1 ? K1 : kend;
+    const rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0x7fffffff, 0x00020000);
+    const rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, 0x7fffffff, 0x00020000);
+    const bool kok = 4 * dkq < klim - k0;
+    unsigned char* sb = smem + st * STAGE;
+#pragma unroll
+    for (int j = 0; j < SA; ++j) {
+      const int ia = wave + NW * j;
+      if (NW * (j + 1) <= NAI || ia < NAI)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(sb + ia * 1024), 16,
+                                                 kok ? (s1 ? a_vo1[j] : a_vo0[j]) : OOB, k0 * 4, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < SB; ++j) {
+      const int ib = wave + NW * j;
+      if (NW * (j + 1) <= NBI || ib < NBI)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sb + BM * 64 + ib * 1024), 16,
+                                                 kok ? (s1 ? b_vo1[j] : b_vo0[j]) : OOB, k0 * 4, 0, 0);
+    }
+  };
+
+  // ---- fragments: lane (l15, q) reads chunk (row l15, k-quad q) of a 16-row tile
+  const int fsl = q ^ nt_swz((l15 >> 2) & 3);
+  const unsigned a_fo = (unsigned)((wrow + l15) * 4 + fsl) * 16u;
+  const unsigned b_fo = (unsigned)(BM * 64) + (unsigned)((wcol + l15) * 4 + fsl) * 16u;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 aC[MI], aP[MI], bX[NH], bY[NI - NH];
+
+  auto read_a = [&](int st, f32x4* a) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(smem + st * STAGE + a_fo + mi * 1024);
+  };
+  auto read_b = [&](int st, f32x4* b, int ni0, int cnt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (i < cnt) b[i] = *reinterpret_cast<const f32x4*>(smem + st * STAGE + b_fo + (ni0 + i) * 1024);
+  };
+  // swapped operands: acc[mi][ni][r] = C[row = wrow + mi*16 + l15][col = wcol + ni*16 + 4*q + r]
+  auto mma_n = [&](const f32x4* a, const f32x4* b, int ni0, auto CNT) __attribute__((always_inline)) {
+    constexpr int cnt = decltype(CNT)::value;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < cnt; ++i)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[mi][ni0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i][s], a[mi][s], acc[mi][ni0 + i], 0, 0, 0);
+  };
+  // column tiles of this wave that hold at least one real column (N = 300: the last wave column has 9 of 10); the B
+  // rows beyond N are zero in LDS, so skipping their MFMAs changes nothing but the time.  Wave-uniform.
+#ifdef GH_NT_NOSKIP
+  const int nv = NI;
+#else
+  const int nv = min(NI, max(0, (N - wcol + 15) >> 4));
+#endif
+  const int nvX = min(NH, nv), nvY = nv - nvX;
+  // CNT < 0: run-time count (odd shapes)
+  auto mma = [&](const f32x4* a, const f32x4* b, int ni0, auto CNT, int cnt_rt) __attribute__((always_inline)) {
+    constexpr int cnt = decltype(CNT)::value;
+    if constexpr (cnt >= 0) {
+      mma_n(a, b, ni0, CNT);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < NI - NH; ++i)
+          if (i < cnt_rt)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+              acc[mi][ni0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i][s], a[mi][s], acc[mi][ni0 + i], 0, 0, 0);
+    }
+  };
+  // stateless input dropout (wrapper.py:189-190) on the A fragments of segment 0: element (row, k) of [rows][drop_ld]
+  auto drop_a = [&](int t, f32x4* a) __attribute__((always_inline)) {
+    const int tt = t + toff;
+    if (tt < nt0) {
+      const int k = kbeg + tt * BK + 4 * q;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const unsigned idx = (unsigned)(m0 + wrow + mi * 16 + l15) * (unsigned)drop_ld + (unsigned)k;
+        const float4 v = drop4(make_float4(a[mi][0], a[mi][1], a[mi][2], a[mi][3]), drop_seed, idx, drop_thresh, drop_scale);
+        a[mi] = f32x4{v.x, v.y, v.z, v.w};
+      }
+    }
+  };
+
+  // ---- main loop: 2 LDS stages, one barrier per K tile.  Instantiated for the common tile counts so that the MFMA
+  //      stream is branch-free: every column tile valid / the last one of the Y batch all padding (N = 300).
+  auto run = [&](auto CX, auto CY) __attribute__((always_inline)) {
+    dma_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      const int st = t & 1;
+      if (t + 1 < T) dma_tile(t + 1, st ^ 1);
+      read_a(st, aC);
+      read_b(st, bX, 0, NH);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t > 0) mma(aP, bY, NH, CY, nvY);         // second half of tile t-1 covers the latency of the reads above
+      __builtin_amdgcn_sched_barrier(0);
+      read_b(st, bY, NH, NI - NH);
+      if (drop_mode == 1) drop_a(t, aC);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(aC, bX, 0, CX, nvX);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) aP[mi] = aC[mi];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    mma(aP, bY, NH, CY, nvY);
+  };
+  if (nvX == NH && nvY == NI - NH) run(std::integral_constant<int, NH>{}, std::integral_constant<int, NI - NH>{});
+  else if (nvX == NH && nvY == NI - NH - 1) run(std::integral_constant<int, NH>{}, std::integral_constant<int, NI - NH - 1>{});
+  else run(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
+
+  // -------------------------------------------------------------------- epilogue on whole rows
+  // Two passes (mi = 0, 1), each: accumulators (+bias) -> LDS, then a LINEAR pass over the 16*WM staged rows: item i
+  // is float4 (row i / C4, column chunk i % C4) with C4 = EP_PITCH/4 a compile-time divisor, so a wave instruction
+  // touches one contiguous run of a row in every epilogue stream.  Row reductions (attention head scores, the GSL
+  // scorer's projection) read the finished rows back from LDS, one wave per row, in a fixed order (deterministic).
+  if (L.dbg & 1) {
+    if (acc[0][0][0] == 12345.678f && acc[1][NI - 1][3] == 1.f) P.C[0] = 0.f;
+    return;
+  }
+  const int epi = P.epi;
+  const int ldc = P.ldc;
+  float* const C = P.C + (split ? (size_t)ks * (size_t)P.split_stride : (size_t)0);
+  const float* bias = P.bias;
+  float* out1 = P.out1;
+  const float* in0 = P.in0;
+  const float* in1 = P.in1;
+  const int accumulate = P.accumulate;
+  const int heads = P.heads;
+  const bool scorer = (epi == EPI_TANH_H) && (P.w2 != nullptr);
+  const bool rowred = (epi == EPI_ATT) || scorer;
+  float* ep = reinterpret_cast<float*>(smem);
+  const int N4 = N >> 2;
+  constexpr int C4 = EP_PITCH / 4;
+  constexpr int ITEMS = 16 * WM * C4;
+  constexpr int NIT = (ITEMS + NTHR - 1) / NTHR;
+  f32x4 bias4[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int col = wcol + ni * 16 + 4 * q;
+    bias4[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias && col < N) bias4[ni] = *reinterpret_cast<const f32x4*>(bias + col);
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    if (mi > 0) __syncthreads();                  // previous pass consumed (the loop's last barrier covers pass 0)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      *reinterpret_cast<f32x4*>(ep + (wm * 16 + l15) * EP_PITCH + wcol + ni * 16 + 4 * q) = acc[mi][ni] + bias4[ni];
+    __syncthreads();
+    // the pass holds, for every wave row b < WM, tile rows b*16*MI + mi*16 + [0,16)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * NTHR;
+      const int rr = i / C4, c4 = i - rr * C4;
+      const int row = m0 + (rr >> 4) * 16 * MI + mi * 16 + (rr & 15);
+      if ((ITEMS % NTHR == 0 || i < ITEMS) && c4 < N4 && row < M) {
+        const int col = 4 * c4;
+        const size_t o = (size_t)row * ldc + col;
+        float* sp = ep + rr * EP_PITCH + col;
+        float4 v = *reinterpret_cast<const float4*>(sp);
+        if (epi == EPI_STORE) {
+          if (drop_mode == 3)
+            v = drop4(v, drop_seed, (unsigned)row * (unsigned)drop_ld + (unsigned)(P.drop_col0 + col), drop_thresh, drop_scale);
+          if (accumulate) {
+            const float4 p = *reinterpret_cast<const float4*>(C + o);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+          }
+          *reinterpret_cast<float4*>(C + o) = v;
+        } else if (epi == EPI_SIGMOID_Z) {
+          *reinterpret_cast<float4*>(C + o) = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+        } else if (epi == EPI_SIGMOID_R) {
+          const float4 x = *reinterpret_cast<const float4*>(in0 + o);
+          const float4 r4 = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+          *reinterpret_cast<float4*>(C + o) = r4;
+          *reinterpret_cast<float4*>(out1 + o) = make_float4(r4.x * x.x, r4.y * x.y, r4.z * x.z, r4.w * x.w);
+        } else if (epi == EPI_TANH_H) {
+          const float4 z = *reinterpret_cast<const float4*>(in0 + o);
+          const float4 x = *reinterpret_cast<const float4*>(in1 + o);
+          const float4 h = make_float4(tanhf_(v.x), tanhf_(v.y), tanhf_(v.z), tanhf_(v.w));
+          float4 y = make_float4(h.x * z.x + x.x * (1.f - z.x), h.y * z.y + x.y * (1.f - z.y),
+                                 h.z * z.z + x.z * (1.f - z.z), h.w * z.w + x.w * (1.f - z.w));
+          *reinterpret_cast<float4*>(C + o) = h;
+          *reinterpret_cast<float4*>(out1 + o) = y;
+          if (scorer) {    // the word scorer sees dropout(out) (its own input dropout, wrapper.py:189-190)
+            if (drop_mode == 2)
+              y = drop4(y, drop_seed, (unsigned)row * (unsigned)drop_ld + (unsigned)col, drop_thresh, drop_scale);
+            *reinterpret_cast<float4*>(sp) = y;
+          }
+        } else if (epi == EPI_BWD_DRX) {
+          const float4 x = *reinterpret_cast<const float4*>(in0 + o);
+          const float4 r4 = *reinterpret_cast<const float4*>(in1 + o);
+          float4 d = *reinterpret_cast<const float4*>(out1 + o);
+          *reinterpret_cast<float4*>(C + o) =
+              make_float4(v.x * x.x * r4.x * (1.f - r4.x), v.y * x.y * r4.y * (1.f - r4.y),
+                          v.z * x.z * r4.z * (1.f - r4.z), v.w * x.w * r4.w * (1.f - r4.w));
+          d.x += v.x * r4.x; d.y += v.y * r4.y; d.z += v.z * r4.z; d.w += v.w * r4.w;
+          *reinterpret_cast<float4*>(out1 + o) = d;
+        } else if (epi == EPI_ATT) {
+          const float4 u4 = *reinterpret_cast<const float4*>(P.u + (size_t)(P.rowg ? P.rowg[row] : row / P.R) * P.ldu + col);
+          const float4 t4 = make_float4(tanhf_(v.x + u4.x), tanhf_(v.y + u4.y), tanhf_(v.z + u4.z), tanhf_(v.w + u4.w));
+          *reinterpret_cast<float4*>(C + o) = t4;
+          *reinterpret_cast<float4*>(sp) = t4;
+        }
+      }
+    }
+    if (rowred) {
+      // e[row][c] = sum_k y[row][k] w2[c][k] for the 16*WM finished rows in LDS: a [16 x N] x [N x <=8] product per row
+      // tile, on MFMA.  Wave (b, kp) takes row tile b and every KSPL-th K tile; partials meet in LDS (fixed order).
+      __syncthreads();
+      constexpr int KSPL = NW / WM;
+      const int nred = scorer ? 1 : heads;
+      const int b = wave % WM, kp = wave / WM;
+      const float* arow = ep + (b * 16 + l15) * EP_PITCH + 4 * q;
+      const float* wrow = P.w2 + (size_t)min(l15, nred - 1) * N + 4 * q;
+      f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int k0 = kp * 16; k0 < N; k0 += 16 * KSPL) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + k0);          // columns >= N of the staged tile are exact zeros
+        f32x4 w4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (l15 < nred && k0 + 4 * q < N) w4 = *reinterpret_cast<const f32x4*>(wrow + k0);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) d = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s2], a4[s2], d, 0, 0, 0);
+      }
+      // d[r] = partial e[row l15][c = 4q + r]
+      float* red = ep + 16 * WM * EP_PITCH;                                   // [KSPL][WM][64] float4, behind the staged rows
+      *reinterpret_cast<f32x4*>(red + ((kp * WM + b) * 64 + lane) * 4) = d;
+      __syncthreads();
+      if (kp == 0) {
+        f32x4 sum = d;
+#pragma unroll
+        for (int k2 = 1; k2 < KSPL; ++k2) sum += *reinterpret_cast<const f32x4*>(red + ((k2 * WM + b) * 64 + lane) * 4);
+        const int row = m0 + b * 16 * MI + mi * 16 + l15;
+        if (row < M) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * q + r < nred) P.e[(size_t)row * nred + 4 * q + r] = sum[r];
+        }
+      }
+    }
+  }
+#endif
+}
+
+}  // namespace gh

@@ -4,13 +4,14 @@
 #include "common.h"
 #include "gemm.hip.h"
 #include "gemm_fast.hip.h"
+#include "gemm_nt.hip.h"
 #include <stdlib.h>
 
 namespace gh {
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// fast-path preconditions of gemm_fast.hip.h
+// fast-path preconditions of gemm_nt.hip.h (NT: both operands contraction-contiguous, LDS-DMA) and gemm_fast.hip.h (TN)
 static bool fast_ok(const Launch& L, bool tn) {
   for (int i = 0; i < L.nprob; ++i) {
     const Problem& p = L.p[i];
@@ -20,14 +21,13 @@ static bool fast_ok(const Launch& L, bool tn) {
       if (!s.vecA || !s.vecB || s.gatherB || s.K < 4) return false;
       if (tn && s.gatherA) return false;
     }
-    if (!tn) {  // the B operand is addressed through a buffer descriptor: one ldb for both K segments, 31-bit byte offsets
-      if (p.nseg > 1 && p.seg[0].ldb != p.seg[1].ldb) return false;
+    if (!tn) {  // operands are addressed through buffer descriptors: 31-bit byte offsets
       for (int j = 0; j < p.nseg; ++j) {
-        if (4.0 * (double)p.seg[j].ldb * (double)p.seg[j].K >= 2147483648.0) return false;
+        if (4.0 * (double)p.seg[j].ldb * (double)p.N >= 2147483648.0) return false;
         if (!p.seg[j].gatherA && 4.0 * (double)p.seg[j].lda * (double)p.M >= 2147483648.0) return false;   // (gathered tables: < 2 GB by contract)
       }
     }
-    if (tn) {   // TN mode addresses its operands through buffer descriptors: 31-bit byte offsets
+    if (tn) {
       const Seg& s = p.seg[0];
       if (4.0 * (double)s.lda * (double)s.K >= 2147483648.0 || 4.0 * (double)s.ldb * (double)s.K >= 2147483648.0) return false;
     }
@@ -36,6 +36,7 @@ static bool fast_ok(const Launch& L, bool tn) {
     if ((p.bias && !al16(p.bias)) || (p.out1 && !al16(p.out1)) || (p.in0 && !al16(p.in0)) || (p.in1 && !al16(p.in1)))
       return false;
     if (p.epi == EPI_ATT && (!al16(p.u) || p.ldu % 4 || !al16(p.w2))) return false;
+    if (p.epi == EPI_TANH_H && p.w2 && !al16(p.w2)) return false;
   }
   return true;
 }
@@ -51,9 +52,8 @@ static bool wants_dropout(const Launch& L) {
 static long long g_path_counts[3] = {0, 0, 0};
 static int g_gemm_mode = 0;       // 0: fp32 MFMA everywhere (default); 1: bf16 MFMA in the big-tile NT/NN GEMMs (gh_set_gemm_mode)
 
-template <int WM, int WN, int NI, int MI = 2>
-static hipError_t launch_cfg(const Launch& L_in, bool tn, hipStream_t s) {
-  Launch L = L_in;
+template <int WM, int WN, int NI>
+static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
   const bool fast = fast_ok(L, tn);
   {
     double fl = 0.0;
@@ -62,42 +62,39 @@ static hipError_t launch_cfg(const Launch& L_in, bool tn, hipStream_t s) {
     g_path_counts[fast ? 0 : 1] += 1;
     if (!fast && fl >= 1e9) g_path_counts[2] += 1;
   }
-  if (!fast && MI != 2 && !tn) {   // the generic kernel's row tile is 32*WM: recount the row tiles
-    L.m_tiles = 0;
-    for (int i = 0; i < L.nprob; ++i) { const int mt = (L.p[i].M + 32 * WM - 1) / (32 * WM); if (mt > L.m_tiles) L.m_tiles = mt; }
-  }
   const int n_outer = tn ? L.ksplit : L.m_tiles;
   const int n_inner = tn ? L.m_tiles * L.nprob : L.nprob * L.ksplit;
   const int grid = 8 * ((n_outer + 7) / 8) * n_inner;
   if (grid <= 0) return hipSuccess;
+  const int tag = (WM * WN == 4 && WN != 4 ? PROF_GEMM_BIG : PROF_GEMM_SMALL) + (tn ? 1 : 0);
   double flops = 0.0;
   if (prof_enabled()) {
     for (int i = 0; i < L.nprob; ++i)
       for (int j = 0; j < L.p[i].nseg; ++j) {
         int rows = L.p[i].M;       // segment 0 is skipped by the row tiles at or beyond seg0_rows: do not count it
         if (j == 0 && !tn && L.p[i].nseg > 1 && L.p[i].seg0_rows > 0) {
-          const int bm = 16 * MI * WM, cut = ((L.p[i].seg0_rows + bm - 1) / bm) * bm;
+          const int bm = 32 * WM, cut = ((L.p[i].seg0_rows + bm - 1) / bm) * bm;
           if (cut < rows) rows = cut;
         }
         flops += 2.0 * rows * L.p[i].N * (double)L.p[i].seg[j].K;
       }
-    prof_begin(s, (WM * WN == 4 && WN != 4 ? PROF_GEMM_BIG : PROF_GEMM_SMALL) + (tn ? 1 : 0));
+    prof_begin(s, tag);
   }
-  if (!fast && wants_dropout(L)) return hipErrorInvalidValue;     // fused dropout exists in the fast kernel only
+  if (!fast && wants_dropout(L)) return hipErrorInvalidValue;     // fused dropout exists in the fast kernels only
+  if (!fast && !tn)
+    for (int i = 0; i < L.nprob; ++i)
+      if (L.p[i].epi == EPI_TANH_H && L.p[i].w2) return hipErrorInvalidValue;   // so does the fused scorer projection
   if (fast) {
     if (tn && g_gemm_mode == 1 && WM == 2 && WN == 2 && NI == 10) {
       if constexpr (WM == 2 && WN == 2 && NI == 10)
         hipLaunchKernelGGL((gemm_fast_kernel<2, 2, 10, true, 2, true>), dim3(grid), dim3(256), 0, s, L);
     } else if (tn) hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, true, 2>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
-    else if (g_gemm_mode == 1 && WM == 2 && WN == 2 && NI == 10 && MI == 2) {
-      if constexpr (WM == 2 && WN == 2 && NI == 10 && MI == 2)
-        hipLaunchKernelGGL((gemm_fast_kernel<2, 2, 10, false, 2, true>), dim3(grid), dim3(256), 0, s, L);
-    } else hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, false, MI>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
+    else hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, NI, 2>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
   } else {
     if (tn) hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, true>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
     else hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, false>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
   }
-  prof_end((WM * WN == 4 && WN != 4 ? PROF_GEMM_BIG : PROF_GEMM_SMALL) + (tn ? 1 : 0), flops, s);
+  prof_end(tag, flops, s);
   return hipGetLastError();
 }
 
@@ -131,6 +128,31 @@ reduce_partials_kernel(const ReduceArgs R) {
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     float* o = it.out + (size_t)i * it.ldc + j;     // += : gradients accumulate into the caller's buffer
+    o[0] += acc.x; o[1] += acc.y; o[2] += acc.z; o[3] += acc.w;
+  }
+}
+
+// Same reduction for FEW output elements and MANY partials (dW2 of the attention: 5 x 300 values, one partial per
+// pair): one wave per float4 element, lanes stride over the partials, fixed-order shuffle tree.
+__global__ void __launch_bounds__(256)
+reduce_partials_wave_kernel(const ReduceArgs R) {
+  const ReduceItem& it = R.it[blockIdx.y];
+  const int J4 = it.J / 4;
+  const int total = it.I * J4;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (e >= total) return;
+  const int i = e / J4, j = 4 * (e % J4);
+  const float* p = it.ws + (size_t)i * it.J + j;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = lane; k < it.ks; k += 64) {
+    const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * it.stride);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o); acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
+  }
+  if (lane == 0) {
+    float* o = it.out + (size_t)i * it.ldc + j;
     o[0] += acc.x; o[1] += acc.y; o[2] += acc.z; o[3] += acc.w;
   }
 }
@@ -195,17 +217,6 @@ nt_finish_kernel(const FinishArgs F) {
   }
 }
 
-// Big-M tile configuration: 0 = 128x304 (4x1 waves, 19 col tiles), 1 = 64x320 (2x2 waves, 10 col tiles).
-// GH_GEMM_CFG overrides the default for A/B runs.
-static int big_cfg() {
-  static int cfg = -1;
-  if (cfg < 0) {
-    const char* e = getenv("GH_GEMM_CFG");
-    cfg = e ? atoi(e) : 1;
-  }
-  return cfg;
-}
-
 // Collects problems that share their row space, splits wide outputs into column blocks the tile
 // can hold, and launches them GH_MAX_PROBLEMS at a time.
 struct Batch {
@@ -223,24 +234,31 @@ struct Batch {
   void want_colsum(float* o, float* o2) { if (L.nprob > 0) { cs_out[L.nprob - 1] = o; cs_out2[L.nprob - 1] = o2; } }
 
   Batch(bool tn_, int rows_hint, hipStream_t s_) : tn(tn_), s(s_) {
-    big = tn_ || rows_hint >= 8192;
-    bm = big ? (big_cfg() == 0 || ((big_cfg() == 4 || big_cfg() == 5) && !tn_) ? 128 : 64) : 32;
-    bn = big ? (big_cfg() == 0 ? GH_BN_BIG : (big_cfg() == 3 || (big_cfg() == 5 && !tn_) ? 160 : 320)) : GH_BN_SMALL;
+    big = tn_ || rows_hint >= 8192;      // 64x320 tile (2x2 waves) for the activation-sized GEMMs, 32x320 (1x4) for few-row ones
+    bm = big ? 64 : 32;
+    bn = 320;
     reset();
   }
   void reset() {
     L.nprob = 0; L.m_tiles = 0; L.ksplit = 1; L.kchunk = 0; k_total = 0;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("GH_DBG"); dbg = e ? atoi(e) : 0; }
+    L.dbg = dbg;
     for (int i = 0; i < GH_MAX_PROBLEMS; ++i) cs_out[i] = cs_out2[i] = nullptr;
   }
 
   void add(const Problem& p) {
-    if (p.epi == EPI_ATT && p.N > bn) { err = hipErrorInvalidValue; return; }
+    if ((p.epi == EPI_ATT || (p.epi == EPI_TANH_H && p.w2)) && p.N > bn) { err = hipErrorInvalidValue; return; }   // row reductions need whole rows
     for (int n0 = 0; n0 < p.N; n0 += bn) {
       Problem q = p;
       q.N = (p.N - n0 < bn) ? p.N - n0 : bn;
       for (int i = 0; i < q.nseg; ++i) {
-        q.seg[i].B += n0;
-        q.seg[i].vecB = vec_ok(q.seg[i].B, q.seg[i].ldb, q.N);
+        if (tn) {
+          q.seg[i].B += n0;
+          q.seg[i].vecB = vec_ok(q.seg[i].B, q.seg[i].ldb, q.N);
+        } else {
+          q.seg[i].B += (size_t)n0 * q.seg[i].ldb;       // B is [N][ldb]: a column block of C is a row block of B
+        }
       }
       q.C += n0;
       q.drop_col0 = p.drop_col0 + n0;
@@ -324,13 +342,7 @@ struct Batch {
     reset();
   }
 
-  hipError_t launch_any() {
-    return !big ? launch_cfg<1, 4, 5>(L, tn, s)
-                : (big_cfg() == 0 ? launch_cfg<4, 1, 19>(L, tn, s)
-                   : (big_cfg() == 3 ? launch_cfg<2, 2, 5>(L, tn, s)
-                      : (big_cfg() == 4 && !tn ? launch_cfg<2, 2, 10, 4>(L, tn, s)
-                         : (big_cfg() == 5 && !tn ? launch_cfg<4, 1, 10>(L, tn, s) : launch_cfg<2, 2, 10>(L, tn, s)))));
-  }
+  hipError_t launch_any() { return big ? launch_cfg<2, 2, 10>(L, tn, s) : launch_cfg<1, 4, 5>(L, tn, s); }
 
   // Few-row NT GEMMs (evidence level, head): too few row tiles to fill 256 CUs, so split K across
   // workgroups, keep the partial tiles in the workspace and finish with nt_finish_kernel.
@@ -382,11 +394,11 @@ struct Batch {
 static Problem gemm_problem(int M, int N, int epi, float* C, int ldc, const float* A, int lda, const float* B, int ldb,
                             int K, const int32_t* gatherA = nullptr) {
   Problem p = make_problem(M, N, epi, C, ldc);
-  p.seg[0] = make_seg(A, lda, B, ldb, K, N, gatherA, nullptr);
+  p.seg[0] = make_seg_nt(A, lda, B, ldb, K, gatherA);
   return p;
 }
 static void add_seg(Problem& p, const float* A, int lda, const float* B, int ldb, int K) {
-  p.seg[p.nseg++] = make_seg(A, lda, B, ldb, K, p.N);
+  p.seg[p.nseg++] = make_seg_nt(A, lda, B, ldb, K);
 }
 static void set_dropout(Problem& p, int mode, int ld, float drop_p, unsigned seed) {
   if (drop_p <= 0.f) return;
@@ -409,11 +421,13 @@ using namespace gh;
 extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
                                 const int32_t* goff, int m_real, int m_rows,
                                 const float* x, const int32_t* ids, int n, int r, int din, int h,
-                                const float* wt_p, const float* wt_z0, const float* wt_z1, const float* wt_r0,
-                                const float* wt_r1, const float* wt_h0, const float* wt_h1,
+                                const float* w_p, const float* w_z0, const float* w_z1, const float* w_r0,
+                                const float* w_r1, const float* w_h0, const float* w_h1,
                                 const float* b_z, const float* b_r, const float* b_h,
                                 float* xp, float* a, float* z, float* rr, float* rx, float* hh, float* out,
-                                float drop_p, uint32_t drop_seed, gh_stream_t stream) {
+                                float drop_p, uint32_t drop_seed,
+                                const float* score_w, float* score_x, float score_drop_p, uint32_t score_drop_seed,
+                                gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   GH_REQUIRE(n > 0 && r > 0 && din > 0 && h > 0, "ggnn_cell_fwd: bad sizes n=%d r=%d din=%d h=%d", n, r, din, h);
   if (!goff) { m_real = n * r; m_rows = n * r; }
@@ -421,9 +435,11 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
   const int M = m_rows;
   if (M == 0) return 0;
   GH_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ggnn_cell_fwd: dropout p=%f not in [0,1)", drop_p);
-  {  // xp = dropout(x) Wp^T   (wrapper.py:189-191); embedding rows gathered and the dropout mask applied in the A loader
+  GH_REQUIRE((score_w == nullptr) == (score_x == nullptr), "ggnn_cell_fwd: score_w and score_x come together");
+  GH_REQUIRE(score_drop_p >= 0.f && score_drop_p < 1.f, "ggnn_cell_fwd: scorer dropout p=%f not in [0,1)", score_drop_p);
+  {  // xp = dropout(x) Wp^T   (wrapper.py:189-191); embedding rows gathered by the loader, the dropout mask applied to the fragments
     Batch b(false, M, s);
-    Problem p = gemm_problem(M, h, EPI_STORE, xp, h, x, din, wt_p, h, din, ids);
+    Problem p = gemm_problem(M, h, EPI_STORE, xp, h, x, din, w_p, din, din, ids);
     set_dropout(p, 1, din, drop_p, drop_seed);
     b.add(p);
     b.flush();
@@ -435,25 +451,30 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
     GH_CHECK_HIP(hipMemsetAsync(a + (size_t)m_real * h, 0, sizeof(float) * (size_t)(m_rows - m_real) * h, s));
   {  // z, r gates (:194-200): [a | xp] . [W?0 | W?1]^T as two K segments
     Batch b(false, M, s);
-    Problem pz = gemm_problem(M, h, EPI_SIGMOID_Z, z, h, a, h, wt_z0, h, h);
-    add_seg(pz, xp, h, wt_z1, h, h);
+    Problem pz = gemm_problem(M, h, EPI_SIGMOID_Z, z, h, a, h, w_z0, h, h);
+    add_seg(pz, xp, h, w_z1, h, h);
     pz.bias = b_z;
-    Problem pr = gemm_problem(M, h, EPI_SIGMOID_R, rr, h, a, h, wt_r0, h, h);
-    add_seg(pr, xp, h, wt_r1, h, h);
+    Problem pr = gemm_problem(M, h, EPI_SIGMOID_R, rr, h, a, h, w_r0, h, h);
+    add_seg(pr, xp, h, w_r1, h, h);
     pr.bias = b_r; pr.out1 = rx; pr.in0 = xp;
     if (m_rows > m_real) pz.seg0_rows = pr.seg0_rows = (m_real > 0 ? m_real : 1);
     b.add(pz); b.add(pr);
     b.flush();
     GH_CHECK_HIP(b.err);
   }
-  {  // h gate and the convex update (:202-206)
+  {  // h gate and the convex update (:202-206); optionally the GSL word scorer's projection of the result (:167)
     Batch b(false, M, s);
-    Problem ph = gemm_problem(M, h, EPI_TANH_H, hh, h, a, h, wt_h0, h, h);
-    add_seg(ph, rx, h, wt_h1, h, h);
+    Problem ph = gemm_problem(M, h, EPI_TANH_H, hh, h, a, h, w_h0, h, h);
+    add_seg(ph, rx, h, w_h1, h, h);
     ph.bias = b_h; ph.out1 = out; ph.in0 = z; ph.in1 = xp;
     if (m_rows > m_real) ph.seg0_rows = (m_real > 0 ? m_real : 1);
+    if (score_w) {
+      ph.w2 = score_w; ph.e = score_x;
+      set_dropout(ph, 2, h, score_drop_p, score_drop_seed);
+    }
     b.add(ph);
     b.flush();
+    GH_REQUIRE(b.err != hipErrorInvalidValue || !score_w, "ggnn_cell_fwd: the fused scorer projection needs h %% 4 == 0 and h <= 320 (h=%d)", h);
     GH_CHECK_HIP(b.err);
   }
   return 0;
@@ -462,8 +483,8 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
 extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
                                 const int32_t* goff, int m_real,
                                 const float* x, const int32_t* ids, int n, int r, int din, int h,
-                                const float* w_p, const float* w_z0, const float* w_z1, const float* w_r0,
-                                const float* w_r1, const float* w_h0, const float* w_h1,
+                                const float* wt_p, const float* wt_z0, const float* wt_z1, const float* wt_r0,
+                                const float* wt_r1, const float* wt_h0, const float* wt_h1,
                                 const float* xp, const float* a, const float* z, const float* rr, const float* rx,
                                 const float* hh, const float* g,
                                 float* dhp, float* dzp, float* drp, float* dxp, float* da,
@@ -481,8 +502,8 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
   if (int e = launch_gate_bwd_pre(g, z, hh, xp, dhp, dzp, dxp, (size_t)M * h, s)) return e;
   {  // hp = a Wh0^T + (r xp) Wh1^T:  da = dhp Wh0 ; d(r xp) = dhp Wh1 -> drp, dxp += .
     Batch b(false, M, s);
-    Problem p0 = gemm_problem(M, h, EPI_STORE, da, h, dhp, h, w_h0, h, h);
-    Problem p1 = gemm_problem(M, h, EPI_BWD_DRX, drp, h, dhp, h, w_h1, h, h);
+    Problem p0 = gemm_problem(M, h, EPI_STORE, da, h, dhp, h, wt_h0, h, h);
+    Problem p1 = gemm_problem(M, h, EPI_BWD_DRX, drp, h, dhp, h, wt_h1, h, h);
     p1.out1 = dxp; p1.in0 = xp; p1.in1 = rr;
     b.add(p0); b.add(p1);
     b.flush();
@@ -490,11 +511,11 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
   }
   {  // da += dzp Wz0 + drp Wr0 ; dxp += dzp Wz1 + drp Wr1
     Batch b(false, M, s);
-    Problem p0 = gemm_problem(M, h, EPI_STORE, da, h, dzp, h, w_z0, h, h);
-    add_seg(p0, drp, h, w_r0, h, h);
+    Problem p0 = gemm_problem(M, h, EPI_STORE, da, h, dzp, h, wt_z0, h, h);
+    add_seg(p0, drp, h, wt_r0, h, h);
     p0.accumulate = 1;
-    Problem p1 = gemm_problem(M, h, EPI_STORE, dxp, h, dzp, h, w_z1, h, h);
-    add_seg(p1, drp, h, w_r1, h, h);
+    Problem p1 = gemm_problem(M, h, EPI_STORE, dxp, h, dzp, h, wt_z1, h, h);
+    add_seg(p1, drp, h, wt_r1, h, h);
     p1.accumulate = 1;
     b.add(p0); b.add(p1);
     b.flush();
@@ -503,7 +524,7 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
   if (int e = launch_spmm(bits, dinv, vals, keep, goff, m_real, da, dxp, n, r, h, 1, 1, s)) return e;   // dxp += A_hat^T da
   if (dx) {  // dx = (dxp Wp) . mask/(1-p)
     Batch b(false, M, s);
-    Problem p = gemm_problem(M, din, EPI_STORE, dx, din, dxp, h, w_p, din, h);
+    Problem p = gemm_problem(M, din, EPI_STORE, dx, din, dxp, h, wt_p, h, h);
     set_dropout(p, 3, din, drop_p, drop_seed);
     b.add(p);
     b.flush();
@@ -538,7 +559,7 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
 
 extern "C" int gh_concat_att_fwd(const float* left, const float* right, const float* mask, const int32_t* goff,
                                  const int32_t* rowg, int m_real, int b, int l, int xl,
-                                 int dr, int ha, int heads, const float* w1t, const float* w2,
+                                 int dr, int ha, int heads, const float* w1, const float* w2,
                                  float* u, float* t, float* e, float* weights, float* attended,
                                  gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -551,9 +572,10 @@ extern "C" int gh_concat_att_fwd(const float* left, const float* right, const fl
   const bool one_block = ha <= Batch(false, M, s).bn;      // column block of the tile configuration this launch will use
   GH_REQUIRE(one_block || (ha % 4 == 0 && al16(t) && al16(u) && al16(w2)),
              "concat_att_fwd: attention hidden %d wider than one column block needs float4-shaped rows", ha);
+  const int xl_in = (left && xl > 0) ? xl : 0;      // column offset of the right branch inside linear1.weight
   if (left && xl > 0) {  // u = W1[:, :xl] . left -- once per pair, not per token (two_branches_attention.py:137-140)
     Batch bt(false, b, s);
-    bt.add(gemm_problem(b, ha, EPI_STORE, u, ha, left, xl, w1t, ha, xl));
+    bt.add(gemm_problem(b, ha, EPI_STORE, u, ha, left, xl, w1, xl + dr, xl));
     bt.flush();
     GH_CHECK_HIP(bt.err);
   } else {
@@ -562,7 +584,7 @@ extern "C" int gh_concat_att_fwd(const float* left, const float* right, const fl
   }
   if (M > 0) {  // t = tanh(W1[:, xl:] . right_t + u) ; e = W2 t  (:140-141)
     Batch bt(false, M, s);
-    Problem p = gemm_problem(M, ha, EPI_ATT, t, ha, right, dr, w1t + (size_t)xl * ha, ha, dr);
+    Problem p = gemm_problem(M, ha, EPI_ATT, t, ha, right, dr, w1 + xl_in, xl_in + dr, dr);
     p.u = u; p.ldu = ha; p.R = l; p.w2 = w2; p.heads = heads; p.e = e; p.rowg = rowg;
     if (!one_block) p.epi = EPI_STORE;     // wide hidden layer (h = 768): the head scores need whole rows, so the
     bt.add(p);                             // tanh + W2 reduction runs as a row-per-wave pass over the stored product
@@ -580,7 +602,7 @@ extern "C" int gh_concat_att_fwd(const float* left, const float* right, const fl
 }
 
 extern "C" int gh_concat_att_bwd(const float* left, const float* right, const int32_t* goff, int m_real, int b, int l,
-                                 int xl, int dr, int ha, int heads, const float* w1, const float* w2, const float* t, const float* weights,
+                                 int xl, int dr, int ha, int heads, const float* w1t, const float* w2, const float* t, const float* weights,
                                  const float* g_att, const float* g_w, float* de, float* dpre, float* du,
                                  float* dleft, float* dright, float* dw1, float* dw2, gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -599,12 +621,12 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, const in
     ReduceArgs R;
     R.n = 1;
     R.it[0] = ReduceItem{dw2_part, dw2, heads, ha, ha, b, (long long)heads * ha};
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((heads * (ha / 4) + 255) / 256, 1), dim3(256), 0, s, R);
+    hipLaunchKernelGGL(reduce_partials_wave_kernel, dim3((heads * (ha / 4) + 3) / 4, 1), dim3(256), 0, s, R);
     GH_LAUNCH_CHECK();
   }
   if (M > 0) {  // dright += dpre W1[:, xl:]
     Batch bt(false, M, s);
-    Problem p = gemm_problem(M, dr, EPI_STORE, dright, dr, dpre, ha, w1 + xl, ldw, ha);
+    Problem p = gemm_problem(M, dr, EPI_STORE, dright, dr, dpre, ha, w1t + (size_t)xl * ha, ha, ha);
     p.accumulate = 1;
     bt.add(p);
     bt.flush();
@@ -612,7 +634,7 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, const in
   }
   if (xl > 0 && dleft) {  // dleft = du W1[:, :xl]
     Batch bt(false, b, s);
-    bt.add(gemm_problem(b, xl, EPI_STORE, dleft, xl, du, ha, w1, ldw, ha));
+    bt.add(gemm_problem(b, xl, EPI_STORE, dleft, xl, du, ha, w1t, ha, ha));
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }
@@ -665,12 +687,12 @@ extern "C" int gh_set_workspace(void* ptr, int64_t bytes) {
   return 0;
 }
 
-extern "C" int gh_linear_fwd(const float* x, const float* wt, const float* bias, float* y, int m, int k, int n,
+extern "C" int gh_linear_fwd(const float* x, const float* w, const float* bias, float* y, int m, int k, int n,
                              gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   GH_REQUIRE(m > 0 && k > 0 && n > 0, "linear_fwd: bad sizes");
   Batch b(false, m, s);
-  Problem p = gemm_problem(m, n, EPI_STORE, y, n, x, k, wt, n, k);
+  Problem p = gemm_problem(m, n, EPI_STORE, y, n, x, k, w, k, k);
   p.bias = bias;
   b.add(p);
   b.flush();
@@ -678,13 +700,13 @@ extern "C" int gh_linear_fwd(const float* x, const float* wt, const float* bias,
   return 0;
 }
 
-extern "C" int gh_linear_bwd(const float* x, const float* w, const float* g, int m, int k, int n, float* dx,
+extern "C" int gh_linear_bwd(const float* x, const float* wt, const float* g, int m, int k, int n, float* dx,
                              float* dw, float* db, gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   GH_REQUIRE(m > 0 && k > 0 && n > 0, "linear_bwd: bad sizes");
   if (dx) {
     Batch b(false, m, s);
-    b.add(gemm_problem(m, k, EPI_STORE, dx, k, g, n, w, k, n));
+    b.add(gemm_problem(m, k, EPI_STORE, dx, k, g, n, wt, n, n));
     b.flush();
     GH_CHECK_HIP(b.err);
   }

@@ -464,8 +464,8 @@ __device__ __forceinline__ void topk_keep(const float* ss, int R, int k, uint64_
 // word scorer (GGNN 300->1, wrapper.py:167) + GSL top-k (:216-219), one workgroup per graph
 __global__ void __launch_bounds__(256)
 scorer_gsl_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
-                  const int32_t* __restrict__ goff, const float* __restrict__ feat, const float* __restrict__ w_p,
-                  const float* __restrict__ gate, int R, int H, int k, int pads_collapsed, float* __restrict__ score, uint64_t* __restrict__ keep, unsigned drop_thresh,
+                  const int32_t* __restrict__ goff, const float* __restrict__ feat, const float* __restrict__ xs_in,
+                  const float* __restrict__ w_p, const float* __restrict__ gate, int R, int H, int k, int pads_collapsed, float* __restrict__ score, uint64_t* __restrict__ keep, unsigned drop_thresh,
                   float drop_scale, unsigned drop_seed) {
   __shared__ float xs[MAX_R];
   __shared__ float ss[MAX_R];
@@ -481,6 +481,9 @@ scorer_gsl_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ d
   const int pad0 = goff ? goff[gridDim.x] + (pads_collapsed ? 0 : g * R - row0 - NR) : row0;
   // x_j = feat_j . w_p   (proj, no bias)
   const bool v4 = (H % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat) & 15) == 0) && ((reinterpret_cast<uintptr_t>(w_p) & 15) == 0);
+  if (xs_in) {      // projection already done by the producing cell's epilogue (gh_ggnn_cell_fwd score_x): one float per node
+    if (tid < R) xs[tid] = xs_in[(unsigned)(tid < NR ? row0 + tid : (pads_collapsed ? pad0 : pad0 + tid))];
+  } else {
 #pragma unroll 4
   for (int j = wave; j < R; j += 4) {
     float acc = 0.f;
@@ -504,6 +507,7 @@ scorer_gsl_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ d
     }
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if (lane == 0) xs[j] = acc;
+  }
   }
   __syncthreads();
   if (tid < R) {
@@ -603,7 +607,7 @@ extern "C" int gh_spmm(const uint64_t* bits, const float* dinv, const float* val
 }
 
 extern "C" int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const int32_t* goff,
-                             int pads_collapsed, const float* feat, const float* w_p, const float* gate, int n, int r, int h, int k, float* score,
+                             int pads_collapsed, const float* feat, const float* score_x, const float* w_p, const float* gate, int n, int r, int h, int k, float* score,
                              uint64_t* keep, float drop_p, uint32_t drop_seed, gh_stream_t stream) {
   GH_REQUIRE(r > 0 && r <= MAX_R, "scorer_gsl: r=%d not in [1,%d]", r, MAX_R);
   GH_REQUIRE(vals || dinv, "scorer_gsl: need dinv or vals");
@@ -613,9 +617,10 @@ extern "C" int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const floa
   GH_REQUIRE(!(pads_collapsed && drop_p > 0.f), "scorer_gsl: collapsed padding rows are an evaluation-mode layout (no dropout)");
   const double th = (double)drop_p * 4294967296.0;
   const unsigned thresh = drop_p > 0.f ? (th >= 4294967295.0 ? 4294967295u : (unsigned)th) : 0u;
-  hipLaunchKernelGGL(scorer_gsl_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, bits, dinv, vals, goff, feat,
+  GH_REQUIRE((feat != nullptr) != (score_x != nullptr), "scorer_gsl: exactly one of feat / score_x");
+  hipLaunchKernelGGL(scorer_gsl_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, bits, dinv, vals, goff, feat, score_x,
                      w_p, gate, r, h, k, (goff && pads_collapsed) ? 1 : 0, score, keep, thresh, 1.0f / (1.0f - drop_p), drop_seed);
-  prof_end(PROF_SCORER_GSL, (double)n * (4.0 * r * h + 8.0 * r * words_for(r) + 8.0 * r + 8.0 * words_for(r)),
+  prof_end(PROF_SCORER_GSL, (double)n * ((feat ? 4.0 * r * h : 4.0 * r) + 8.0 * r * words_for(r) + 8.0 * r + 8.0 * words_for(r)),
            (hipStream_t)stream);
   GH_LAUNCH_CHECK();
   return 0;

@@ -75,17 +75,18 @@ class GGNN(nn.Module):
             return (float(self.dropout.p), ops.new_dropout_seed())
         return None
 
-    def forward(self, adj, x, plan=None, rows=0):
+    def forward(self, adj, x, plan=None, rows=0, score=None):
         """adj: dense (N,R,R) or PackedAdj; x: (N,R,Din).  Returns (N,R,Dout).
         Training-mode input dropout (wrapper.py:189-190) runs inside the first GEMM's loader.
-        plan (ops.RaggedPlan, internal fast path): x is node-compact (>= rows, Din); returns (rows, Dout)."""
+        plan (ops.RaggedPlan, internal fast path): x is node-compact (>= rows, Din); returns (rows, Dout).
+        score (internal, see ops.ggnn_cell): also return the consuming word scorer's projection of the output."""
         adj = ops.as_packed(adj)
         d = self._drop()
         if d is None:
-            return ops.ggnn_cell(adj, self.dropout(x), None, self._params(), plan=plan, rows=rows)
-        return ops.ggnn_cell(adj, x, None, self._params(), d[0], d[1], plan=plan, rows=rows)
+            return ops.ggnn_cell(adj, self.dropout(x), None, self._params(), plan=plan, rows=rows, score=score)
+        return ops.ggnn_cell(adj, x, None, self._params(), d[0], d[1], plan=plan, rows=rows, score=score)
 
-    def forward_ids(self, adj, embedding: nn.Embedding, ids: torch.Tensor, plan=None, rows=0):
+    def forward_ids(self, adj, embedding: nn.Embedding, ids: torch.Tensor, plan=None, rows=0, score=None):
         """Same cell on ``embedding(ids)`` with the row gather fused into the first GEMM
         (graph_based_semantic_structure.py:100,150); training-mode dropout is applied there too.  Falls
         back to an explicit lookup + nn.Dropout only for widths that are not float4-shaped.
@@ -97,9 +98,9 @@ class GGNN(nn.Module):
             ids = plan.cids[:rows]
         if d is None:
             x = self.dropout(embedding(ids.long()))
-            return ops.ggnn_cell(adj, x, None, self._params(), plan=plan, rows=rows)
+            return ops.ggnn_cell(adj, x, None, self._params(), plan=plan, rows=rows, score=score)
         return ops.ggnn_cell(adj, embedding.weight, ids.to(torch.int32).reshape(-1), self._params(), d[0], d[1],
-                             plan=plan, rows=rows)
+                             plan=plan, rows=rows, score=score)
 
 
 # ------------------------------------------------------------------ Models/BiDAF/wrapper.py:210-227
@@ -148,22 +149,40 @@ class GGNN_with_GSL(nn.Module):
             srcs += [m.linear.weight, m.linear.bias]
         return ops.derived("gate12", tuple(srcs), lambda: torch.cat([t.detach().reshape(1) for t in srcs]))
 
-    def _refine(self, adj: PackedAdj, feat, plan=None, collapsed=False):
+    def _scorer_drop(self):
+        """(p, seed) of word_scorer1's own input dropout for this call (wrapper.py:189-190)."""
         s = self.word_scorer1
-        drop_p, seed = 0.0, 0
         if hasattr(s, "dropout") and self.training and s.dropout.p > 0:
-            drop_p, seed = float(s.dropout.p), ops.new_dropout_seed()   # word_scorer1's own input dropout (wrapper.py:189-190)
+            return float(s.dropout.p), ops.new_dropout_seed()
+        return 0.0, 0
+
+    def _score_arg(self):
+        """Argument that makes the first cell's last epilogue also produce the scorer's projection (or None)."""
+        w = self.word_scorer1.proj.linear.weight
+        if not ops.scorer_fusable(w.shape[1]):
+            return None
+        return (w,) + self._scorer_drop()
+
+    def _refine(self, adj: PackedAdj, feat, plan=None, collapsed=False, score_x=None):
+        s = self.word_scorer1
+        drop_p, seed = (0.0, 0) if score_x is not None else self._scorer_drop()
         k = int(self.gsl1.rate * adj.r)
         score, keep = ops.scorer_gsl(adj, feat, s.proj.linear.weight, self._gate12(), k, drop_p, seed, plan=plan,
-                                     collapsed=collapsed)
+                                     collapsed=collapsed, score_x=score_x)
         self.last_score, self.last_keep = score, keep
         return adj.with_keep(keep)
 
+    def _first_cell(self, run):
+        """Run feat_prop1 through `run(score)`; returns (feat, score_x or None)."""
+        sc = self._score_arg()
+        res = run(sc)
+        return res if sc is not None else (res, None)
+
     def forward(self, adj, feat):
         adj = ops.as_packed(adj)
-        feat = self.feat_prop1(adj, feat)
+        feat, sx = self._first_cell(lambda sc: self.feat_prop1(adj, feat, score=sc))
         self._milestone(feat)
-        adj_refined = self._refine(adj, feat)
+        adj_refined = self._refine(adj, feat, score_x=sx)
         return self.feat_prop2(adj_refined, feat)
 
     def forward_ids(self, adj, embedding, ids, plan=None):
@@ -172,17 +191,17 @@ class GGNN_with_GSL(nn.Module):
         (plan.m_real, H) instead of (N,R,H)."""
         adj = ops.as_packed(adj)
         if plan is None:
-            feat = self.feat_prop1.forward_ids(adj, embedding, ids)
+            feat, sx = self._first_cell(lambda sc: self.feat_prop1.forward_ids(adj, embedding, ids, score=sc))
             self._milestone(feat)
-            adj_refined = self._refine(adj, feat)
+            adj_refined = self._refine(adj, feat, score_x=sx)
             return self.feat_prop2(adj_refined, feat)
         # without dropout (evaluation) every padding row of the batch is the same vector: the first cell then runs on
         # the real rows plus ONE representative padding row instead of all n*R rows
         collapsed = not self.training
         rows = min(plan.m_real + 1, plan.m_tot) if collapsed else plan.m_tot
-        feat = self.feat_prop1.forward_ids(adj, embedding, ids, plan=plan, rows=rows)
+        feat, sx = self._first_cell(lambda sc: self.feat_prop1.forward_ids(adj, embedding, ids, plan=plan, rows=rows, score=sc))
         self._milestone(feat)
-        adj_refined = self._refine(adj, feat, plan, collapsed)
+        adj_refined = self._refine(adj, feat, plan, collapsed, score_x=sx)
         return self.feat_prop2(adj_refined, feat, plan=plan, rows=plan.m_real)
 
 

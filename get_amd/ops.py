@@ -254,7 +254,7 @@ class _GGNNCell(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, ids, adj: PackedAdj, w_p, w_z0, b_z0, w_z1, b_z1, w_r0, b_r0, w_r1, b_r1, w_h0, b_h0, w_h1,
-                b_h1, drop_p=0.0, drop_seed=0, plan=None, rows=0):
+                b_h1, drop_p=0.0, drop_seed=0, plan=None, rows=0, score=None):
         x = _f32(x)
         n, r = adj.n, adj.r
         h, din = w_p.shape
@@ -270,25 +270,36 @@ class _GGNNCell(torch.autograd.Function):
         else:
             assert x.numel() == m * din, f"x has {x.numel()} elements, expected {m}x{din}"
         dev = x.device
+        # forward products x.W^T take the weights as stored; the backward's dX = g.W takes the cached transposes
         ws = [_f32(w.detach()) for w in (w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1)]
         wts = [transposed(w) for w in (w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1)]
         b_z, b_r, b_h = derived("cell_bias", (b_z0, b_z1, b_r0, b_r1, b_h0, b_h1), lambda: tuple(
             _f32(u.detach() + v.detach()) for u, v in ((b_z0, b_z1), (b_r0, b_r1), (b_h0, b_h1))))
         buf = torch.empty((7, m, h), device=dev, dtype=torch.float32)
         xp, a, z, rr, rx, hh, out = buf.unbind(0)
+        sx = None
+        sc = (None, None, 0.0, 0)
+        if score is not None:      # (scorer proj weight (h,), dropout p, seed): projection fused into the last epilogue
+            sw, sp, sseed = score
+            sx = torch.empty((m,), device=dev, dtype=torch.float32)
+            sc = (ptr(_f32(sw.detach().reshape(-1))), ptr(sx), float(sp), int(sseed))
         call("gh_ggnn_cell_fwd", *adj._args(), *_plan_args(plan), m, ptr(x), ptr(ids), n, r, din, h,
-             *[ptr(t) for t in wts], ptr(b_z), ptr(b_r), ptr(b_h),
-             ptr(xp), ptr(a), ptr(z), ptr(rr), ptr(rx), ptr(hh), ptr(out), float(drop_p), int(drop_seed), stream())
+             *[ptr(t) for t in ws], ptr(b_z), ptr(b_r), ptr(b_h),
+             ptr(xp), ptr(a), ptr(z), ptr(rr), ptr(rx), ptr(hh), ptr(out), float(drop_p), int(drop_seed), *sc, stream())
         ctx.adj, ctx.ids, ctx.dims, ctx.plan, ctx.rows = adj, ids, (n, r, din, h), plan, (m, mb)
         ctx.drop = (float(drop_p), int(drop_seed))
         ctx.params = (w_p, w_z0, b_z0, w_z1, b_z1, w_r0, b_r0, w_r1, b_r1, w_h0, b_h0, w_h1, b_h1)
-        ctx.save_for_backward(x, buf, *ws)
+        ctx.save_for_backward(x, buf, *wts)
         ctx.x_needs_grad = ctx.needs_input_grad[0]
-        return out.view(n, r, h) if plan is None else out
+        res = out.view(n, r, h) if plan is None else out
+        if score is not None:
+            ctx.mark_non_differentiable(sx)
+            return res, sx
+        return res
 
     @staticmethod
-    def backward(ctx, g):
-        x, buf, w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1 = ctx.saved_tensors
+    def backward(ctx, g, *_unused):
+        x, buf, w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1 = ctx.saved_tensors      # the TRANSPOSED weights
         xp, a, z, rr, rx, hh, _ = buf.unbind(0)
         n, r, din, h = ctx.dims
         m_fwd, m = ctx.rows                   # the backward runs on the real-node rows only (m == m_fwd when padded)
@@ -331,21 +342,28 @@ class _GGNNCell(torch.autograd.Function):
             else:
                 dx = dx.view(x.shape)
         if direct:
-            return (dx, None, None) + (None,) * 17
+            return (dx, None, None) + (None,) * 18
         dz0, dz1, dr0, dr1, dh0, dh1 = dws.unbind(0)
         bz, br, bh = dbs.unbind(0)
-        return (dx, None, None, dw_p, dz0, bz, dz1, bz, dr0, br, dr1, br, dh0, bh, dh1, bh, None, None, None, None)
+        return (dx, None, None, dw_p, dz0, bz, dz1, bz, dr0, br, dr1, br, dh0, bh, dh1, bh, None, None, None, None, None)
 
 
 def ggnn_cell(adj: PackedAdj, x, ids, params, drop_p: float = 0.0, drop_seed: int = 0, plan: "RaggedPlan" = None,
-              rows: int = 0):
+              rows: int = 0, score=None):
     """params: (w_p, w_z0, b_z0, w_z1, b_z1, w_r0, b_r0, w_r1, b_r1, w_h0, b_h0, w_h1, b_h1).
     drop_p > 0 applies the cell's input dropout inside the first GEMM (stateless hash mask keyed by drop_seed).
     plan: node-compact layout -- x is (>= rows, din) (or table + ids), the forward computes the first `rows`
-    rows (plan.m_real or plan.m_tot), the backward the plan.m_real real-node rows; returns (rows, h)."""
+    rows (plan.m_real or plan.m_tot), the backward the plan.m_real real-node rows; returns (rows, h).
+    score = (w (h,), p, seed): also returns the GSL word scorer's projection dropout_p(out) . w per row, produced by
+    the last GEMM's epilogue (see `scorer_fusable`); the result is then (out, score_x)."""
     if plan is not None and not rows:
         rows = plan.m_real
-    return _GGNNCell.apply(x, ids, adj, *params, drop_p, drop_seed, plan, rows)
+    return _GGNNCell.apply(x, ids, adj, *params, drop_p, drop_seed, plan, rows, score)
+
+
+def scorer_fusable(h: int) -> bool:
+    """The scorer projection rides in the h-gate GEMM's epilogue when a whole output row lives in one workgroup."""
+    return h % 4 == 0 and 4 <= h <= 320
 
 
 def fused_dropout_ok(din: int, h: int) -> bool:
@@ -376,24 +394,29 @@ def dropout_mask_reference(seed: int, rows: int, cols: int, p: float):
 # --------------------------------------------------------------------------- word scorer + GSL (no gradient)
 @torch.no_grad()
 def scorer_gsl(adj: PackedAdj, feat: torch.Tensor, w_p, gate12: torch.Tensor, k: int, drop_p: float = 0.0,
-               drop_seed: int = 0, plan: "RaggedPlan" = None, collapsed: bool = False):
+               drop_seed: int = 0, plan: "RaggedPlan" = None, collapsed: bool = False, score_x: torch.Tensor = None):
     """GGNN(h->1) score of every node and the top-k keep set (wrapper.py:167-168, :215-219).
-    feat: (N,R,H), or node-compact (N*R, H) incl. the padding rows when `plan` is given.
+    feat: (N,R,H), or node-compact (N*R, H) incl. the padding rows when `plan` is given; alternatively
+    score_x (rows,) = the projections proj(dropout(feat)) already produced by ggnn_cell(..., score=...).
     Returns (score (N,R) fp32, keep (N,W) int64 bit words) -- both in padded node indexing."""
-    feat = _f32(feat.detach())
+    src = score_x if score_x is not None else feat
+    src = _f32(src.detach())
     if plan is not None:
         need = min(plan.m_real + 1, plan.m_tot) if collapsed else plan.m_tot
-        assert feat.dim() == 2 and feat.shape[0] == need, "the scorer needs the padding rows too (they compete in top-k)"
+        assert src.shape[0] == need and src.dim() == (1 if score_x is not None else 2), \
+            "the scorer needs the padding rows too (they compete in top-k)"
         assert not (collapsed and drop_p > 0.0), "collapsed padding rows are an evaluation-mode layout"
-        n, r, h = plan.n, plan.r, feat.shape[1]
+        n, r = plan.n, plan.r
     else:
-        n, r, h = feat.shape
-    score = torch.empty((n, r), device=feat.device, dtype=torch.float32)
-    keep = torch.empty((n, adj.words), device=feat.device, dtype=torch.int64)
+        n, r = adj.n, adj.r
+        assert src.numel() == n * r * (1 if score_x is not None else src.shape[-1])
+    h = w_p.numel()
+    score = torch.empty((n, r), device=src.device, dtype=torch.float32)
+    keep = torch.empty((n, adj.words), device=src.device, dtype=torch.int64)
     w_p = _f32(w_p.detach().reshape(-1))
     gate12 = _f32(gate12.detach())
     call("gh_scorer_gsl", ptr(adj.bits), ptr(adj.dinv), ptr(adj.vals), _plan_args(plan)[0], 1 if (collapsed and plan is not None) else 0,
-         ptr(feat), ptr(w_p), ptr(gate12), n, r, h,
+         None if score_x is not None else ptr(src), ptr(src) if score_x is not None else None, ptr(w_p), ptr(gate12), n, r, h,
          int(k), ptr(score), ptr(keep), float(drop_p), int(drop_seed), stream())
     return score, keep
 
@@ -431,25 +454,25 @@ class _ConcatAtt(torch.autograd.Function):
         dev = right.device
         maskf = _f32(mask.to(torch.float32))
         w1c, w2c = _f32(w1.detach()), _f32(w2.detach())
-        w1t = transposed(w1)
+        w1t = transposed(w1)          # for the backward's dX products
         u = torch.empty((b, ha), device=dev, dtype=torch.float32)
         t = torch.empty((m, ha), device=dev, dtype=torch.float32)
         e = torch.empty((m, heads), device=dev, dtype=torch.float32)
         weights = torch.empty((m, heads) if plan is not None else (b, l, heads), device=dev, dtype=torch.float32)
         attended = torch.empty((b, dr, heads), device=dev, dtype=torch.float32)
         pl = (None, None, 0) if plan is None else (ptr(plan.goff), ptr(plan.rowg), plan.m_real)
-        call("gh_concat_att_fwd", ptr(left), ptr(right), ptr(maskf), *pl, b, l, xl, dr, ha, heads, ptr(w1t), ptr(w2c),
+        call("gh_concat_att_fwd", ptr(left), ptr(right), ptr(maskf), *pl, b, l, xl, dr, ha, heads, ptr(w1c), ptr(w2c),
              ptr(u), ptr(t), ptr(e), ptr(weights), ptr(attended), stream())
         ctx.dims = (b, l, xl, dr, ha, heads, m)
         ctx.plan = plan
         ctx.params = (w1, w2)
         ctx.has_left = left is not None
-        ctx.save_for_backward(left if left is not None else right.new_empty(0), right, w1c, w2c, t, weights)
+        ctx.save_for_backward(left if left is not None else right.new_empty(0), right, w1t, w2c, t, weights)
         return attended, weights
 
     @staticmethod
     def backward(ctx, g_att, g_w):
-        left, right, w1, w2, t, weights = ctx.saved_tensors
+        left, right, w1t, w2, t, weights = ctx.saved_tensors
         b, l, xl, dr, ha, heads, m = ctx.dims
         plan = ctx.plan
         dev = right.device
@@ -469,7 +492,7 @@ class _ConcatAtt(torch.autograd.Function):
         else:
             dw1 = torch.zeros((ha, xl + dr), device=dev, dtype=torch.float32)
             dw2 = torch.zeros((heads, ha), device=dev, dtype=torch.float32)
-        call("gh_concat_att_bwd", ptr(left), ptr(right), *_plan_args(plan), b, l, xl, dr, ha, heads, ptr(w1), ptr(w2), ptr(t),
+        call("gh_concat_att_bwd", ptr(left), ptr(right), *_plan_args(plan), b, l, xl, dr, ha, heads, ptr(w1t), ptr(w2), ptr(t),
              ptr(weights), ptr(g_att), ptr(g_w), ptr(de), ptr(dpre), ptr(du), ptr(dleft), ptr(dright), ptr(dw1),
              ptr(dw2), stream())
         if direct:
@@ -492,8 +515,8 @@ class _Linear(torch.autograd.Function):
         wc = _f32(w.detach())
         y = torch.empty((m, n), device=x.device, dtype=torch.float32)
         bc = _f32(b.detach()) if b is not None else None
-        call("gh_linear_fwd", ptr(x2), ptr(transposed(w)), ptr(bc), ptr(y), m, k, n, stream())
-        ctx.save_for_backward(x2, wc)
+        call("gh_linear_fwd", ptr(x2), ptr(wc), ptr(bc), ptr(y), m, k, n, stream())
+        ctx.save_for_backward(x2, transposed(w))
         ctx.params = (w, b)
         ctx.has_bias = b is not None
         ctx.xshape = x.shape
@@ -501,9 +524,9 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        x2, w = ctx.saved_tensors
+        x2, wt = ctx.saved_tensors
         m, k = x2.shape
-        n = w.shape[0]
+        n = wt.shape[1]
         g2 = _f32(g).reshape(m, n)
         _lib.ensure_workspace(g.device)
         dx = torch.empty((m, k), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
@@ -514,7 +537,7 @@ class _Linear(torch.autograd.Function):
         else:
             dw = torch.zeros((n, k), device=g.device, dtype=torch.float32)
             db = torch.zeros((n,), device=g.device, dtype=torch.float32) if ctx.has_bias else None
-        call("gh_linear_bwd", ptr(x2), ptr(w), ptr(g2), m, k, n, ptr(dx), ptr(dw), ptr(db), stream())
+        call("gh_linear_bwd", ptr(x2), ptr(wt), ptr(g2), m, k, n, ptr(dx), ptr(dw), ptr(db), stream())
         dxo = dx.view(ctx.xshape) if dx is not None else None
         if direct:
             return dxo, None, None

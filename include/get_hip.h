@@ -52,7 +52,7 @@ extern "C" {
 
 typedef void* gh_stream_t;
 
-#define GH_ABI_VERSION 3
+#define GH_ABI_VERSION 4
 
 int gh_abi_version(void);
 /* Thread-local message of the last failing call on this thread (never NULL). */
@@ -83,7 +83,9 @@ int gh_spmm(const uint64_t* bits, const float* dinv, const float* vals, const ui
             const int32_t* goff, int m_real, const float* x, float* y, int n, int r, int h, int transpose,
             int accumulate, gh_stream_t stream);
 
-/* ---- weight packing: W[n_out][n_in] -> Wt[n_in][n_out] (k-major operand of the MFMA GEMMs) ---- */
+/* ---- weight packing: W[n_out][n_in] -> Wt[n_in][n_out] ----
+ * The MFMA GEMMs take both operands contraction-contiguous: forward products x.W^T use the weight exactly as
+ * PyTorch stores it, the backward's dX = g.W needs the transposed copy made here (refreshed once per optimiser step). */
 int gh_transpose(const float* w, float* wt, int rows, int cols, gh_stream_t stream);
 /* All weights of a model in one launch: n matrices, HOST arrays of device pointers and sizes. */
 int gh_transpose_batch(int n, const void* const* src_host, void* const* dst_host, const int* rows_host,
@@ -92,25 +94,31 @@ int gh_transpose_batch(int n, const void* const* src_host, void* const* dst_host
 /* ---- a2  GGNN cell: Models/BiDAF/wrapper.py:188-208 GGNN.forward ----
  * Input rows are x[m][din] (m = n*r), or emb[ids[m]][din] when ids != NULL (fused
  * embedding gather, graph_based_semantic_structure.py:100,150).
- * wt_*: TRANSPOSED weights (gh_transpose of the reference's linear.weight):
- *   wt_p[din][h]; wt_z0,wt_z1,wt_r0,wt_r1,wt_h0,wt_h1 [h][h].
+ * w_*: the reference's linear.weight tensors as stored: w_p[h][din]; w_z0,w_z1,w_r0,w_r1,w_h0,w_h1 [h][h].
  * b_z = bz0+bz1, b_r = br0+br1, b_h = bh0+bh1 (each [h]).
  * Saved for backward (all [m][h]): xp, a, z, r, rx, hh.  out [m][h].
  * drop_p > 0: the cell's input dropout (wrapper.py:185-190) is applied inside the first GEMM's loader with a
  * stateless mask -- element (m,k) kept iff hash(drop_seed, m*din+k) >= drop_p*2^32, scaled by 1/(1-drop_p);
  * pass the same (drop_p, drop_seed) to the backward.  Needs din % 4 == 0 and h % 4 == 0.
  * goff != NULL: node-compact layout; the cell runs on the first m_rows rows (m_real <= m_rows <= n*r; rows beyond
- * m_real are padding nodes: no neighbours).  goff == NULL: m_real/m_rows are ignored, m = n*r. */
+ * m_real are padding nodes: no neighbours).  goff == NULL: m_real/m_rows are ignored, m = n*r.
+ * score_w/score_x (both or neither; needs h % 4 == 0 and h <= 320): the GSL word scorer that consumes this cell's
+ * output (wrapper.py:167, GGNN(h->1)) starts with proj(dropout(out)), a [m][h] x [h] product; with score_w[h] =
+ * that proj weight the last GEMM's epilogue writes score_x[m] = dropout(out)[m] . score_w while `out` is still in
+ * registers (mask = the scorer's own: hash(score_drop_seed, m*h+k) >= score_drop_p*2^32), and gh_scorer_gsl then
+ * takes score_x instead of re-reading `out`. */
 int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
                      const int32_t* goff, int m_real, int m_rows,
                      const float* x, const int32_t* ids, int n, int r, int din, int h,
-                     const float* wt_p, const float* wt_z0, const float* wt_z1, const float* wt_r0,
-                     const float* wt_r1, const float* wt_h0, const float* wt_h1,
+                     const float* w_p, const float* w_z0, const float* w_z1, const float* w_r0,
+                     const float* w_r1, const float* w_h0, const float* w_h1,
                      const float* b_z, const float* b_r, const float* b_h,
                      float* xp, float* a, float* z, float* rr, float* rx, float* hh, float* out,
-                     float drop_p, uint32_t drop_seed, gh_stream_t stream);
+                     float drop_p, uint32_t drop_seed,
+                     const float* score_w, float* score_x, float score_drop_p, uint32_t score_drop_seed,
+                     gh_stream_t stream);
 
-/* Backward of the cell.  w_*: the reference's UNtransposed weights [h][h] / w_p[h][din].
+/* Backward of the cell.  wt_*: TRANSPOSED weights (gh_transpose of linear.weight): wt_p[din][h], the others [h][h].
  * g [m][h] = dL/dout.  Scratch (all [m][h]): dhp, dzp, drp, dxp, da.
  * Outputs: dx [m][din] (may be NULL: frozen embedding), and ACCUMULATED (+=) into
  * dw_p[h][din], dw_z0..dw_h1 [h][h], db_z[h], db_r[h], db_h[h]  (caller zeroes them, or hands the
@@ -121,8 +129,8 @@ int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const float* vals,
 int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
                      const int32_t* goff, int m_real,
                      const float* x, const int32_t* ids, int n, int r, int din, int h,
-                     const float* w_p, const float* w_z0, const float* w_z1, const float* w_r0,
-                     const float* w_r1, const float* w_h0, const float* w_h1,
+                     const float* wt_p, const float* wt_z0, const float* wt_z1, const float* wt_r0,
+                     const float* wt_r1, const float* wt_h0, const float* wt_h1,
                      const float* xp, const float* a, const float* z, const float* rr, const float* rx,
                      const float* hh, const float* g,
                      float* dhp, float* dzp, float* drp, float* dxp, float* da,
@@ -137,9 +145,11 @@ int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const float* vals,
  * drop_p/drop_seed: the scorer cell's own input dropout in training mode (same stateless mask as above).
  * goff != NULL: feat is node-compact [n*r][h] INCLUDING the padding rows (they compete in the top-k).
  * pads_collapsed (with goff, drop_p == 0 only): without dropout all padding rows of a batch are identical, so feat
- * holds just ONE of them, at row goff[n] (feat is [goff[n] + 1][h]); every padding node scores with that row. */
+ * holds just ONE of them, at row goff[n] (feat is [goff[n] + 1][h]); every padding node scores with that row.
+ * Exactly one of feat / score_x is non-NULL: score_x[rows] = the projections proj(dropout(feat)) already produced by
+ * gh_ggnn_cell_fwd's epilogue (same row indexing as feat; w_p, h and the dropout arguments are then unused). */
 int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const int32_t* goff, int pads_collapsed,
-                  const float* feat, const float* w_p, const float* gate, int n, int r, int h, int k,
+                  const float* feat, const float* score_x, const float* w_p, const float* gate, int n, int r, int h, int k,
                   float* score, uint64_t* keep, float drop_p, uint32_t drop_seed, gh_stream_t stream);
 /* GSL alone on given scores (GSL.forward on arbitrary score input). */
 int gh_gsl_topk(const float* score, int n, int r, int k, uint64_t* keep, gh_stream_t stream);
@@ -150,21 +160,21 @@ int gh_adj_unpack(const uint64_t* bits, const float* dinv, const float* vals, co
 /* ---- a5/a6  concat attention: thirdparty/two_branches_attention.py:121-148 (left != NULL) and
  *      thirdparty/self_attention.py:75-100 (left == NULL) ----
  * left [b][xl] (or NULL, xl = 0), right [b][l][dr], mask [b][l] float (0 = padded).
- * w1t = transpose of linear1.weight: [xl+dr][ha]; w2 = linear2.weight [heads][ha] (heads <= 8).
+ * w1 = linear1.weight [ha][xl+dr] as stored; w2 = linear2.weight [heads][ha] (heads <= 8).
  * Saved: u [b][ha] (left branch, hoisted out of the per-token product), t [b*l][ha] (tanh), e [b*l][heads].
  * Out: weights [b][l][heads], attended [b][dr][heads].
  * goff/rowg != NULL (both): right, mask, t, e, weights are node-compact with m_real rows, pair g owning rows
  * [goff[g], goff[g+1]) (at most l of them) and rowg[row] = g; softmax runs over the pair's real rows only. */
 int gh_concat_att_fwd(const float* left, const float* right, const float* mask, const int32_t* goff,
                       const int32_t* rowg, int m_real, int b, int l, int xl, int dr,
-                      int ha, int heads, const float* w1t, const float* w2,
+                      int ha, int heads, const float* w1, const float* w2,
                       float* u, float* t, float* e, float* weights, float* attended, gh_stream_t stream);
-/* Backward.  w1 = linear1.weight [ha][xl+dr] untransposed.  g_att [b][dr][heads], g_w [b][l][heads] or NULL.
+/* Backward.  w1t = transpose of linear1.weight: [xl+dr][ha].  g_att [b][dr][heads], g_w [b][l][heads] or NULL.
  * Scratch: de [b*l][heads], dpre [b*l][ha], du [b][ha].
  * Out: dleft [b][xl] (NULL ok), dright [b][l][dr]; ACCUMULATED: dw1 [ha][xl+dr], dw2 [heads][ha]. */
 int gh_concat_att_bwd(const float* left, const float* right, const int32_t* goff, int m_real, int b, int l, int xl,
                       int dr, int ha, int heads,
-                      const float* w1, const float* w2, const float* t, const float* weights,
+                      const float* w1t, const float* w2, const float* t, const float* weights,
                       const float* g_att, const float* g_w,
                       float* de, float* dpre, float* du,
                       float* dleft, float* dright, float* dw1, float* dw2, gh_stream_t stream);
@@ -185,10 +195,10 @@ int gh_set_gemm_mode(int mode);
 int gh_set_workspace(void* ptr, int64_t bytes);
 
 /* ---- plain linear y = x W^T + b (model head, graph_based_semantic_structure.py:69-72) ---- */
-int gh_linear_fwd(const float* x, const float* wt, const float* bias, float* y, int m, int k, int n,
+int gh_linear_fwd(const float* x, const float* w, const float* bias, float* y, int m, int k, int n,
                   gh_stream_t stream);
-/* dx = g W (NULL ok); dw += g^T x; db += colsum(g) (NULL ok). */
-int gh_linear_bwd(const float* x, const float* w, const float* g, int m, int k, int n,
+/* dx = g W (NULL ok; wt = W^T [k][n]); dw += g^T x; db += colsum(g) (NULL ok). */
+int gh_linear_bwd(const float* x, const float* wt, const float* g, int m, int k, int n,
                   float* dx, float* dw, float* db, gh_stream_t stream);
 
 /* ---- a8  ragged helpers: Models/FCWithEvidences/basic_fc_model.py:80-121 ----
