@@ -49,10 +49,14 @@ class NativeBatch:
         if compact is None:
             compact = os.environ.get("GET_AMD_PADDED", "0") != "1"
         self.compact = bool(compact)
-        et = np.asarray(evd_tokens.cpu() if torch.is_tensor(evd_tokens) else evd_tokens)
-        el = np.clip(np.asarray(evd_len.cpu() if torch.is_tensor(evd_len) else evd_len), 0, et.shape[1] if et.ndim == 2 else 0)
-        self.evd_nodes_host = np.array([len(set(row[:n].tolist())) for row, n in zip(et, el)], dtype=np.int64)
-        self.m_real = int(self.evd_nodes_host.sum())
+        # ... which the device graph build reports (n_nodes).  One launch + one 4-byte read-back when the batch is
+        # CONSTRUCTED -- the stage a loader runs one batch ahead of the training step -- instead of a per-row Python
+        # set() over the token lists on the host.
+        if self.b1 > 0:
+            _, _, d_n = ops.graph_build(self.evd_tokens, self.evd_len, self.window)
+            self.m_real = int(d_n.sum().item())
+        else:
+            self.m_real = 0
 
     def inputs(self):
         """Per-step device work: token ids -> (query node ids, padded document ids, kargs) for

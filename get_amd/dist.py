@@ -19,7 +19,9 @@ DEAD_PREFIXES = ("bilstm.", "query_bilstm.", "trans.", "ggnn_with_gsl.word_score
 # branch and the claim-source table, which autograd schedules after it).  Everything else -- head, both attentions,
 # the article-source table and the second evidence cell, 76 % of the bucket -- is final once the gradient w.r.t. the
 # first cell's output exists, so its share of the all-reduce can run underneath the rest of the backward.
-LATE_PREFIXES = ("ggnn_with_gsl.feat_prop1.", "ggnn4claim_1.", "claim_source_embs.")
+# The word-embedding table belongs here too: when it is trainable (embedding_freeze=False) its gradient is scattered
+# by the FIRST evidence cell's and the claim cell's backward, i.e. after the milestone.
+LATE_PREFIXES = ("ggnn_with_gsl.feat_prop1.", "ggnn4claim_1.", "claim_source_embs.", "embedding.")
 
 
 def live_parameters(model: torch.nn.Module):
@@ -40,7 +42,7 @@ class FlatTrainer:
     live parameter are views into them, so autograd accumulates straight into the all-reduce bucket."""
 
     def __init__(self, model: torch.nn.Module, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 process_group=None, late_prefixes: Sequence[str] = LATE_PREFIXES):
+                 process_group=None, late_prefixes: Sequence[str] = LATE_PREFIXES, check_overlap: bool = False):
         self.model = model
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.group = process_group
@@ -50,6 +52,10 @@ class FlatTrainer:
         live = [x for x in live if not x[0].startswith(late_prefixes)] + [x for x in live if x[0].startswith(late_prefixes)]
         self._early_work = None
         self._overlap_ok = True
+        # check_overlap: verify on every step that no "early" gradient changed after its all-reduce was started (one
+        # extra reduction + host sync per step: a debugging aid for new model variants, off in production)
+        self._check_overlap = bool(check_overlap)
+        self._early_snapshot = None
         self.live_names: List[str] = [n for n, _ in live]
         self.params = [p for _, p in live]
         # every parameter starts on a 256-byte boundary of the flat buffers: the kernels take weights and gradients
@@ -107,8 +113,17 @@ class FlatTrainer:
 
     def allreduce_early_async(self):
         """Start the all-reduce of the early-final part of the bucket (call it once those gradients are complete in
-        stream order, e.g. from the hook ``attach_overlap`` installs).  No-op for a single rank or when already started."""
-        if self.world > 1 and self._early_work is None and 0 < self.n_early < self.numel and self._overlap_ok:
+        stream order, e.g. from the hook ``attach_overlap`` installs).  No-op for a single rank.  A second call while
+        the first collective is still pending means a second backward pass ran before ``allreduce()`` / ``step()``
+        (gradient accumulation): its early gradients would be added to an already reduced range, so this is rejected
+        -- accumulate with the overlap detached, or call ``allreduce()`` after every backward."""
+        if self._early_work is not None:
+            raise RuntimeError("get_amd: a second backward pass reached the all-reduce milestone while the first early "
+                               "all-reduce is still pending; gradient accumulation needs detach_overlap() (one "
+                               "all-reduce per step) or an allreduce() after every backward")
+        if self.world > 1 and 0 < self.n_early < self.numel and self._overlap_ok:
+            if self._check_overlap:
+                self._early_snapshot = self.flat_g[:self.n_early].clone()
             try:
                 self._early_work = dist.all_reduce(self.flat_g[:self.n_early], op=dist.ReduceOp.SUM, group=self.group,
                                                    async_op=True)
@@ -125,6 +140,16 @@ class FlatTrainer:
             if self._early_work is not None:
                 self._early_work.wait()
                 self._early_work = None
+                if self._check_overlap and self._early_snapshot is not None:
+                    # every rank contributed its snapshot, so the reduced range must equal the sum of the snapshots:
+                    # reduce the snapshots again and compare (a gradient that landed after the milestone shows up here)
+                    ref = self._early_snapshot
+                    dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.group)
+                    bad = float((ref - self.flat_g[:self.n_early]).abs().max())
+                    self._early_snapshot = None
+                    if bad != 0.0:
+                        raise RuntimeError(f"get_amd: an early-bucket gradient changed after its all-reduce started (max "
+                                           f"diff {bad:.3e}); a parameter is missing from late_prefixes")
                 dist.all_reduce(self.flat_g[self.n_early:], op=dist.ReduceOp.SUM, group=self.group)
             else:
                 dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
@@ -137,6 +162,14 @@ class FlatTrainer:
         if module is None:
             raise ValueError("attach_overlap: no module with a grad_milestone_hook slot")
         module.grad_milestone_hook = self.allreduce_early_async
+        self._overlap_module = module
+
+    def detach_overlap(self):
+        """Back to one all-reduce per step (required for gradient accumulation over several backward passes)."""
+        m = getattr(self, "_overlap_module", None)
+        if m is not None:
+            m.grad_milestone_hook = None
+            self._overlap_module = None
 
     def step(self):
         """all-reduce + fused Adam on the flat bucket (gradient averaged over ranks inside the kernel)."""

@@ -50,6 +50,17 @@ class SynthConfig:
         }
 
 
+# Evidences per claim on Snopes: histogram over counts 1..26 of the 782 claims of the reference's
+# formatted_data/declare/Snopes/mapped_data/5fold/test_0.tsv (mean 6.92, max 26 -- SURVEY.md 8(d) "realistic series").
+SNOPES_EVD_HIST = (107, 94, 79, 69, 60, 44, 57, 32, 38, 28, 23, 23, 18, 15, 14, 14, 14, 6, 13, 4, 9, 5, 6, 6, 2, 2)
+
+
+def snopes_evidence_counts(rng: np.random.Generator, n_claims: int) -> np.ndarray:
+    """Evidence counts drawn from the empirical Snopes histogram."""
+    h = np.asarray(SNOPES_EVD_HIST, dtype=np.float64)
+    return (rng.choice(len(h), size=n_claims, p=h / h.sum()) + 1).astype(np.int64)
+
+
 def _zipf_probs(n: int, s: float = 1.1) -> np.ndarray:
     p = 1.0 / np.arange(1, n + 1, dtype=np.float64) ** s
     return p / p.sum()

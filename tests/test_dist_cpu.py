@@ -157,3 +157,63 @@ def test_shard_claims_partitions():
     got = sorted(i for r in range(4) for i in shard_claims(256, r, 4))
     assert got == list(range(256))
     assert len(shard_claims(256, 3, 8)) == 32
+
+
+def _worker_second_backward(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = Toy2()
+    tr = FlatTrainer(model, late_prefixes=("late.",))
+    tr.attach_overlap(model)
+    torch.manual_seed(7)
+    x, y = torch.randn(4, 6), torch.randint(0, 3, (4,))
+    tr.zero_grad()
+    torch.nn.functional.cross_entropy(model(x), y).backward()
+    try:                                                  # gradient accumulation under overlap must be rejected loudly
+        torch.nn.functional.cross_entropy(model(x), y).backward()
+        ok = False
+    except RuntimeError as e:
+        ok = "second backward" in str(e)
+    tr.allreduce()                                        # the pending collective is still consumed cleanly
+    tr.detach_overlap()                                   # ... and accumulation works once the overlap is detached
+    tr.zero_grad()
+    for _ in range(2):
+        torch.nn.functional.cross_entropy(model(x), y).backward()
+    tr.allreduce()
+    if rank == 0:
+        out.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_second_backward_under_overlap_is_rejected():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_second_backward, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_trainable_word_embedding_sits_in_the_late_range():
+    """embedding.weight receives its gradient from the first evidence cell / the claim cell, i.e. AFTER the
+    overlap milestone -- it must not be part of the early all-reduce."""
+    from get_amd import modules
+    from get_amd.synth import make_embeddings
+    from oracle.cases_model import MODEL_CASES
+    cfg, seed = MODEL_CASES["small"]
+    emb, art, clm = make_embeddings(cfg, seed)
+    params = cfg.model_params(emb, art, clm)
+    params["embedding_freeze"] = False
+    model = modules.Graph_basedSemantiStructure(params)
+    tr = FlatTrainer(model)
+    assert "embedding.weight" in tr.live_names
+    off = 0
+    for n, p in zip(tr.live_names, tr.params):
+        if n == "embedding.weight":
+            assert off >= tr.n_early, "trainable embedding table landed in the early all-reduce range"
+        off += (p.numel() + 63) // 64 * 64

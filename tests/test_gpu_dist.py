@@ -1,0 +1,119 @@
+"""The N>1 data-parallel path with the REAL model on a GPU: 2 processes sharing cuda:0 (gloo stands in for RCCL on a
+1-GPU box), claims sharded by `shard_claims`, gradients in the flat bucket, the early part of the all-reduce started
+from inside backward (`attach_overlap`).  The averaged bucket must equal the single-process gradient of the union
+batch (1e-5 relative), and one fused Adam step must leave both replicas bit-identical."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(cfg, seed, dev, claims=None, compact=True):
+    from get_amd import modules
+    from get_amd.batch import NativeBatch
+    from get_amd.synth import make_embeddings, make_raw_batch, make_state_dict
+    emb, art, clm = make_embeddings(cfg, seed)
+    model = modules.Graph_basedSemantiStructure(cfg.model_params(emb, art, clm))
+    full = model.state_dict()
+    full.update({k: torch.from_numpy(v) for k, v in make_state_dict(cfg, seed).items()})
+    model.load_state_dict(full, strict=True)
+    model = model.to(dev).train(False)          # evaluation mode: no dropout, so every rank/union run is deterministic
+    raw = make_raw_batch(cfg, seed)
+    counts = raw["evd_counts"]
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    if claims is None:
+        claims = range(cfg.batch)
+    cl = list(claims)
+    rows = np.concatenate([np.arange(offs[c], offs[c + 1]) for c in cl])
+    nb = NativeBatch(raw["claim_tokens"][cl], raw["claim_len"][cl], raw["evd_tokens"][rows], raw["evd_len"][rows],
+                     counts[cl], raw["doc_sources"][cl], raw["query_sources"][cl], raw["labels"][cl], window=cfg.window,
+                     n_max=cfg.fixed_num_evidences, device=dev, compact=compact)
+    return model, nb
+
+
+def _cfg():
+    from get_amd.synth import SynthConfig
+    return SynthConfig(batch=8, emb_dim=64, hidden=64, vocab=500, n_article_src=20, n_claim_src=10, src_dim=16,
+                       evd_counts=[3, 7, 1, 30, 12, 5, 2, 9])
+
+
+def _worker(rank, world, port, q, compact):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from get_amd.dist import FlatTrainer, shard_claims
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg, seed = _cfg(), 5
+        model, nb = _make(cfg, seed, "cuda:0", shard_claims(cfg.batch, rank, world), compact)
+        tr = FlatTrainer(model, check_overlap=True)
+        tr.attach_overlap()
+        for step in range(2):
+            tr.zero_grad()
+            q_, d_, k_ = nb.inputs()
+            loss = torch.nn.functional.cross_entropy(model(q_, d_, **k_), nb.labels)
+            loss.backward()
+            assert tr._early_work is not None, "the milestone hook did not start the early all-reduce"
+            if step == 0:
+                tr.allreduce()
+                g_avg = (tr.flat_g / world).cpu().clone()
+                q.put(("grad", rank, g_avg.numpy(), list(tr.live_names), [int(p.numel()) for p in tr.params]))
+                # the same reduced bucket feeds the optimiser: finish the step by hand (allreduce() already ran)
+                from get_amd import ops
+                tr.t += 1
+                ops.adam_step_flat(tr.flat_p, tr.flat_g, tr.flat_m, tr.flat_v, tr.t, lr=tr.lr, betas=tr.betas, eps=tr.eps,
+                                   weight_decay=tr.weight_decay, grad_scale=1.0 / world)
+                ops.refresh_transposes(tr._matrices)
+            else:
+                tr.step()
+        q.put(("params", rank, tr.flat_p.cpu().numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("compact", [True, False])
+def test_two_ranks_real_model_match_the_union_batch(compact):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, compact)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(4)]
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    grads = {r: (g, names, sizes) for kind, r, g, names, sizes in [x for x in got if x[0] == "grad"]}
+    params = {x[1]: x[2] for x in got if x[0] == "params"}
+    assert np.array_equal(grads[0][0], grads[1][0]), "ranks disagree on the reduced bucket"
+    assert np.array_equal(params[0], params[1]), "replicas diverged after two optimiser steps"
+    # single process, union batch, plain autograd (no trainer, no bucket)
+    cfg, seed = _cfg(), 5
+    model, nb = _make(cfg, seed, "cuda:0", None, compact)
+    q_, d_, k_ = nb.inputs()
+    torch.nn.functional.cross_entropy(model(q_, d_, **k_), nb.labels).backward()
+    named = dict(model.named_parameters())
+    g, names, sizes = grads[0]
+    off = 0
+    worst = 0.0
+    for n, sz in zip(names, sizes):
+        ref = named[n].grad.detach().reshape(-1).cpu().numpy().astype(np.float64)
+        mine = g[off:off + sz].astype(np.float64)
+        scale = max(np.abs(ref).max(), 1e-8)
+        worst = max(worst, np.abs(mine - ref).max() / scale)
+        off += (sz + 63) // 64 * 64
+    assert worst <= 1e-5, f"averaged 2-rank gradient differs from the union-batch gradient by {worst:.2e} (relative)"

@@ -491,3 +491,21 @@ def test_training_loop_overfits_a_small_batch():
         losses.append(float(loss.item()))
     assert all(np.isfinite(losses))
     assert np.mean(losses[-5:]) < 0.35 * np.mean(losses[:3]), losses[::6]
+
+
+def test_native_batch_counts_nodes_like_convert_text():
+    """m_real sizes every launch of the compact layout: it must equal the sum of convert_text's `length_`
+    (interactions.py:351), also for ragged evidence counts, short texts and repeated tokens."""
+    from get_amd.batch import NativeBatch
+    from get_amd.synth import SynthConfig
+    cfg = SynthConfig(batch=5, n_evd=0, vocab=60, evd_counts=[1, 7, 30, 2, 11])
+    raw = make_raw_batch(cfg, 3)
+    raw["evd_len"][0] = 1
+    raw["evd_tokens"][1, :] = 5                       # one token repeated: a single node
+    nb = NativeBatch(raw["claim_tokens"], raw["claim_len"], raw["evd_tokens"], raw["evd_len"], raw["evd_counts"],
+                     raw["doc_sources"], raw["query_sources"], raw["labels"], window=cfg.window,
+                     n_max=cfg.fixed_num_evidences, device=DEV)
+    want = [O.convert_text([int(t) for t in row], cfg.len_right, int(n), cfg.window)[2]
+            for row, n in zip(raw["evd_tokens"], raw["evd_len"])]
+    assert nb.m_real == sum(want) and want[0] == 1 and want[1] == 1
+    assert nb.b1 == 51 and nb.compact in (True, False)
