@@ -387,7 +387,7 @@ def main():
     per_rank = args.batch
     if args.global_batch > 0:
         per_rank = len(shard_claims(args.global_batch, rank, world))
-    cfg_in = SynthConfig(batch=per_rank, n_evd=args.n_evd, len_right=args.len_right, hidden=args.hidden,
+    cfg_in = SynthConfig(batch=per_rank, n_evd=args.n_evd, len_right=args.len_right, hidden=args.hidden, emb_dim=args.hidden,
                          word_heads=args.word_heads, window=args.window, gsl_rate=args.gsl_rate)
     wl = build_workload(seed=20240229 + rank, device=device, cfg=cfg_in, compact=False if args.padded else None,
                         n_batches=args.batches, evd_dist=args.evd_dist)

@@ -36,6 +36,7 @@ class NativeBatch:
         self.claim_tokens, self.claim_len = t(claim_tokens).int(), t(claim_len).int()
         self.evd_tokens, self.evd_len = t(evd_tokens).int(), t(evd_len).int()
         self.counts = t(counts_host)
+        self._counts_host = counts_host
         self.doc_sources, self.query_sources, self.labels = t(doc_sources), t(query_sources), t(labels)
         self.b, self.b1 = int(counts_host.shape[0]), int(counts_host.sum())
         assert self.evd_tokens.shape[0] == self.b1, "evd_tokens must hold sum(evd_counts) rows"
@@ -98,25 +99,38 @@ def kargs_from_reference_tensors(query_lens, evd_doc_contents, evd_docs_adj, que
     return kargs
 
 
+    def subset(self, lo: int, hi: int) -> "NativeBatch":
+        """Claims [lo, hi) of this batch as a batch of their own (device-side slices; evaluation in chunks)."""
+        offs = np.concatenate([[0], np.cumsum(self._counts_host)])
+        r0, r1 = int(offs[lo]), int(offs[hi])
+        return NativeBatch(self.claim_tokens[lo:hi], self.claim_len[lo:hi], self.evd_tokens[r0:r1], self.evd_len[r0:r1],
+                           self._counts_host[lo:hi], self.doc_sources[lo:hi], self.query_sources[lo:hi], self.labels[lo:hi],
+                           window=self.window, n_max=self.n_max, device=self.device, compact=self.compact)
+
+
 @torch.no_grad()
 def batched_predict(model, batch: "NativeBatch", claims_per_call: int = 0):
     """Evaluation without the reference's one-claim-per-forward loop
     (Fitting/FittingFC/char_man_fitter_query_repr1.py:260-364 runs ~780 B=1 forwards per validation pass):
-    all claims of `batch` go through the ragged kernels in one forward (or in chunks of `claims_per_call`).
+    all claims of `batch` go through the ragged kernels in one forward, or in chunks of `claims_per_call` claims
+    (claims are independent, so chunking changes nothing but the peak memory).
 
     Returns (phi (B,C), word_att list of (n_b, R, hw) tensors per claim, evd_att (B, n_max, he)) -- the
     observables `_prepare_error_analysis` consumes (:422-472), with each head's weights summing to one."""
     was_training = model.training
     model.train(False)
     try:
-        query, document, kargs = batch.inputs()
-        kargs = dict(kargs)
-        kargs[K.OutputRankingKey] = True
-        if claims_per_call and claims_per_call < batch.b:
-            raise NotImplementedError("chunked evaluation: build one NativeBatch per chunk")
-        phi, (word_w, evd_w) = model(query, document, **kargs)
-        counts = batch.counts.cpu().tolist()
-        word_per_claim = list(torch.split(word_w, counts, dim=0))
-        return phi, word_per_claim, evd_w
+        step = batch.b if not claims_per_call or claims_per_call >= batch.b else int(claims_per_call)
+        phis, words, evds = [], [], []
+        for lo in range(0, batch.b, step):
+            part = batch if step == batch.b else batch.subset(lo, min(batch.b, lo + step))
+            query, document, kargs = part.inputs()
+            kargs = dict(kargs)
+            kargs[K.OutputRankingKey] = True
+            phi, (word_w, evd_w) = model(query, document, **kargs)
+            phis.append(phi)
+            evds.append(evd_w)
+            words += list(torch.split(word_w, part._counts_host.tolist(), dim=0))
+        return torch.cat(phis, 0), words, torch.cat(evds, 0)
     finally:
         model.train(was_training)

@@ -78,7 +78,10 @@ def g6_inputs(ci):
     mask = (np.arange(l)[None, :] < valid[:, None]).astype(np.float32)
     w1 = (rng.standard_normal((ha, d)) / np.sqrt(d)).astype(np.float32)
     w2 = (rng.standard_normal((heads, ha)) / np.sqrt(ha)).astype(np.float32)
-    return dict(tsr=tsr, valid=valid, mask=mask, w1=w1, w2=w2)
+    # upstream gradients for the backward fixture (drawn AFTER everything else, so the forward inputs keep their values)
+    g_att = rng.standard_normal((b, heads, d)).astype(np.float32)      # attended is (B, C, D) in self_attention.py:98
+    g_w = rng.standard_normal((b, l, heads)).astype(np.float32)
+    return dict(tsr=tsr, valid=valid, mask=mask, w1=w1, w2=w2, g_att=g_att, g_w=g_w)
 
 
 def g3_scores(ci, r, ties, b=3):

@@ -36,7 +36,7 @@ from oracle import cases  # noqa: E402
 from oracle.assemble import assemble_inputs, reference_kargs  # noqa: E402
 from oracle.cases_model import MODEL_CASES  # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("GET_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")
 torch.set_num_threads(8)
 
 
@@ -249,10 +249,21 @@ def g5_g6():
         tsr, valid, mask, w1, w2 = c["tsr"], c["valid"], c["mask"], c["w1"], c["w2"]
         mod = ref_sa.MultiHeadSelfAttentionICLR2017Extend(inp_dim=d, out_dim=ha, num_heads=heads)
         mod.load_state_dict({"linear1.weight": torch.from_numpy(w1), "linear2.weight": torch.from_numpy(w2)})
-        with torch.no_grad():
-            att, w = mod(torch.from_numpy(tsr), torch.from_numpy(mask), return_att_weights=True)
+        tt = torch.from_numpy(tsr).requires_grad_(True)
+        att, w = mod(tt, torch.from_numpy(mask), return_att_weights=True)
+        # backward of the `left is None` branch (self_attention.py:75-100): d tsr and both weight gradients
+        ((att * torch.from_numpy(c["g_att"])).sum() + (w * torch.from_numpy(c["g_w"])).sum()).backward()
         store[f"c{ci}_valid"] = valid
-        store[f"c{ci}_att"], store[f"c{ci}_w"] = att.numpy(), w.numpy()
+        store[f"c{ci}_att"], store[f"c{ci}_w"] = att.detach().numpy(), w.detach().numpy()
+        if tsr.size <= 40000:
+            store[f"c{ci}_dtsr"] = tt.grad.numpy()
+        else:
+            put_summary(store, f"c{ci}_dtsr", tt.grad)
+        for pname, prm in mod.named_parameters():
+            if prm.numel() <= 4096:
+                store[f"c{ci}_g::{pname}"] = prm.grad.numpy()
+            else:
+                put_summary(store, f"c{ci}_g::{pname}", prm.grad)
         meta.append(dict(b=b, l=l, d=d, ha=ha, heads=heads, seed=600 + ci))
     store["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, "g6_self_att.npz"), **store)
@@ -317,7 +328,7 @@ def g7_g8():
             opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-3)
             opt.step()
             for pname, prm in model.named_parameters():
-                if prm.requires_grad:
+                if prm.grad is not None:      # Adam skips grad-None parameters; the dead ones are unseeded noise
                     store[f"adam::{pname}"] = prm.detach().numpy()
         store["meta"] = np.frombuffer(json.dumps(meta, default=str).encode(), dtype=np.uint8)
         np.savez_compressed(os.path.join(OUT, f"g7_model_{name}.npz"), **store)

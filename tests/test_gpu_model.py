@@ -151,6 +151,57 @@ def test_bench_shape_forward_backward_properties():
     assert float((phi[:4].detach().cpu() - phi_o).abs().max()) <= 1e-4
 
 
+def _full_size_properties(cfg, seed, compact, slice_claims, min_rows):
+    """Size-independent properties of one forward + backward at a BASELINE shape, plus an oracle slice (logits 1e-4,
+    word-attention weights 1e-5) of the first `slice_claims` claims of the same batch."""
+    from bench import build_workload
+    from get_amd import _lib
+    wl = build_workload(seed=seed, device=DEV, cfg=cfg, compact=compact)
+    assert wl["compact"] == compact
+    model = wl["model"].train(False)
+    b, n, r, hw, he = cfg.batch, cfg.fixed_num_evidences, cfg.len_right, cfg.word_heads, cfg.evd_heads
+    b1 = int(wl["b1"])
+    rows = wl["m_real"] if compact else b1 * r
+    assert rows >= min_rows, "the shape must take the big-tile GEMM path"
+    _lib.gemm_path_counters(reset=True)
+    phi, (ww, ew) = model(wl["query"], wl["document"], **dict(wl["kargs"], output_ranking=True))
+    assert phi.shape == (b, 2) and torch.isfinite(phi).all()
+    assert ww.shape == (b1, r, hw) and ew.shape == (b, n, he)
+    assert torch.allclose(ww.sum(1), torch.ones(b1, hw, device=DEV), atol=1e-5)
+    counts = torch.as_tensor(wl["raw"]["evd_counts"])
+    assert torch.allclose(ew.sum(1), torch.ones(b, he, device=DEV), atol=1e-5)
+    slot_pad = (torch.arange(n)[None, :] >= counts[:, None]).to(DEV)
+    assert float(ew.detach()[slot_pad].abs().max() if slot_pad.any() else 0.0) == 0.0      # padded evidence slots
+    pad = wl["kargs"]["doc_content_without_padding_evidences"] < 1
+    assert float(ww.detach()[pad].abs().max()) == 0.0                                          # padded graph nodes
+    torch.nn.functional.cross_entropy(phi, wl["labels"]).backward()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), k
+    assert _lib.gemm_path_counters()["generic_large"] == 0, "a large GEMM fell off the MFMA fast path"
+    sub = wl["oracle_slice"](slice_claims)
+    nb1 = int(wl["raw"]["evd_counts"][:slice_claims].sum())
+    assert float((phi[:slice_claims].detach().cpu() - sub["phi"]).abs().max()) <= 1e-4
+    assert float((ww[:nb1].detach().cpu() - sub["word_w"]).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_config2_politifact_full_size(compact):
+    """BASELINE configs[2] at FULL size: B=64 claims x 10 evidences, L_right=200 (4 bit words per adjacency row, 8-slab
+    aggregation), D=H=300 -- properties + a 2-claim oracle slice, both row layouts."""
+    from get_amd.synth import SynthConfig
+    _full_size_properties(SynthConfig(batch=64, n_evd=10, len_right=200), 20240301, compact, 2, 8192)
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_config4_h768_full_width_fp32(compact):
+    """BASELINE configs[4] shape in fp32 at a batch that takes the big-tile path (>= 8192 real node rows): h=768 (three
+    column blocks per GEMM), 8 word heads, gnn_window=5, gsl_rate=0.8 -- properties + a 2-claim oracle slice."""
+    from get_amd.synth import SynthConfig
+    cfg = SynthConfig(batch=5, n_evd=30, emb_dim=768, hidden=768, word_heads=8, window=5, gsl_rate=0.8)
+    _full_size_properties(cfg, 20240302, compact, 2, 8192)
+
+
 @pytest.mark.parametrize("compact", [False, True])
 def test_politifact_shaped_long_evidence_vs_oracle(compact):
     """BASELINE configs[2] shape (L_right=200, 10 evidences/claim) at reduced width: full model, native
@@ -336,6 +387,48 @@ def test_batched_predict_equals_per_claim_predict():
         assert float((p1[0] - phi[b]).detach().abs().max()) <= 1e-5
         assert float((w1 - word_w[b]).abs().max()) <= 1e-6 and float((e1[0] - evd_w[b]).abs().max()) <= 1e-6
         assert torch.allclose(word_w[b].sum(1), torch.ones_like(word_w[b].sum(1)), atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["small", "small_claimsrc"])
+def test_batched_predict_vs_reference_fixture_and_eval_protocol(name):
+    """Row (f)3 against the REFERENCE: `batched_predict` (one ragged forward, and in chunks of 2 claims) must reproduce
+    G7's logits / word weights / evidence weights, and so must the evaluation protocol of
+    char_man_fitter_query_repr1.py:298-349 -- one claim per forward, int32 ids and lengths, output_ranking, weights
+    summing to one within 1e-5 (:433, :448)."""
+    from get_amd.batch import NativeBatch, batched_predict
+    z, meta = load(f"g7_model_{name}.npz")
+    cfg, seed = MODEL_CASES[name]
+    model = build_model(cfg, seed)
+    raw = make_raw_batch(cfg, seed)
+    nb = NativeBatch(raw["claim_tokens"], raw["claim_len"], raw["evd_tokens"], raw["evd_len"], raw["evd_counts"],
+                     raw["doc_sources"], raw["query_sources"], raw["labels"], window=cfg.window, device=DEV)
+    counts = raw["evd_counts"]
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    for chunk in (0, 2):
+        phi, word_w, evd_w = batched_predict(model, nb, claims_per_call=chunk)
+        assert np.abs(phi.cpu().numpy() - z["phi"]).max() <= 1e-4
+        assert np.abs(evd_w.cpu().numpy() - z["evd_w"]).max() <= 1e-5
+        assert len(word_w) == cfg.batch
+        for b in range(cfg.batch):
+            assert np.abs(word_w[b].cpu().numpy() - z["word_w"][offs[b]:offs[b + 1]]).max() <= 1e-5
+    # the reference's own loop: B = 1, int32 tensors, dense adjacency from the host-side assembly
+    inp = assemble_inputs(raw, cfg, O.convert_text)
+    for b in range(cfg.batch):
+        e = slice(int(offs[b]), int(offs[b + 1]))
+        k = {"query_lens": torch.from_numpy(inp["query_lens"][b:b + 1]).int().to(DEV), "docs_lens": None,
+             "doc_lens_indices": None,
+             "doc_content_without_padding_evidences": torch.from_numpy(inp["doc_ids"][e]).int().to(DEV),
+             "evd_cnt_each_query": torch.from_numpy(counts[b:b + 1]).to(DEV), "fixed_num_evidences": cfg.fixed_num_evidences,
+             "query_adj": torch.from_numpy(inp["query_adj"][b:b + 1]).to(DEV),
+             "docs_adj": torch.from_numpy(inp["doc_adj"][e]).to(DEV),
+             "doc_sources": torch.from_numpy(inp["doc_sources"][b:b + 1]).int().to(DEV),
+             "query_sources": torch.from_numpy(inp["query_sources"][b:b + 1]).int().to(DEV), "output_ranking": True}
+        with torch.no_grad():
+            p1, (w1, e1) = model.predict(torch.from_numpy(inp["query"][b:b + 1]).int().to(DEV),
+                                         torch.from_numpy(inp["document"][b:b + 1]).int().to(DEV), **k)
+        assert np.abs(p1.cpu().numpy() - z["phi"][b:b + 1]).max() <= 1e-4
+        assert np.abs(w1.cpu().numpy() - z["word_w"][e]).max() <= 1e-5 and np.abs(e1.cpu().numpy() - z["evd_w"][b:b + 1]).max() <= 1e-5
+        assert abs(float(w1.sum(1).mean()) - 1.0) <= 1e-5 and abs(float(e1.sum(1).mean()) - 1.0) <= 1e-5
 
 
 def test_trainer_checkpoint_resume_is_bit_identical():

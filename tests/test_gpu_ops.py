@@ -263,10 +263,16 @@ def test_self_att_extend_vs_golden(ci):
     mod = modules.MultiHeadSelfAttentionICLR2017Extend(inp_dim=d, out_dim=ha, num_heads=heads)
     mod.load_state_dict({"linear1.weight": torch.from_numpy(c["w1"]), "linear2.weight": torch.from_numpy(c["w2"])})
     mod = mod.to(DEV)
-    att, w = mod(T(c["tsr"]), T(c["mask"]), return_att_weights=True)
+    tsr = T(c["tsr"], True)
+    att, w = mod(tsr, T(c["mask"]), return_att_weights=True)
     assert att.shape == (b, heads, d)
     assert maxerr(att.detach().cpu(), z[f"c{ci}_att"]) <= 1e-5
     assert maxerr(w.detach().cpu(), z[f"c{ci}_w"]) <= 1e-6
+    # backward of the `left = NULL` branch of gh_concat_att_bwd against the reference's gradients (self_attention.py:75-100)
+    ((att * T(c["g_att"])).sum() + (w * T(c["g_w"])).sum()).backward()
+    check_grad(z, f"c{ci}_dtsr", tsr.grad.cpu().numpy())
+    check_grad(z, f"c{ci}_g::linear1.weight", mod.linear1.weight.grad.cpu().numpy())
+    check_grad(z, f"c{ci}_g::linear2.weight", mod.linear2.weight.grad.cpu().numpy())
 
 
 # ---------------------------------------------------------------- linear / ragged helpers / Adam
