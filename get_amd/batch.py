@@ -78,6 +78,15 @@ class NativeBatch:
         return q_ids, document.view(self.b, self.n_max, r), kargs
 
 
+    def subset(self, lo: int, hi: int) -> "NativeBatch":
+        """Claims [lo, hi) of this batch as a batch of their own (device-side slices; evaluation in chunks)."""
+        offs = np.concatenate([[0], np.cumsum(self._counts_host)])
+        r0, r1 = int(offs[lo]), int(offs[hi])
+        return NativeBatch(self.claim_tokens[lo:hi], self.claim_len[lo:hi], self.evd_tokens[r0:r1], self.evd_len[r0:r1],
+                           self._counts_host[lo:hi], self.doc_sources[lo:hi], self.query_sources[lo:hi], self.labels[lo:hi],
+                           window=self.window, n_max=self.n_max, device=self.device, compact=self.compact)
+
+
 def kargs_from_reference_tensors(query_lens, evd_doc_contents, evd_docs_adj, query_adj, evd_counts, doc_sources,
                                  query_sources=None, n_max: int = 30):
     """Compatibility shim: the tensors the reference fitter holds before its de-padding loop
@@ -97,15 +106,6 @@ def kargs_from_reference_tensors(query_lens, evd_doc_contents, evd_docs_adj, que
     if query_sources is not None:
         kargs[K.QuerySources] = query_sources
     return kargs
-
-
-    def subset(self, lo: int, hi: int) -> "NativeBatch":
-        """Claims [lo, hi) of this batch as a batch of their own (device-side slices; evaluation in chunks)."""
-        offs = np.concatenate([[0], np.cumsum(self._counts_host)])
-        r0, r1 = int(offs[lo]), int(offs[hi])
-        return NativeBatch(self.claim_tokens[lo:hi], self.claim_len[lo:hi], self.evd_tokens[r0:r1], self.evd_len[r0:r1],
-                           self._counts_host[lo:hi], self.doc_sources[lo:hi], self.query_sources[lo:hi], self.labels[lo:hi],
-                           window=self.window, n_max=self.n_max, device=self.device, compact=self.compact)
 
 
 @torch.no_grad()
