@@ -48,6 +48,7 @@ SIGNATURES = {
     "gh_masked_mean_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "gh_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     "gh_set_workspace": [_P, _L],
+    "gh_set_stream_workspace": [_P, _P, _L],
     "gh_profile_enable": [_I],
     "gh_profile_select": [_U],
     "gh_profile_collect": [_P, _I],
@@ -111,23 +112,34 @@ def load():
     return lib
 
 
-_workspace = None
+_workspaces = {}
 
 
 def ensure_workspace(device, nbytes: int = 256 << 20):
-    """Register (once per process) the split-K scratch buffer of the weight-gradient GEMMs."""
-    global _workspace
-    if _workspace is None or _workspace.device != torch.device(device) or _workspace.numel() * 4 < nbytes:
-        _workspace = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
-        call("gh_set_workspace", _workspace.data_ptr(), _workspace.numel() * 4)
-    return _workspace
+    """Register (once per device and stream) the split-K scratch buffer of the weight-gradient GEMMs for the CURRENT
+    stream of `device`: two streams or two devices in one process never share a scratch area."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    st = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev.index, st)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+        _workspaces[key] = ws
+        call("gh_set_stream_workspace", st, ws.data_ptr(), ws.numel() * 4)
+    return ws
 
 
 def ptr(t):
-    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous."""
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous and live on the CURRENT device: the
+    kernels are launched on the current device's current stream (wrap multi-device use in torch.cuda.device(...))."""
     if t is None:
         return None
     assert t.is_contiguous(), "get_amd: non-contiguous tensor handed to the C-ABI"
+    if t.is_cuda and t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"get_amd: tensor on cuda:{t.device.index} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "launches go to the current device's stream -- use `with torch.cuda.device(tensor.device):`")
     return t.data_ptr()
 
 

@@ -51,7 +51,10 @@ int launch_gate_bwd_pre(const float* g, const float* z, const float* hh, const f
 int launch_colsum3(const float* a, const float* b, const float* c, float* oa, float* ob, float* oc, int m, int h,
                    hipStream_t s, float* oa2 = nullptr, float* ob2 = nullptr, float* oc2 = nullptr);
 int launch_colsum(const float* a, float* oa, int m, int h, hipStream_t s);
-void set_colsum_workspace(float* p, size_t bytes);
+// Scratch registered by the caller: per stream (gh_set_stream_workspace) or the process default (gh_set_workspace).
+// `p` serves the split-K partial tiles, `cs` (the last 1/16) the column-sum partials.
+struct Workspace { float* p; size_t bytes; float* cs; size_t cs_bytes; };
+Workspace workspace_for(hipStream_t s);
 int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m, int d, hipStream_t s,
                        float drop_p = 0.f, unsigned drop_seed = 0);
 int launch_att_softmax_fwd(const float* e, const float* mask, const float* right, const int32_t* goff, int m_real,

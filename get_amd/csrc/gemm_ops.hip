@@ -100,8 +100,31 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
 
 // Split-K scratch registered by the caller (gh_set_workspace); partial tiles are written with plain
 // stores and summed by reduce_partials_kernel instead of cross-XCD fp32 atomics.
-static float* g_ws = nullptr;
-static size_t g_ws_bytes = 0;
+// Registry: one default buffer plus any number of per-stream buffers (two streams that both split K must not share
+// one scratch area); looked up by the launch's stream on every call.
+}  // namespace gh
+#include <mutex>
+#include <unordered_map>
+namespace gh {
+static std::mutex g_ws_mu;
+static Workspace g_ws_default = {nullptr, 0, nullptr, 0};
+static std::unordered_map<hipStream_t, Workspace> g_ws_stream;
+static Workspace make_workspace(void* ptr, int64_t bytes) {
+  // the last 1/16 of the buffer (16-byte aligned) serves the column-sum partials, the rest split-K tiles
+  Workspace w = {nullptr, 0, nullptr, 0};
+  if (!ptr || bytes < (1 << 20)) return w;
+  const size_t tail = ((size_t)bytes / 16) & ~(size_t)15;
+  w.p = (float*)ptr;
+  w.bytes = ((size_t)bytes - tail) & ~(size_t)15;
+  w.cs = (float*)((char*)ptr + w.bytes);
+  w.cs_bytes = tail;
+  return w;
+}
+Workspace workspace_for(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  auto it = g_ws_stream.find(s);
+  return it != g_ws_stream.end() ? it->second : g_ws_default;
+}
 
 struct ReduceItem { const float* ws; float* out; int I, J, ldc, ks; long long stride; };
 struct ReduceArgs { ReduceItem it[GH_MAX_PROBLEMS]; int n; };
@@ -233,7 +256,11 @@ struct Batch {
   bool colsum_fused = false;
   void want_colsum(float* o, float* o2) { if (L.nprob > 0) { cs_out[L.nprob - 1] = o; cs_out2[L.nprob - 1] = o2; } }
 
+  float* g_ws = nullptr;
+  size_t g_ws_bytes = 0;
   Batch(bool tn_, int rows_hint, hipStream_t s_) : tn(tn_), s(s_) {
+    const Workspace w = workspace_for(s_);
+    g_ws = w.p; g_ws_bytes = w.bytes;
     big = tn_ || rows_hint >= 8192;      // 64x320 tile (2x2 waves) for the activation-sized GEMMs, 32x320 (1x4) for few-row ones
     bm = big ? 64 : 32;
     bn = 320;
@@ -615,7 +642,8 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, const in
   if (int e = launch_att_softmax_bwd(right, weights, g_att, g_w, goff, m_real, b, l, dr, heads, de, dright, s)) return e;
   // dW2 = de^T t rides along with the dpre pass (per-pair partials in the workspace, one reduce)
   const size_t dw2_bytes = (size_t)b * heads * ha * sizeof(float);
-  float* dw2_part = (g_ws && dw2_bytes <= g_ws_bytes && ha % 4 == 0) ? g_ws : nullptr;
+  const Workspace wsp = workspace_for(s);
+  float* dw2_part = (wsp.p && dw2_bytes <= wsp.bytes && ha % 4 == 0) ? wsp.p : nullptr;
   if (int e = launch_att_dpre(de, w2, t, goff, m_real, b, l, ha, heads, dpre, du, dw2_part, s)) return e;
   if (dw2_part) {
     ReduceArgs R;
@@ -673,17 +701,15 @@ extern "C" int gh_gemm_path_counters(int64_t* out_host, int reset) {
 }
 
 extern "C" int gh_set_workspace(void* ptr, int64_t bytes) {
-  // the last 1/16 of the buffer (16-byte aligned) serves the column-sum partials, the rest split-K tiles
-  if (!ptr || bytes < (1 << 20)) {
-    g_ws = nullptr; g_ws_bytes = 0;
-    set_colsum_workspace(nullptr, 0);
-    return 0;
-  }
-  const size_t tail = ((size_t)bytes / 16) & ~(size_t)15;
-  g_ws = (float*)ptr;
-  g_ws_bytes = (size_t)bytes - tail;
-  g_ws_bytes &= ~(size_t)15;
-  set_colsum_workspace((float*)((char*)ptr + g_ws_bytes), tail);
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  g_ws_default = make_workspace(ptr, bytes);
+  return 0;
+}
+
+extern "C" int gh_set_stream_workspace(gh_stream_t stream, void* ptr, int64_t bytes) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  if (!ptr) g_ws_stream.erase((hipStream_t)stream);
+  else g_ws_stream[(hipStream_t)stream] = make_workspace(ptr, bytes);
   return 0;
 }
 

@@ -92,12 +92,16 @@ adj_pack_kernel(const T* __restrict__ adj, int R, uint64_t* __restrict__ bits, f
     const size_t rb = ((size_t)g * R + i) * R;
     for (int w = 0; w < W; ++w) {
       const int j = w * 64 + lane;
-      float v = 0.f;
+      float v = 0.f, vt = 0.f;
       if (j < R) {
         v = (float)adj[rb + j];
         vals[rb + j] = v;
+        vt = (float)adj[((size_t)g * R + j) * R + i];
       }
-      const unsigned long long m = __ballot(v != 0.f);
+      // the bit pattern is SYMMETRISED (A[i][j] != 0 or A[j][i] != 0): the transposed aggregation of the backward walks
+      // row i's bits and reads vals[j][i], so an entry present only in A^T must have its bit too; the extra entries
+      // carry the value 0 in `vals` and change no result
+      const unsigned long long m = __ballot(v != 0.f || vt != 0.f);
       if (lane == 0) bits[((size_t)g * R + i) * W + w] = m;
     }
   }

@@ -217,9 +217,6 @@ colsum_final_kernel(const float* __restrict__ ws, int nblk, int h, float* __rest
   }
 }
 
-static float* g_cs_ws = nullptr;
-static size_t g_cs_ws_bytes = 0;
-void set_colsum_workspace(float* p, size_t bytes) { g_cs_ws = p; g_cs_ws_bytes = bytes; }
 
 int launch_colsum3(const float* a, const float* b, const float* c, float* oa, float* ob, float* oc, int m, int h,
                    hipStream_t s, float* oa2, float* ob2, float* oc2) {
@@ -228,7 +225,9 @@ int launch_colsum3(const float* a, const float* b, const float* c, float* oa, fl
   const int nblk = (m + CS2_ROWS - 1) / CS2_ROWS;
   const size_t need = (size_t)nblk * 3 * h * sizeof(float);
   const double bytes = 4.0 * (double)m * h * (1 + (b != nullptr) + (c != nullptr));
-  if (g_cs_ws && need <= g_cs_ws_bytes && h % 4 == 0 && h / 4 <= 256 && (al & 15) == 0) {
+  const Workspace wsp = workspace_for(s);
+  float* const g_cs_ws = wsp.cs;
+  if (g_cs_ws && need <= wsp.cs_bytes && h % 4 == 0 && h / 4 <= 256 && (al & 15) == 0) {
     const int n4 = h / 4;
     const int RL = (256 / n4) > 0 ? (256 / n4) : 1;
     const int threads = ((n4 * RL + 63) / 64) * 64;
@@ -547,10 +546,12 @@ seg_offsets_kernel(const int64_t* __restrict__ counts, int B, int32_t* __restric
   __syncthreads();
   __threadfence_block();
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    const int lo = offsets[b], hi = min(offsets[b + 1], b1);
+    const int lo = min(offsets[b], b1), hi = min(offsets[b + 1], b1);
     for (int p = lo; p < hi; ++p) pair2claim[p] = b;
   }
-  (void)total;
+  // counts that sum to less than b1 (a caller bug the reference reports as a shape error): the rows beyond the last
+  // claim map to claim 0 instead of staying uninitialised -- no out-of-bounds gather downstream
+  for (int p = total + threadIdx.x; p < b1; p += blockDim.x) pair2claim[p] = 0;
 }
 
 __global__ void __launch_bounds__(256)
@@ -577,7 +578,7 @@ __global__ void __launch_bounds__(256)
 seg_pad_kernel(const float* __restrict__ src, const int32_t* __restrict__ offsets, float* __restrict__ dst, int n_max,
                int X, int dst_ld) {
   const int b = blockIdx.x / n_max, slot = blockIdx.x % n_max;
-  const int lo = offsets[b], cnt = offsets[b + 1] - lo;
+  const int lo = offsets[b], cnt = min(offsets[b + 1] - lo, n_max);
   float* d = dst + ((size_t)b * n_max + slot) * dst_ld;
   if (slot < cnt) {
     const float* s = src + (size_t)(lo + slot) * X;
@@ -590,7 +591,7 @@ __global__ void __launch_bounds__(256)
 seg_unpad_kernel(const float* __restrict__ src, const int32_t* __restrict__ offsets, float* __restrict__ dst,
                  int n_max, int X, int src_ld) {
   const int b = blockIdx.x / n_max, slot = blockIdx.x % n_max;
-  const int lo = offsets[b], cnt = offsets[b + 1] - lo;
+  const int lo = offsets[b], cnt = min(offsets[b + 1] - lo, n_max);
   if (slot >= cnt) return;
   const float* s = src + ((size_t)b * n_max + slot) * src_ld;
   float* d = dst + (size_t)(lo + slot) * X;

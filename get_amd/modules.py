@@ -27,10 +27,19 @@ from .keywords import KeyWordSettings
 from .ops import PackedAdj
 
 
+def _drop_caches_on_load(module: nn.Module):
+    """The forward reads cached derivatives of the weights (transposes, fused bias sums, packed scalar gates; ops.transposed
+    / ops.derived) that are validated by tensor identity and in-place version.  load_state_dict copies into `.data`
+    without bumping the version, so every module here invalidates the caches after a load.  Any OTHER raw `.data` write
+    (EMA swaps, hand-written optimisers) must call ops.bump_weight_epoch() itself."""
+    module.register_load_state_dict_post_hook(lambda m, incompatible_keys: ops.bump_weight_epoch())
+
+
 # ------------------------------------------------------------------ Models/BiDAF/wrapper.py:330-347
 class Linear(nn.Module):
     def __init__(self, in_features, out_features, bias=True, dropout=0.0):
         super().__init__()
+        _drop_caches_on_load(self)
         self.linear = nn.Linear(in_features=in_features, out_features=out_features, bias=bias)
         if dropout > 0:
             self.dropout = nn.Dropout(p=dropout)
@@ -225,6 +234,7 @@ class ConcatNotEqualSelfAtt(nn.Module):
     def __init__(self, inp_dim: int, out_dim: int, num_heads: int = 1):
         super().__init__()
         self.inp_dim, self.out_dim, self.num_heads = inp_dim, out_dim, num_heads
+        _drop_caches_on_load(self)
         self.linear1 = nn.Linear(inp_dim, out_dim, bias=False)
         self.linear2 = nn.Linear(out_dim, num_heads, bias=False)
 
@@ -246,6 +256,7 @@ class MultiHeadSelfAttentionICLR2017Extend(nn.Module):
     def __init__(self, inp_dim: int, out_dim: int, num_heads: int):
         super().__init__()
         self.inp_dim, self.out_dim, self.num_heads = inp_dim, out_dim, num_heads
+        _drop_caches_on_load(self)
         self.linear1 = nn.Linear(inp_dim, out_dim, bias=False)
         self.linear2 = nn.Linear(out_dim, num_heads, bias=False)
 
@@ -280,6 +291,7 @@ class Graph_basedSemantiStructure(nn.Module):
 
     def __init__(self, params):
         super().__init__()
+        _drop_caches_on_load(self)
         self._params = params
         self.embedding = self._make_default_embedding_layer(params)
         self.num_classes = params["num_classes"]

@@ -598,7 +598,7 @@ class _SegPad(torch.autograd.Function):             # basic_fc_model.py:94-121 _
         g = _f32(g)
         seg = ctx.seg
         x = g.shape[2]
-        d = torch.empty((seg.b1, x), device=g.device, dtype=torch.float32)
+        d = torch.zeros((seg.b1, x), device=g.device, dtype=torch.float32)     # rows no slot maps to (counts > n_max) get 0
         call("gh_seg_unpad", ptr(g), ptr(seg.offsets), ptr(d), seg.b, seg.n_max, x, x, stream())
         return d, None
 

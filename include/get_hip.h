@@ -14,7 +14,11 @@
  *   - every pointer is a DEVICE pointer unless it says "host"; all float data is
  *     fp32, dense, row-major; ids are int32; adjacency bit rows are uint64 words
  *   - nothing allocates: outputs and scratch are caller-provided
- *   - stream-ordered and re-entrant; `stream` is a hipStream_t passed as void*
+ *   - stream-ordered; `stream` is a hipStream_t passed as void*.  Calls carry all their state in their arguments
+ *     except three pieces of process configuration: the split-K scratch (registered per stream with
+ *     gh_set_stream_workspace, or one default buffer with gh_set_workspace -- concurrent streams that both run
+ *     backward passes need one buffer each), the GEMM arithmetic mode (gh_set_gemm_mode, set before launching work)
+ *     and the measurement hook (gh_profile_*, single stream by design)
  *   - returns 0 on success, non-zero on error (message via gh_last_error());
  *     never aborts the process
  *
@@ -66,7 +70,9 @@ int gh_graph_build(const int32_t* tokens, const int32_t* lengths, int n_texts, i
                    int32_t* node_ids, int32_t* n_nodes, uint64_t* bits, float* dinv, gh_stream_t stream);
 
 /* Dense adjacency handed over by the reference API ((N,R,R) float64 from handlers/mz_sampler.py:146,
- * cast by `.float()` at graph_based_semantic_structure.py:99,149) -> packed bits + fp32 values. */
+ * cast by `.float()` at graph_based_semantic_structure.py:99,149) -> packed bits + fp32 values.  The bit pattern is the
+ * union of A's and A^T's non-zero patterns (entries present on one side only carry the value 0), so that the
+ * transposed aggregation of the backward pass sees every entry of an adjacency whose pattern is not symmetric. */
 int gh_adj_pack_f64(const double* adj, int n, int r, uint64_t* bits, float* vals, gh_stream_t stream);
 int gh_adj_pack_f32(const float* adj, int n, int r, uint64_t* bits, float* vals, gh_stream_t stream);
 
@@ -193,6 +199,8 @@ int gh_set_gemm_mode(int mode);
  * (or when it is too small) the chunks add into the output with fp32 atomics.  All work that uses
  * it is ordered on the stream of the call, so one buffer serves one stream at a time. */
 int gh_set_workspace(void* ptr, int64_t bytes);
+/* The same, for work launched on `stream` only (takes precedence over the default buffer; NULL ptr unregisters). */
+int gh_set_stream_workspace(gh_stream_t stream, void* ptr, int64_t bytes);
 
 /* ---- plain linear y = x W^T + b (model head, graph_based_semantic_structure.py:69-72) ---- */
 int gh_linear_fwd(const float* x, const float* w, const float* bias, float* y, int m, int k, int n,

@@ -117,6 +117,45 @@ def test_spmm_modes(r, h):
     assert maxerr(pk.to_dense().cpu(), (adj * mask).astype(np.float32)) <= 2e-7
 
 
+@pytest.mark.parametrize("r", [30, 100, 130])
+def test_spmm_pattern_asymmetric_adjacency(r):
+    """A dense adjacency whose NON-ZERO PATTERN is not symmetric (A[j][i] != 0 while A[i][j] == 0, e.g. a directed or
+    row-masked graph handed over through the reference API): forward, the transposed backward, the GGNN cell's
+    gradients and the dense round trip must all see every entry."""
+    from get_amd import modules, ops
+    rng = np.random.default_rng(900 + r)
+    n, h = 3, 32
+    a = rng.standard_normal((n, r, r)) * (rng.random((n, r, r)) < 0.06)           # random directed pattern
+    a[:, np.arange(r), np.arange(r)] = 1.0
+    a[:, :, r - 1] = 0.0                                                             # a column with no entries at all ...
+    a[:, r - 1, : r // 2] = 0.5                                                      # ... whose row has many
+    assert ((a != 0) != (a.transpose(0, 2, 1) != 0)).any()
+    x = rng.standard_normal((n, r, h)).astype(np.float32)
+    g = rng.standard_normal((n, r, h)).astype(np.float32)
+    pw = ops.PackedAdj.from_dense(T(a))
+    assert maxerr(pw.to_dense().cpu(), a.astype(np.float32)) == 0.0
+    xt = T(x, grad=True)
+    y = ops.spmm(pw, xt)
+    ref = torch.from_numpy(a).float() @ torch.from_numpy(x)
+    assert maxerr(y.detach().cpu(), ref) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    (y * T(g)).sum().backward()
+    refg = torch.from_numpy(a).float().transpose(1, 2) @ torch.from_numpy(g)
+    assert maxerr(xt.grad.cpu(), refg) <= 2e-6 * max(1.0, float(refg.abs().max()))
+    # the whole cell (the backward's `dxp += A^T da`) against the oracle
+    p = cases.cell_params(rng, h, h)
+    cell = modules.GGNN(h, h, dropout=0.0)
+    _load_cell(cell, p)
+    cell = cell.to(DEV)
+    xc = T(x, grad=True)
+    (cell(T(a), xc) * T(g)).sum().backward()
+    po = {k: torch.from_numpy(v).requires_grad_(True) for k, v in p.items()}
+    xo = torch.from_numpy(x).requires_grad_(True)
+    (O.ggnn_cell(torch.from_numpy(a).float(), xo, po) * torch.from_numpy(g)).sum().backward()
+    assert maxerr(xc.grad.cpu(), xo.grad) <= 1e-3 * float(xo.grad.abs().max()) + 1e-6
+    for k, prm in cell.named_parameters():
+        assert maxerr(prm.grad.cpu(), po[k].grad) <= 1e-3 * float(po[k].grad.abs().max()) + 1e-6, k
+
+
 # ---------------------------------------------------------------- a2 GGNN cell (G2)
 def _load_cell(mod, p, prefix=""):
     sd = {k[len(prefix):]: torch.from_numpy(v) for k, v in p.items() if k.startswith(prefix)}
