@@ -5,7 +5,7 @@
 // with up to two K-segments (so [a | x] . [W0 | W1]^T needs no concatenated copy); NT mode takes B as
 // [N][ldb] (the weight as PyTorch stores it; dX products take the cached transpose).  This file is the generic,
 // scalar-guarded kernel (odd shapes, unaligned operands); the fast paths are gemm_nt.hip.h (NT) and
-// gemm_fast.hip.h (TN).  TN mode (weight gradients) computes
+// gemm_tn.hip.h (TN).  TN mode (weight gradients) computes
 //     C_p[I][J] += sum_m A[m][I]^T B[m][J]          (split over m, fp32 atomics).
 //
 // Tiling: workgroup = WM x WN waves, wave tile = 32 x (16*NI), K tile = 16.

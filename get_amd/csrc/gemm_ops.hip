@@ -3,15 +3,15 @@
 #include "../../include/get_hip.h"
 #include "common.h"
 #include "gemm.hip.h"
-#include "gemm_fast.hip.h"
 #include "gemm_nt.hip.h"
+#include "gemm_tn.hip.h"
 #include <stdlib.h>
 
 namespace gh {
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// fast-path preconditions of gemm_nt.hip.h (NT: both operands contraction-contiguous, LDS-DMA) and gemm_fast.hip.h (TN)
+// fast-path preconditions of gemm_nt.hip.h (NT: both operands contraction-contiguous) and gemm_tn.hip.h (TN); both LDS-DMA
 static bool fast_ok(const Launch& L, bool tn) {
   for (int i = 0; i < L.nprob; ++i) {
     const Problem& p = L.p[i];
@@ -84,13 +84,17 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
   if (!fast && !tn)
     for (int i = 0; i < L.nprob; ++i)
       if (L.p[i].epi == EPI_TANH_H && L.p[i].w2) return hipErrorInvalidValue;   // so does the fused scorer projection
-  if (fast) {
-    if (tn && g_gemm_mode == 1 && WM == 2 && WN == 2 && NI == 10) {
-      if constexpr (WM == 2 && WN == 2 && NI == 10)
-        hipLaunchKernelGGL((gemm_fast_kernel<2, 2, 10, true, 2, true>), dim3(grid), dim3(256), 0, s, L);
-    } else if (tn) hipLaunchKernelGGL((gemm_fast_kernel<WM, WN, NI, true, 2>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
-    else hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, NI, 2>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
-  } else {
+  bool launched = false;
+  if (fast && !tn) {
+    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, NI, 2>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
+    launched = true;
+  } else if (fast && tn) {
+    if constexpr (WM == 2 && WN == 2 && NI == 10) {        // weight gradients always take the 64x320 tile (Batch: big = tn || ...)
+      hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 10>), dim3(grid), dim3(256), 0, s, L);
+      launched = true;
+    }
+  }
+  if (!launched) {
     if (tn) hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, true>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
     else hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, false>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
   }

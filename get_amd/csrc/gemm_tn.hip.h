@@ -1,0 +1,219 @@
+// Grouped fp32 MFMA GEMM, "TN" form (weight gradients), for gfx950:
+//     C_p[I][J] (+)= sum_{m in K chunk} A_p[m][I] . B_p[m][J]          (A = upstream gradient rows, B = activation rows)
+// split over the M rows ("K" of this product) into L.ksplit chunks; every (chunk, problem, row tile) is one workgroup
+// that writes its partial 64 x 320 tile (plain 16-byte stores, summed by reduce_partials_kernel) or adds it atomically.
+//
+// Same machinery as gemm_nt.hip.h -- operands by LDS-DMA, two LDS stages, one barrier per 16-row K tile -- with the
+// operands k-major as they sit in memory ([m][i], [m][j]):
+//   * LDS image = the 16 k-rows of the tile back to back, exactly as the DMA delivers them (A: 16 x 256 B, B: 16 x 1280 B;
+//     odd k-rows of A are rotated by 128 B through the DMA's source address so that the 8-byte fragment reads of the two
+//     k-rows in one LDS access group fall into different bank halves);
+//   * INTERLEAVED MFMA tiles: output row tile mi holds rows {wrow + 2 l + mi}, column tile 4g + c holds columns
+//     {wcol + 64 g + 4 l + c} (l = 0..15).  A lane's A fragment for all row tiles of a k-step is then ONE 8-byte LDS read
+//     and its B fragments for four column tiles ONE 16-byte read: 4 LDS reads per k-step instead of 12, and the four
+//     accumulators of a column group are four consecutive columns, i.e. one 16-byte store in the epilogue;
+//   * the bias gradient (column sums of A over the chunk) falls out of the A fragments: 2 adds per k-step.
+// Preconditions (host-checked, otherwise gemm.hip.h's generic kernel): 16-byte aligned rows, I and J multiples of 4,
+// no row gather, 31-bit byte offsets.
+#pragma once
+#include "gemm.hip.h"
+
+namespace gh {
+
+template <int WM, int WN, int NI>
+__global__ void __launch_bounds__(WM * WN * 64, 3)
+gemm_tn_kernel(const Launch L_byval) {
+  (void)L_byval;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const GH_KARG Launch& L = *(const GH_KARG Launch*)__builtin_amdgcn_kernarg_segment_ptr();
+  typedef __amdgpu_buffer_rsrc_t rsrc_t;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  constexpr int MI = 2;
+  constexpr int NW = WM * WN, NTHR = NW * 64;
+  constexpr int BM = 16 * MI * WM, BN = 16 * NI * WN, BK = 16;
+  constexpr int A_BYTES = BK * BM * 4, B_BYTES = BK * BN * 4;
+  constexpr int NAI = A_BYTES / 1024, NBI = B_BYTES / 1024;          // DMA instructions per K tile
+  constexpr int SA = (NAI + NW - 1) / NW, SB = (NBI + NW - 1) / NW;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int NG4 = NI / 4, NG2 = (NI % 4) / 2;                     // column groups read with 16-byte / 8-byte loads
+  static_assert((NI % 2 == 0) && (BM == 64 || BM == 32), "tile shape");
+  static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0, "whole DMA instructions");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  // ---- work decode: the (row tile, problem) blocks of one K chunk share an XCD (the chunk's rows are read once per L2)
+  const int n_inner = L.m_tiles * L.nprob;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int ks = xcd + 8 * (slot / n_inner);
+  const int inner = slot % n_inner;
+  if (ks >= L.ksplit) return;
+  const int prob = inner % L.nprob;
+  const int m_tile = inner / L.nprob;
+  const GH_KARG Problem& P = L.p[prob];
+  const int M = P.M, N = P.N;               // output tile space: M = I rows, N = J columns
+  const int m0 = m_tile * BM;
+  if (m0 >= M) return;
+  const int kbeg = ks * L.kchunk;
+  const int kend = min(P.seg[0].K, kbeg + L.kchunk);
+  if (kbeg >= kend) return;
+  const int T = (kend - kbeg + BK - 1) / BK;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int wrow = wm * 16 * MI, wcol = wn * 16 * NI;
+  const int l15 = lane & 15, q = lane >> 4;
+
+  const float* A = P.seg[0].A; const float* B = P.seg[0].B;
+  const int lda = P.seg[0].lda, ldb = P.seg[0].ldb;
+  // rows at or beyond kend read as zeros through the descriptor's range check (the byte offset includes soffset)
+  const rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, kend * lda * 4, 0x00020000);
+  const rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, kend * ldb * 4, 0x00020000);
+
+  // DMA slots: linear chunk c of the A image = (k-row c / (BM/4), physical column chunk c % (BM/4)); odd k-rows hold
+  // logical chunk (physical ^ 8): a 128-byte rotation
+  unsigned a_vo[SA], b_vo[SB];
+#pragma unroll
+  for (int j = 0; j < SA; ++j) {
+    const int ia = wave + NW * j;
+    const int c = ia * 64 + lane;
+    const int krow = c / (BM / 4), pc = c % (BM / 4);
+    const int lc = (BM == 64) ? (pc ^ ((krow & 1) << 3)) : pc;
+    const int col = m0 + 4 * lc;
+    a_vo[j] = ((NW * (j + 1) <= NAI || ia < NAI) && col < M) ? ((unsigned)krow * (unsigned)lda + (unsigned)col) * 4u : OOB;
+  }
+#pragma unroll
+  for (int j = 0; j < SB; ++j) {
+    const int ib = wave + NW * j;
+    const int c = ib * 64 + lane;
+    const int krow = c / (BN / 4), pc = c % (BN / 4);
+    const int col = 4 * pc;
+    b_vo[j] = ((NW * (j + 1) <= NBI || ib < NBI) && col < N) ? ((unsigned)krow * (unsigned)ldb + (unsigned)col) * 4u : OOB;
+  }
+  auto dma_tile = [&](int t, int st) __attribute__((always_inline)) {
+    const int k0 = kbeg + t * BK;
+    unsigned char* sb = smem + st * STAGE;
+#pragma unroll
+    for (int j = 0; j < SA; ++j) {
+      const int ia = wave + NW * j;
+      if (NW * (j + 1) <= NAI || ia < NAI)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(sb + ia * 1024), 16, a_vo[j],
+                                                 k0 * lda * 4, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < SB; ++j) {
+      const int ib = wave + NW * j;
+      if (NW * (j + 1) <= NBI || ib < NBI)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sb + A_BYTES + ib * 1024), 16,
+                                                 b_vo[j], k0 * ldb * 4, 0, 0);
+    }
+  };
+
+  // fragment addresses of k-step s: k-row 4 s + q
+  const unsigned a_col = (unsigned)(wrow + 2 * l15);                             // logical float column of this lane's row pair
+  const unsigned a_fo0 = (unsigned)q * (BM * 4) + (((BM == 64) ? (a_col ^ ((q & 1) << 5)) : a_col) * 4u);
+  const unsigned b_fo = (unsigned)A_BYTES + (unsigned)q * (BN * 4) + (unsigned)(wcol + 4 * l15) * 4u;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x2 csum = f32x2{0.f, 0.f};
+  float* const colsum = P.colsum;
+
+  struct Frag { f32x2 a; f32x4 b4[NG4 > 0 ? NG4 : 1]; f32x2 b2[NG2 > 0 ? NG2 : 1]; };
+  auto read_frag = [&](int st, int s, Frag& f) __attribute__((always_inline)) {
+    const unsigned char* sb = smem + st * STAGE + s * 4 * (BM * 4);
+    f.a = *reinterpret_cast<const f32x2*>(sb + a_fo0);
+    const unsigned char* bb = smem + st * STAGE + s * 4 * (BN * 4) + b_fo;
+#pragma unroll
+    for (int g = 0; g < NG4; ++g) f.b4[g] = *reinterpret_cast<const f32x4*>(bb + g * 256);
+#pragma unroll
+    for (int g = 0; g < NG2; ++g) f.b2[g] = *reinterpret_cast<const f32x2*>(smem + st * STAGE + A_BYTES + (s * 4 + q) * (BN * 4) +
+                                                                             (unsigned)(wcol + 64 * NG4 + 32 * g + 2 * l15) * 4u);
+  };
+  // acc[mi][ni][r] = C[i = wrow + 2 (4 q + r) + mi][j = column of tile ni at lane l15]
+  auto mma = [&](const Frag& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = 0; g < NG4; ++g)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[mi][4 * g + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[mi], f.b4[g][c], acc[mi][4 * g + c], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < NG2; ++g)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[mi][4 * NG4 + 2 * g + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[mi], f.b2[g][c], acc[mi][4 * NG4 + 2 * g + c], 0, 0, 0);
+    if (colsum) csum += f.a;
+  };
+
+  dma_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  Frag f0, f1;
+  for (int t = 0; t < T; ++t) {
+    const int st = t & 1;
+    if (t + 1 < T) dma_tile(t + 1, st ^ 1);
+    read_frag(st, 0, f0);
+    read_frag(st, 1, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f0);
+    read_frag(st, 2, f0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f1);
+    read_frag(st, 3, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f0);
+    mma(f1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  if (colsum && wn == 0) {
+    // lanes with the same l15 hold the sums of k-rows = q (mod 4): fold the four, lane q = 0 writes the column pair
+    csum[0] += __shfl_xor(csum[0], 16); csum[1] += __shfl_xor(csum[1], 16);
+    csum[0] += __shfl_xor(csum[0], 32); csum[1] += __shfl_xor(csum[1], 32);
+    const int c = m0 + wrow + 2 * l15;
+    if (q == 0 && c < M) *reinterpret_cast<f32x2*>(colsum + (size_t)ks * (size_t)P.colsum_stride + c) = csum;
+  }
+
+  // ---- epilogue: partial tile (or atomic add).  Row i = m0 + wrow + 2 (4 q + r) + mi; a column group is 4 consecutive j.
+  const int ldc = P.ldc;
+  float* const C = P.C + (size_t)ks * (size_t)P.split_stride;
+  const bool atomic = P.epi == EPI_ATOMIC;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + wrow + 2 * (4 * q + r) + mi;
+      if (row >= M) continue;
+      float* crow = C + (size_t)row * ldc;
+#pragma unroll
+      for (int g = 0; g < NG4; ++g) {
+        const int col = wcol + 64 * g + 4 * l15;
+        if (col < N) {
+          const float4 v = make_float4(acc[mi][4 * g + 0][r], acc[mi][4 * g + 1][r], acc[mi][4 * g + 2][r], acc[mi][4 * g + 3][r]);
+          if (atomic) { atomicAdd(crow + col, v.x); atomicAdd(crow + col + 1, v.y); atomicAdd(crow + col + 2, v.z); atomicAdd(crow + col + 3, v.w); }
+          else *reinterpret_cast<float4*>(crow + col) = v;
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < NG2; ++g) {
+        const int col = wcol + 64 * NG4 + 32 * g + 2 * l15;
+        if (col < N) {
+          const float2 v = make_float2(acc[mi][4 * NG4 + 2 * g][r], acc[mi][4 * NG4 + 2 * g + 1][r]);
+          if (atomic) { atomicAdd(crow + col, v.x); atomicAdd(crow + col + 1, v.y); }
+          else *reinterpret_cast<float2*>(crow + col) = v;
+        }
+      }
+    }
+#endif
+}
+
+}  // namespace gh

@@ -78,7 +78,8 @@ def test_adj_pack_unpack_roundtrip():
             p = PackedAdj.from_dense(T(a.astype(dt)))
             back = p.to_dense().cpu().numpy()
             assert np.array_equal(back, a.astype(dt).astype(np.float32))
-            assert np.array_equal(bits_to_bool(p.bits, r), a != 0)
+            # bit pattern = union of A's and A^T's patterns (the transposed aggregation walks row i's bits for A[j][i])
+            assert np.array_equal(bits_to_bool(p.bits, r), (a != 0) | (a.transpose(0, 2, 1) != 0))
 
 
 # ---------------------------------------------------------------- aggregation
