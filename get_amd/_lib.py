@@ -26,11 +26,11 @@ SIGNATURES = {
     "gh_graph_build": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "gh_adj_pack_f64": [_P, _I, _I, _P, _P, _P],
     "gh_adj_pack_f32": [_P, _I, _I, _P, _P, _P],
-    "gh_ragged_plan": [_P, _P, _I, _I, _P, _P, _P, _P, _P],
+    "gh_ragged_plan": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "gh_spmm": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "gh_transpose": [_P, _P, _I, _I, _P],
     "gh_transpose_batch": [_I, _P, _P, _P, _P, _P],
-    "gh_ggnn_cell_fwd": [_P] * 5 + [_I, _I] + [_P] * 2 + [_I] * 4 + [_P] * 10 + [_P] * 7 + [_F, _U, _P, _P, _F, _U, _P],
+    "gh_ggnn_cell_fwd": [_P] * 5 + [_I, _I] + [_P] * 2 + [_I] * 4 + [_P] * 13 + [_P] * 7 + [_F, _U, _P, _P, _F, _U, _P],
     "gh_ggnn_cell_bwd": [_P] * 5 + [_I] + [_P] * 2 + [_I] * 4 + [_P] * 7 + [_P] * 7 + [_P] * 5 + [_P] * 14 + [_F, _U, _P],
     "gh_scorer_gsl": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _U, _P],
     "gh_gsl_topk": [_P, _I, _I, _I, _P, _P],
@@ -38,8 +38,10 @@ SIGNATURES = {
     "gh_concat_att_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "gh_concat_att_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "gh_linear_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
-    "gh_linear_bwd": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
-    "gh_seg_offsets": [_P, _I, _P, _P, _I, _P],
+    "gh_linear_bwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "gh_evd_assemble_fwd": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "gh_evd_assemble_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "gh_seg_offsets": [_P, _I, _P, _P, _I, _P, _P],
     "gh_seg_broadcast": [_P, _P, _P, _I, _I, _P],
     "gh_seg_sum": [_P, _P, _P, _I, _I, _P],
     "gh_seg_pad": [_P, _P, _P, _I, _I, _I, _I, _P],

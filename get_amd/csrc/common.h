@@ -57,6 +57,9 @@ struct Workspace { float* p; size_t bytes; float* cs; size_t cs_bytes; };
 Workspace workspace_for(hipStream_t s);
 int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m, int d, hipStream_t s,
                        float drop_p = 0.f, unsigned drop_seed = 0);
+int launch_tiny_linear_fwd(const float* x, const float* w, const float* bias, float* y, int m, int k, int n, hipStream_t s);
+int launch_tiny_linear_bwd(const float* x, const float* w, const float* g, float* dx, float* dw, float* db, int m, int k, int n,
+                           hipStream_t s);
 int launch_att_softmax_fwd(const float* e, const float* mask, const float* right, const int32_t* goff, int m_real,
                            int b, int l, int dr, int heads, float* weights, float* attended, hipStream_t s);
 int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w,

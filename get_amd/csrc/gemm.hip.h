@@ -48,6 +48,7 @@ struct Problem {
   int accumulate;
   float* C; int ldc;
   const float* bias;
+  const float* bias2;       // optional second bias added to `bias` (b?0 + b?1 of a gate; NT fast kernel and the generic kernel)
   float* out1;
   const float* in0; const float* in1;   // same leading dimension as C
   const float* u; const float* w2; float* e; int ldu; int R; int heads;
@@ -357,7 +358,7 @@ gemm_kernel(const Launch L_byval) {
     for (int ni = 0; ni < NI; ++ni) {
       const int col = wcol + ni * 16 + l15;
       const bool tile_ok = (mi < mi_cnt) && (ni < ni_cnt) && (col < N);
-      const float bias = (tile_ok && P.bias) ? P.bias[col] : 0.f;
+      const float bias = ((tile_ok && P.bias) ? P.bias[col] : 0.f) + ((tile_ok && P.bias2) ? P.bias2[col] : 0.f);
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int row = m0 + wrow + mi * 16 + q * 4 + reg;

@@ -284,6 +284,7 @@ gemm_nt_kernel(const Launch L_byval) {
     const int col = wcol + ni * 16 + 4 * q;
     bias4[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (bias && col < N) bias4[ni] = *reinterpret_cast<const f32x4*>(bias + col);
+    if (P.bias2 && col < N) bias4[ni] += *reinterpret_cast<const f32x4*>(P.bias2 + col);
   }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {

@@ -33,7 +33,7 @@ static bool fast_ok(const Launch& L, bool tn) {
     }
     if (p.N % 4 || p.N < 4 || p.ldc % 4 || !al16(p.C)) return false;
     if (tn && (p.M % 4 || p.M < 4)) return false;
-    if ((p.bias && !al16(p.bias)) || (p.out1 && !al16(p.out1)) || (p.in0 && !al16(p.in0)) || (p.in1 && !al16(p.in1)))
+    if ((p.bias && !al16(p.bias)) || (p.bias2 && !al16(p.bias2)) || (p.out1 && !al16(p.out1)) || (p.in0 && !al16(p.in0)) || (p.in1 && !al16(p.in1)))
       return false;
     if (p.epi == EPI_ATT && (!al16(p.u) || p.ldu % 4 || !al16(p.w2))) return false;
     if (p.epi == EPI_TANH_H && p.w2 && !al16(p.w2)) return false;
@@ -294,6 +294,7 @@ struct Batch {
       q.C += n0;
       q.drop_col0 = p.drop_col0 + n0;
       if (q.bias) q.bias += n0;
+      if (q.bias2) q.bias2 += n0;
       if (q.out1) q.out1 += n0;
       if (q.in0) q.in0 += n0;
       if (q.in1) q.in1 += n0;
@@ -383,7 +384,7 @@ struct Batch {
     int kmax = 0;
     for (int i = 0; i < L.nprob; ++i) {
       const Problem& q = L.p[i];
-      if (q.nseg != 1 || (q.epi != EPI_STORE && q.epi != EPI_ATT) || q.drop_mode == 3) return false;
+      if (q.nseg != 1 || (q.epi != EPI_STORE && q.epi != EPI_ATT) || q.drop_mode == 3 || q.bias2) return false;
       if (q.seg[0].K > kmax) kmax = q.seg[0].K;
     }
     int ks = kmax / 64;
@@ -454,7 +455,8 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
                                 const float* x, const int32_t* ids, int n, int r, int din, int h,
                                 const float* w_p, const float* w_z0, const float* w_z1, const float* w_r0,
                                 const float* w_r1, const float* w_h0, const float* w_h1,
-                                const float* b_z, const float* b_r, const float* b_h,
+                                const float* b_z0, const float* b_z1, const float* b_r0, const float* b_r1,
+                                const float* b_h0, const float* b_h1,
                                 float* xp, float* a, float* z, float* rr, float* rx, float* hh, float* out,
                                 float drop_p, uint32_t drop_seed,
                                 const float* score_w, float* score_x, float score_drop_p, uint32_t score_drop_seed,
@@ -484,10 +486,10 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
     Batch b(false, M, s);
     Problem pz = gemm_problem(M, h, EPI_SIGMOID_Z, z, h, a, h, w_z0, h, h);
     add_seg(pz, xp, h, w_z1, h, h);
-    pz.bias = b_z;
+    pz.bias = b_z0; pz.bias2 = b_z1;
     Problem pr = gemm_problem(M, h, EPI_SIGMOID_R, rr, h, a, h, w_r0, h, h);
     add_seg(pr, xp, h, w_r1, h, h);
-    pr.bias = b_r; pr.out1 = rx; pr.in0 = xp;
+    pr.bias = b_r0; pr.bias2 = b_r1; pr.out1 = rx; pr.in0 = xp;
     if (m_rows > m_real) pz.seg0_rows = pr.seg0_rows = (m_real > 0 ? m_real : 1);
     b.add(pz); b.add(pr);
     b.flush();
@@ -497,7 +499,7 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
     Batch b(false, M, s);
     Problem ph = gemm_problem(M, h, EPI_TANH_H, hh, h, a, h, w_h0, h, h);
     add_seg(ph, rx, h, w_h1, h, h);
-    ph.bias = b_h; ph.out1 = out; ph.in0 = z; ph.in1 = xp;
+    ph.bias = b_h0; ph.bias2 = b_h1; ph.out1 = out; ph.in0 = z; ph.in1 = xp;
     if (m_rows > m_real) ph.seg0_rows = (m_real > 0 ? m_real : 1);
     if (score_w) {
       ph.w2 = score_w; ph.e = score_x;
@@ -721,6 +723,7 @@ extern "C" int gh_linear_fwd(const float* x, const float* w, const float* bias, 
                              gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   GH_REQUIRE(m > 0 && k > 0 && n > 0, "linear_fwd: bad sizes");
+  if (n <= 8) return launch_tiny_linear_fwd(x, w, bias, y, m, k, n, s);      // the 2-class head: one wave per row
   Batch b(false, m, s);
   Problem p = gemm_problem(m, n, EPI_STORE, y, n, x, k, w, k, k);
   p.bias = bias;
@@ -730,10 +733,11 @@ extern "C" int gh_linear_fwd(const float* x, const float* w, const float* bias, 
   return 0;
 }
 
-extern "C" int gh_linear_bwd(const float* x, const float* wt, const float* g, int m, int k, int n, float* dx,
+extern "C" int gh_linear_bwd(const float* x, const float* wt, const float* w, const float* g, int m, int k, int n, float* dx,
                              float* dw, float* db, gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   GH_REQUIRE(m > 0 && k > 0 && n > 0, "linear_bwd: bad sizes");
+  if (n <= 8 && w) return launch_tiny_linear_bwd(x, w, g, dx, dw, db, m, k, n, s);
   if (dx) {
     Batch b(false, m, s);
     b.add(gemm_problem(m, k, EPI_STORE, dx, k, g, n, wt, n, n));

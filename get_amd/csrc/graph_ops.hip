@@ -433,7 +433,8 @@ ragged_scan_kernel(const int32_t* __restrict__ n_nodes, int n, int R, int32_t* _
 
 __global__ void __launch_bounds__(256)
 ragged_fill_kernel(const int32_t* __restrict__ goff, const int32_t* __restrict__ node_ids, int n, int R,
-                   int32_t* __restrict__ rowg, int32_t* __restrict__ src, int32_t* __restrict__ cids) {
+                   int32_t* __restrict__ rowg, int32_t* __restrict__ src, int32_t* __restrict__ cids,
+                   float* __restrict__ maskf) {
   const int g = blockIdx.x;
   const int row0 = goff[g], NR = goff[g + 1] - row0;
   const int pad0 = goff[n] + g * R - row0 - NR;
@@ -441,7 +442,9 @@ ragged_fill_kernel(const int32_t* __restrict__ goff, const int32_t* __restrict__
     const int row = j < NR ? row0 + j : pad0 + j;
     rowg[row] = g;
     src[row] = g * R + j;
-    if (cids) cids[row] = node_ids[(size_t)g * R + j];
+    const int id = (cids || maskf) ? node_ids[(size_t)g * R + j] : 0;
+    if (cids) cids[row] = id;
+    if (maskf) maskf[row] = id >= 1 ? 1.f : 0.f;       // the word attention's mask (doc >= 1, graph_based_semantic_structure.py:180)
   }
 }
 
@@ -568,12 +571,12 @@ extern "C" int gh_graph_build(const int32_t* tokens, const int32_t* lengths, int
 }
 
 extern "C" int gh_ragged_plan(const int32_t* n_nodes, const int32_t* node_ids, int n, int r, int32_t* goff,
-                              int32_t* rowg, int32_t* src, int32_t* cids, gh_stream_t stream) {
+                              int32_t* rowg, int32_t* src, int32_t* cids, float* maskf, gh_stream_t stream) {
   GH_REQUIRE(r > 0 && r <= MAX_R, "ragged_plan: r=%d not in [1,%d]", r, MAX_R);
-  GH_REQUIRE((cids == nullptr) || (node_ids != nullptr), "ragged_plan: cids needs node_ids");
+  GH_REQUIRE((cids == nullptr && maskf == nullptr) || (node_ids != nullptr), "ragged_plan: cids / maskf need node_ids");
   if (n <= 0) return 0;
   hipLaunchKernelGGL(ragged_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_nodes, n, r, goff);
-  hipLaunchKernelGGL(ragged_fill_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, goff, node_ids, n, r, rowg, src, cids);
+  hipLaunchKernelGGL(ragged_fill_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, goff, node_ids, n, r, rowg, src, cids, maskf);
   GH_LAUNCH_CHECK();
   return 0;
 }

@@ -535,7 +535,7 @@ int launch_att_dpre(const float* de, const float* w2, const float* t, const int3
 // ---------------------------------------------------------------------------- ragged helpers (basic_fc_model.py:80-121)
 __global__ void __launch_bounds__(256)
 seg_offsets_kernel(const int64_t* __restrict__ counts, int B, int32_t* __restrict__ offsets,
-                   int32_t* __restrict__ pair2claim, int b1) {
+                   int32_t* __restrict__ pair2claim, int b1, float* __restrict__ has) {
   __shared__ int total;
   if (threadIdx.x == 0) {
     int acc = 0;
@@ -552,6 +552,8 @@ seg_offsets_kernel(const int64_t* __restrict__ counts, int B, int32_t* __restric
   // counts that sum to less than b1 (a caller bug the reference reports as a shape error): the rows beyond the last
   // claim map to claim 0 instead of staying uninitialised -- no out-of-bounds gather downstream
   for (int p = total + threadIdx.x; p < b1; p += blockDim.x) pair2claim[p] = 0;
+  if (has)
+    for (int b = threadIdx.x; b < B; b += blockDim.x) has[b] = counts[b] > 0 ? 1.f : 0.f;
 }
 
 __global__ void __launch_bounds__(256)
@@ -617,6 +619,138 @@ masked_mean_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ 
   const int b = blockIdx.x / L, l = blockIdx.x % L;
   const float sc = (ids[b * L + l] > 0) ? 1.f / lens[b] : 0.f;
   for (int i = threadIdx.x; i < H; i += blockDim.x) dhid[((size_t)b * L + l) * H + i] = g[(size_t)b * H + i] * sc;
+}
+
+// ---------------------------------------------------------------------------- evidence-level assembly
+// graph_based_semantic_structure.py:157-170,195-215 in one launch: right[b][slot] = [ pad_right(avg)[b][slot] |
+// article_source_embs(max(src, 0)) ], mask[b][slot] = (sum_r document[b][slot][r] >= 1).  Replaces seg_pad +
+// masked_fill + embedding + cat + sum/compare/cast (8 launches).  One workgroup per (claim, slot).
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256)
+evd_assemble_fwd_kernel(const float* __restrict__ avg, const int32_t* __restrict__ offsets, const float* __restrict__ table,
+                        const TS* __restrict__ sources, const TD* __restrict__ document, float* __restrict__ right,
+                        float* __restrict__ mask, int n_max, int Xa, int Ds, int R) {
+  const int b = blockIdx.x / n_max, slot = blockIdx.x % n_max;
+  const int lo = offsets[b], cnt = min(offsets[b + 1] - lo, n_max);
+  float* d = right + (size_t)blockIdx.x * (Xa + Ds);
+  if (slot < cnt) {
+    const float* sp = avg + (size_t)(lo + slot) * Xa;
+    for (int i = threadIdx.x; i < Xa; i += blockDim.x) d[i] = sp[i];
+  } else {
+    for (int i = threadIdx.x; i < Xa; i += blockDim.x) d[i] = 0.f;
+  }
+  if (Ds > 0) {
+    long long sid = (long long)sources[blockIdx.x];
+    if (sid < 0) sid = 0;                                        // -1 padding -> row 0 (:166-168)
+    const float* tp = table + (size_t)sid * Ds;
+    for (int i = threadIdx.x; i < Ds; i += blockDim.x) d[Xa + i] = tp[i];
+  }
+  if (threadIdx.x < 64) {                                        // slot mask: any node id >= 1 (ids are non-negative)
+    long long acc = 0;
+    const TD* dp = document + (size_t)blockIdx.x * R;
+    for (int r = threadIdx.x; r < R; r += 64) acc += (long long)dp[r];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (threadIdx.x == 0) mask[blockIdx.x] = acc >= 1 ? 1.f : 0.f;
+  }
+}
+
+// backward: d_avg = unpad(g[:, :, :Xa]);  d_table[s] += sum over the slots with source s of g[:, :, Xa:], summed in
+// slot order by the FIRST slot that holds s (deterministic: no float atomics, no sort)
+template <typename TS>
+__global__ void __launch_bounds__(256)
+evd_assemble_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ offsets, const TS* __restrict__ sources,
+                        float* __restrict__ d_avg, float* __restrict__ d_table, int n_slots, int n_max, int Xa, int Ds) {
+  extern __shared__ int sids[];
+  const int me = blockIdx.x;
+  const int b = me / n_max, slot = me % n_max;
+  const int lo = offsets[b], cnt = min(offsets[b + 1] - lo, n_max);
+  const float* gp = g + (size_t)me * (Xa + Ds);
+  if (slot < cnt && d_avg) {
+    float* d = d_avg + (size_t)(lo + slot) * Xa;
+    for (int i = threadIdx.x; i < Xa; i += blockDim.x) d[i] = gp[i];
+  }
+  if (Ds <= 0 || !d_table) return;
+  for (int i = threadIdx.x; i < n_slots; i += blockDim.x) { const long long v = (long long)sources[i]; sids[i] = v < 0 ? 0 : (int)v; }
+  __syncthreads();
+  const int mine = sids[me];
+  __shared__ int earlier;
+  if (threadIdx.x == 0) earlier = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < me; i += blockDim.x)
+    if (sids[i] == mine) earlier = 1;
+  __syncthreads();
+  if (earlier) return;                                            // an earlier slot owns this source's row
+  for (int i = threadIdx.x; i < Ds; i += blockDim.x) {
+    float acc = 0.f;
+    for (int j = me; j < n_slots; ++j)
+      if (sids[j] == mine) acc += g[(size_t)j * (Xa + Ds) + Xa + i];
+    d_table[(size_t)mine * Ds + i] += acc;
+  }
+}
+
+// ---------------------------------------------------------------------------- linear layers with a handful of outputs
+// y[m][n] = x[m][:] . w[n][:] + b[n]  for n <= 8 (the 2-class head, graph_based_semantic_structure.py:72): one wave per row
+__global__ void __launch_bounds__(256)
+tiny_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                       float* __restrict__ y, int m, int k, int n) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= m) return;
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+  for (int i = lane; i < k; i += 64) {
+    const float xv = x[(size_t)row * k + i];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < n) acc[c] += xv * w[(size_t)c * k + i];
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (c < n) {
+      float v = acc[c];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) y[(size_t)row * n + c] = v + (bias ? bias[c] : 0.f);
+    }
+}
+// dx[m][k] = g[m][:] . w[:][k] ;  dw[n][k] += sum_m g[m][n] x[m][k] ;  db[n] += sum_m g[m][n]   (w given as stored, [n][k])
+__global__ void __launch_bounds__(256)
+tiny_linear_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ g,
+                       float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int m, int k, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;            // column k index
+  if (i < k) {
+    float wc[8], dwc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { wc[c] = c < n ? w[(size_t)c * k + i] : 0.f; dwc[c] = 0.f; }
+    for (int r = 0; r < m; ++r) {
+      const float xv = x[(size_t)r * k + i];
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < n) { const float gv = g[(size_t)r * n + c]; d += gv * wc[c]; dwc[c] += gv * xv; }
+      if (dx) dx[(size_t)r * k + i] = d;
+    }
+    if (dw)
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < n) dw[(size_t)c * k + i] += dwc[c];
+  }
+  if (db && blockIdx.x == 0 && threadIdx.x < n) {
+    float acc = 0.f;
+    for (int r = 0; r < m; ++r) acc += g[(size_t)r * n + threadIdx.x];
+    db[threadIdx.x] += acc;
+  }
+}
+
+int launch_tiny_linear_fwd(const float* x, const float* w, const float* bias, float* y, int m, int k, int n, hipStream_t s) {
+  hipLaunchKernelGGL(tiny_linear_fwd_kernel, dim3((m + 3) / 4), dim3(256), 0, s, x, w, bias, y, m, k, n);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+int launch_tiny_linear_bwd(const float* x, const float* w, const float* g, float* dx, float* dw, float* db, int m, int k, int n,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(tiny_linear_bwd_kernel, dim3((k + 255) / 256), dim3(256), 0, s, x, w, g, dx, dw, db, m, k, n);
+  GH_LAUNCH_CHECK();
+  return 0;
 }
 
 // ---------------------------------------------------------------------------- flat Adam (torch.optim.Adam, L2 weight decay)
@@ -697,10 +831,10 @@ extern "C" int gh_transpose_batch(int n, const void* const* src, void* const* ds
   return 0;
 }
 
-extern "C" int gh_seg_offsets(const int64_t* counts, int b, int32_t* offsets, int32_t* pair2claim, int b1,
+extern "C" int gh_seg_offsets(const int64_t* counts, int b, int32_t* offsets, int32_t* pair2claim, int b1, float* has,
                               gh_stream_t stream) {
   GH_REQUIRE(b > 0, "seg_offsets: b=%d", b);
-  hipLaunchKernelGGL(seg_offsets_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counts, b, offsets, pair2claim, b1);
+  hipLaunchKernelGGL(seg_offsets_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counts, b, offsets, pair2claim, b1, has);
   GH_LAUNCH_CHECK();
   return 0;
 }
@@ -758,6 +892,40 @@ extern "C" int gh_adam_step(float* p, const float* g, float* m, float* v, int64_
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (size_t)count, lr, beta1,
                      beta2, eps, weight_decay, bc1, (float)sqrt(bc2), grad_scale);
   prof_end(PROF_ADAM, 28.0 * (double)count, (hipStream_t)stream);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gh_evd_assemble_fwd(const float* avg, const int32_t* offsets, const float* table, const void* sources,
+                                   int sources_i64, const void* document, int document_i64, int b, int n_max, int xa, int ds,
+                                   int r, float* right, float* mask, gh_stream_t stream) {
+  GH_REQUIRE(b > 0 && n_max > 0 && xa > 0 && ds >= 0 && r > 0, "evd_assemble_fwd: bad sizes");
+  GH_REQUIRE(ds == 0 || (table && sources), "evd_assemble_fwd: article-source width %d needs a table and source ids", ds);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(b * n_max), blk(256);
+#define GH_EA(TS, TD) hipLaunchKernelGGL((evd_assemble_fwd_kernel<TS, TD>), grid, blk, 0, s, avg, offsets, table, (const TS*)sources, \
+                                         (const TD*)document, right, mask, n_max, xa, ds, r)
+  if (sources_i64 && document_i64) GH_EA(int64_t, int64_t);
+  else if (sources_i64) GH_EA(int64_t, int32_t);
+  else if (document_i64) GH_EA(int32_t, int64_t);
+  else GH_EA(int32_t, int32_t);
+#undef GH_EA
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gh_evd_assemble_bwd(const float* g, const int32_t* offsets, const void* sources, int sources_i64, int b, int n_max,
+                                   int xa, int ds, float* d_avg, float* d_table, gh_stream_t stream) {
+  GH_REQUIRE(b > 0 && n_max > 0 && xa > 0 && ds >= 0, "evd_assemble_bwd: bad sizes");
+  const int n_slots = b * n_max;
+  GH_REQUIRE((size_t)n_slots * 4 <= 60 * 1024, "evd_assemble_bwd: %d slots do not fit the source-id table in LDS", n_slots);
+  hipStream_t s = (hipStream_t)stream;
+  if (sources_i64)
+    hipLaunchKernelGGL((evd_assemble_bwd_kernel<int64_t>), dim3(n_slots), dim3(256), (size_t)n_slots * 4, s, g, offsets,
+                       (const int64_t*)sources, d_avg, d_table, n_slots, n_max, xa, ds);
+  else
+    hipLaunchKernelGGL((evd_assemble_bwd_kernel<int32_t>), dim3(n_slots), dim3(256), (size_t)n_slots * 4, s, g, offsets,
+                       (const int32_t*)sources, d_avg, d_table, n_slots, n_max, xa, ds);
   GH_LAUNCH_CHECK();
   return 0;
 }

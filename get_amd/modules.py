@@ -395,22 +395,21 @@ class Graph_basedSemantiStructure(nn.Module):
         if plan is None:
             att, word_att_weights = self.self_att_word(query_repr, doc_out, doc >= 1)
         else:
-            att, word_w = self.self_att_word(query_repr, doc_out, plan.cids[:plan.m_real] >= 1, plan=plan)
+            att, word_w = self.self_att_word(query_repr, doc_out, plan.maskf[:plan.m_real], plan=plan)
             word_att_weights = None
         avg = torch.flatten(att, start_dim=1)                                   # (B1, H*hw), head fastest
 
+        # evidence-level attention (:195-221).  Its left input is row 0 of pad_right([claim source | query_repr]), i.e. the
+        # claim's own vector (zeros for a claim without evidences) -- taken per claim instead of broadcasting to B1 pairs,
+        # padding to (B, n, X) and slicing slot 0
+        left_claim = q_repr
         if self.use_claim_source:
             claim_embs = self.claim_source_embs(kargs[K.QuerySources].long()).squeeze(1)
-            query_repr = torch.cat([ops.seg_broadcast(claim_embs, seg), query_repr], dim=-1)
-
-        # evidence-level attention (:195-221)
-        new_left = ops.seg_pad(query_repr, seg)[:, 0, :]                        # (B, X)
-        padded_avg = ops.seg_pad(avg, seg)                                      # (B, n, H*hw)
-        mask = (torch.sum(document, dim=-1) >= 1).float()
-        if self.use_article_source:
-            src = kargs[K.DocSources]
-            src = src.masked_fill(src == -1, 0)                                 # (:166-168)
-            padded_avg = torch.cat([padded_avg, self.article_source_embs(src.long())], dim=-1)
+            left_claim = torch.cat([claim_embs, q_repr], dim=-1)                # source first (:116)
+        new_left = left_claim * seg.has                                         # (B, X)
+        # pad_right(avg) ++ article_source_embs(src with -1 -> 0) and the slot mask, one launch (:157-170, :195-215)
+        padded_avg, mask = ops.evd_assemble(avg, self.article_source_embs.weight if self.use_article_source else None, seg,
+                                            kargs[K.DocSources] if self.use_article_source else None, document)
         attended_avg, evd_att_weight = self.self_att_evd(new_left.contiguous(), padded_avg, mask)
         output = torch.cat([new_left, torch.flatten(attended_avg, start_dim=1)], dim=-1)   # (:251-267)
         phi = self.out(output)

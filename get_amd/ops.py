@@ -185,7 +185,7 @@ class RaggedPlan:
     forward and the scorer (whose padding scores compete in GSL's top-k, wrapper.py:216-219) need them.
     ``m_real`` (sum of node counts) must be known on the HOST: it sizes the launches."""
 
-    __slots__ = ("n", "r", "m_real", "m_tot", "goff", "rowg", "src", "cids")
+    __slots__ = ("n", "r", "m_real", "m_tot", "goff", "rowg", "src", "cids", "maskf")
 
     def __init__(self, n_nodes: torch.Tensor, node_ids: torch.Tensor, m_real: int):
         _lib.require_cuda(n_nodes, node_ids)
@@ -199,8 +199,9 @@ class RaggedPlan:
         self.rowg = torch.empty((n * r,), device=dev, dtype=torch.int32)
         self.src = torch.empty((n * r,), device=dev, dtype=torch.int32)
         self.cids = torch.empty((n * r,), device=dev, dtype=torch.int32)
+        self.maskf = torch.empty((n * r,), device=dev, dtype=torch.float32)     # (cids >= 1): the word attention's mask
         call("gh_ragged_plan", ptr(n_nodes), ptr(node_ids), n, r, ptr(self.goff), ptr(self.rowg), ptr(self.src),
-             ptr(self.cids), stream())
+             ptr(self.cids), ptr(self.maskf), stream())
 
     def to_padded(self, x: torch.Tensor, rows: Optional[int] = None) -> torch.Tensor:
         """Compact rows (m, ...) -> padded (n, r, ...) with zeros where no compact row was given."""
@@ -273,8 +274,7 @@ class _GGNNCell(torch.autograd.Function):
         # forward products x.W^T take the weights as stored; the backward's dX = g.W takes the cached transposes
         ws = [_f32(w.detach()) for w in (w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1)]
         wts = [transposed(w) for w in (w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1)]
-        b_z, b_r, b_h = derived("cell_bias", (b_z0, b_z1, b_r0, b_r1, b_h0, b_h1), lambda: tuple(
-            _f32(u.detach() + v.detach()) for u, v in ((b_z0, b_z1), (b_r0, b_r1), (b_h0, b_h1))))
+        bs = [_f32(t.detach()) for t in (b_z0, b_z1, b_r0, b_r1, b_h0, b_h1)]      # the epilogues add b?0 + b?1
         buf = torch.empty((7, m, h), device=dev, dtype=torch.float32)
         xp, a, z, rr, rx, hh, out = buf.unbind(0)
         sx = None
@@ -284,7 +284,7 @@ class _GGNNCell(torch.autograd.Function):
             sx = torch.empty((m,), device=dev, dtype=torch.float32)
             sc = (ptr(_f32(sw.detach().reshape(-1))), ptr(sx), float(sp), int(sseed))
         call("gh_ggnn_cell_fwd", *adj._args(), *_plan_args(plan), m, ptr(x), ptr(ids), n, r, din, h,
-             *[ptr(t) for t in ws], ptr(b_z), ptr(b_r), ptr(b_h),
+             *[ptr(t) for t in ws], *[ptr(t) for t in bs],
              ptr(xp), ptr(a), ptr(z), ptr(rr), ptr(rx), ptr(hh), ptr(out), float(drop_p), int(drop_seed), *sc, stream())
         ctx.adj, ctx.ids, ctx.dims, ctx.plan, ctx.rows = adj, ids, (n, r, din, h), plan, (m, mb)
         ctx.drop = (float(drop_p), int(drop_seed))
@@ -516,7 +516,7 @@ class _Linear(torch.autograd.Function):
         y = torch.empty((m, n), device=x.device, dtype=torch.float32)
         bc = _f32(b.detach()) if b is not None else None
         call("gh_linear_fwd", ptr(x2), ptr(wc), ptr(bc), ptr(y), m, k, n, stream())
-        ctx.save_for_backward(x2, transposed(w))
+        ctx.save_for_backward(x2, transposed(w), wc)
         ctx.params = (w, b)
         ctx.has_bias = b is not None
         ctx.xshape = x.shape
@@ -524,7 +524,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        x2, wt = ctx.saved_tensors
+        x2, wt, wc = ctx.saved_tensors
         m, k = x2.shape
         n = wt.shape[1]
         g2 = _f32(g).reshape(m, n)
@@ -537,7 +537,7 @@ class _Linear(torch.autograd.Function):
         else:
             dw = torch.zeros((n, k), device=g.device, dtype=torch.float32)
             db = torch.zeros((n,), device=g.device, dtype=torch.float32) if ctx.has_bias else None
-        call("gh_linear_bwd", ptr(x2), ptr(wt), ptr(g2), m, k, n, ptr(dx), ptr(dw), ptr(db), stream())
+        call("gh_linear_bwd", ptr(x2), ptr(wt), ptr(wc), ptr(g2), m, k, n, ptr(dx), ptr(dw), ptr(db), stream())
         dxo = dx.view(ctx.xshape) if dx is not None else None
         if direct:
             return dxo, None, None
@@ -560,7 +560,8 @@ class Segments:
         self.n_max = int(n_max)
         self.offsets = torch.empty((self.b + 1,), device=counts.device, dtype=torch.int32)
         self.pair2claim = torch.empty((max(self.b1, 1),), device=counts.device, dtype=torch.int32)
-        call("gh_seg_offsets", ptr(counts), self.b, ptr(self.offsets), ptr(self.pair2claim), self.b1, stream())
+        self.has = torch.empty((self.b, 1), device=counts.device, dtype=torch.float32)      # 1.0 where the claim has evidences
+        call("gh_seg_offsets", ptr(counts), self.b, ptr(self.offsets), ptr(self.pair2claim), self.b1, ptr(self.has), stream())
 
 
 class _SegBroadcast(torch.autograd.Function):       # basic_fc_model.py:80-92 _pad_left_tensor
@@ -609,6 +610,64 @@ def seg_broadcast(src, seg):
 
 def seg_pad(src, seg):
     return _SegPad.apply(src, seg)
+
+
+class _EvdAssemble(torch.autograd.Function):
+    """graph_based_semantic_structure.py:157-170,195-215: pad_right(avg) ++ article_source_embs(sources) and the slot mask."""
+
+    @staticmethod
+    def forward(ctx, avg, table, seg: Segments, sources, document):
+        avg = _f32(avg)
+        xa = avg.shape[1]
+        b, n = seg.b, seg.n_max
+        ds = 0
+        tb = None
+        if table is not None:
+            tb = _f32(table.detach())
+            ds = tb.shape[1]
+            if sources.dtype not in (torch.int32, torch.int64):
+                sources = sources.long()
+            sources = sources.contiguous()
+            assert sources.numel() == b * n
+        if document.dtype not in (torch.int32, torch.int64):
+            document = document.long()
+        document = document.contiguous()
+        r = document.shape[-1]
+        assert document.numel() == b * n * r
+        right = torch.empty((b, n, xa + ds), device=avg.device, dtype=torch.float32)
+        mask = torch.empty((b, n), device=avg.device, dtype=torch.float32)
+        call("gh_evd_assemble_fwd", ptr(avg), ptr(seg.offsets), ptr(tb), ptr(sources) if table is not None else None,
+             1 if (table is not None and sources.dtype == torch.int64) else 0, ptr(document),
+             1 if document.dtype == torch.int64 else 0, b, n, xa, ds, r, ptr(right), ptr(mask), stream())
+        ctx.seg, ctx.dims, ctx.table = seg, (xa, ds), table
+        ctx.sources = sources if table is not None else None
+        ctx.mark_non_differentiable(mask)
+        return right, mask
+
+    @staticmethod
+    def backward(ctx, g, _gm):
+        seg = ctx.seg
+        xa, ds = ctx.dims
+        g = _f32(g)
+        table = ctx.table
+        d_avg = torch.empty((seg.b1, xa), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        d_table = None
+        ret_table = None
+        if table is not None and table.requires_grad:
+            if _direct(table):
+                d_table = table.grad
+            else:
+                d_table = torch.zeros_like(table, dtype=torch.float32)
+                ret_table = d_table
+        src = ctx.sources
+        call("gh_evd_assemble_bwd", ptr(g), ptr(seg.offsets), ptr(src), 1 if (src is not None and src.dtype == torch.int64) else 0,
+             seg.b, seg.n_max, xa, ds if d_table is not None else 0, ptr(d_avg), ptr(d_table), stream())
+        return d_avg, ret_table, None, None, None
+
+
+def evd_assemble(avg, table, seg, sources, document):
+    """-> (right (B, n, Xa + Ds), mask (B, n) float).  table: the article-source embedding weight or None."""
+    return _EvdAssemble.apply(avg, table, seg, sources, document)
 
 
 class _MaskedMean(torch.autograd.Function):         # graph_based_semantic_structure.py:145,153

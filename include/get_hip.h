@@ -78,9 +78,10 @@ int gh_adj_pack_f32(const float* adj, int n, int r, uint64_t* bits, float* vals,
 
 /* Node-compact layout plan from the node counts of gh_graph_build (device arrays):
  *   goff[n+1] (see above); rowg[n*r] graph of every compact row; src[n*r] padded row index g*r+j of every compact
- *   row (scatter/gather between the two layouts); cids[n*r] = node_ids[src[.]] (NULL ok: not written). */
+ *   row (scatter/gather between the two layouts); cids[n*r] = node_ids[src[.]] and maskf[n*r] = (cids >= 1) as float,
+ *   the word attention's mask (both NULL ok: not written). */
 int gh_ragged_plan(const int32_t* n_nodes, const int32_t* node_ids, int n, int r, int32_t* goff, int32_t* rowg,
-                   int32_t* src, int32_t* cids, gh_stream_t stream);
+                   int32_t* src, int32_t* cids, float* maskf, gh_stream_t stream);
 
 /* ---- aggregation  a = A_hat x : Models/BiDAF/wrapper.py:192 `adj.matmul(x)` ----
  * x,y [n][r][h] (goff == NULL) or node-compact [m_real][h].  transpose: use A^T (backward of the weighted mode);
@@ -101,7 +102,7 @@ int gh_transpose_batch(int n, const void* const* src_host, void* const* dst_host
  * Input rows are x[m][din] (m = n*r), or emb[ids[m]][din] when ids != NULL (fused
  * embedding gather, graph_based_semantic_structure.py:100,150).
  * w_*: the reference's linear.weight tensors as stored: w_p[h][din]; w_z0,w_z1,w_r0,w_r1,w_h0,w_h1 [h][h].
- * b_z = bz0+bz1, b_r = br0+br1, b_h = bh0+bh1 (each [h]).
+ * b_?0, b_?1: the two biases of every gate (each [h]); the epilogues add both.
  * Saved for backward (all [m][h]): xp, a, z, r, rx, hh.  out [m][h].
  * drop_p > 0: the cell's input dropout (wrapper.py:185-190) is applied inside the first GEMM's loader with a
  * stateless mask -- element (m,k) kept iff hash(drop_seed, m*din+k) >= drop_p*2^32, scaled by 1/(1-drop_p);
@@ -118,7 +119,8 @@ int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const float* vals,
                      const float* x, const int32_t* ids, int n, int r, int din, int h,
                      const float* w_p, const float* w_z0, const float* w_z1, const float* w_r0,
                      const float* w_r1, const float* w_h0, const float* w_h1,
-                     const float* b_z, const float* b_r, const float* b_h,
+                     const float* b_z0, const float* b_z1, const float* b_r0, const float* b_r1,
+                     const float* b_h0, const float* b_h1,
                      float* xp, float* a, float* z, float* rr, float* rx, float* hh, float* out,
                      float drop_p, uint32_t drop_seed,
                      const float* score_w, float* score_x, float score_drop_p, uint32_t score_drop_seed,
@@ -205,19 +207,33 @@ int gh_set_stream_workspace(gh_stream_t stream, void* ptr, int64_t bytes);
 /* ---- plain linear y = x W^T + b (model head, graph_based_semantic_structure.py:69-72) ---- */
 int gh_linear_fwd(const float* x, const float* w, const float* bias, float* y, int m, int k, int n,
                   gh_stream_t stream);
-/* dx = g W (NULL ok; wt = W^T [k][n]); dw += g^T x; db += colsum(g) (NULL ok). */
-int gh_linear_bwd(const float* x, const float* wt, const float* g, int m, int k, int n,
+/* dx = g W (NULL ok; wt = W^T [k][n]); dw += g^T x; db += colsum(g) (NULL ok).  w = W as stored (NULL ok): layers with
+ * n <= 8 outputs (the 2-class head) then run as one row-per-wave kernel instead of three MFMA launches. */
+int gh_linear_bwd(const float* x, const float* wt, const float* w, const float* g, int m, int k, int n,
                   float* dx, float* dw, float* db, gh_stream_t stream);
 
 /* ---- a8  ragged helpers: Models/FCWithEvidences/basic_fc_model.py:80-121 ----
  * offsets[b+1] int32 prefix sum of evidence counts (device). */
-int gh_seg_offsets(const int64_t* counts, int b, int32_t* offsets, int32_t* pair2claim, int b1, gh_stream_t stream);
+/* has[b] (NULL ok) = 1.0 for claims with at least one evidence: row 0 of pad_right(x) is x's first row of the claim times has. */
+int gh_seg_offsets(const int64_t* counts, int b, int32_t* offsets, int32_t* pair2claim, int b1, float* has,
+                   gh_stream_t stream);
 int gh_seg_broadcast(const float* src, const int32_t* pair2claim, float* dst, int b1, int x, gh_stream_t stream);
 int gh_seg_sum(const float* src, const int32_t* offsets, float* dst, int b, int x, gh_stream_t stream);
 int gh_seg_pad(const float* src, const int32_t* offsets, float* dst, int b, int n_max, int x, int dst_ld,
                gh_stream_t stream);
 int gh_seg_unpad(const float* src, const int32_t* offsets, float* dst, int b, int n_max, int x, int src_ld,
                  gh_stream_t stream);
+/* ---- evidence-level assembly: graph_based_semantic_structure.py:157-170,195-215 in one launch ----
+ * right[b][slot][0:xa] = avg row of the claim's slot-th evidence (zeros beyond its count); right[b][slot][xa:xa+ds] =
+ * table[max(sources[b][slot], 0)] (article-source embedding, -1 padding -> row 0; ds = 0: no table);
+ * mask[b][slot] = (sum_r document[b][slot][r] >= 1).  sources/document are int32 or int64 (flag). */
+int gh_evd_assemble_fwd(const float* avg, const int32_t* offsets, const float* table, const void* sources, int sources_i64,
+                        const void* document, int document_i64, int b, int n_max, int xa, int ds, int r,
+                        float* right, float* mask, gh_stream_t stream);
+/* Backward: d_avg[b1][xa] (NULL ok) = unpad(g[:, :, :xa]); d_table[s][ds] += the g[:, :, xa:] rows of the slots with source s,
+ * summed in slot order (deterministic).  g [b][n_max][xa+ds]. */
+int gh_evd_assemble_bwd(const float* g, const int32_t* offsets, const void* sources, int sources_i64, int b, int n_max,
+                        int xa, int ds, float* d_avg, float* d_table, gh_stream_t stream);
 /* masked mean over claim nodes (graph_based_semantic_structure.py:153): dst[b][h] = sum_l hid*mask / len */
 int gh_masked_mean_fwd(const float* hid, const int32_t* ids, const float* lens, float* dst, int b, int l, int h,
                        gh_stream_t stream);

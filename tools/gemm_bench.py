@@ -28,9 +28,9 @@ def bench(m, k, n, reps=20, mode="fwd"):
         if mode == "fwd":
             call("gh_linear_fwd", ptr(x), ptr(w), ptr(b), ptr(y), m, k, n, stream())
         elif mode == "dx":
-            call("gh_linear_bwd", ptr(x), ptr(wt), ptr(g), m, k, n, ptr(dx), None, None, stream())
+            call("gh_linear_bwd", ptr(x), ptr(wt), ptr(w), ptr(g), m, k, n, ptr(dx), None, None, stream())
         else:
-            call("gh_linear_bwd", ptr(x), ptr(wt), ptr(g), m, k, n, None, ptr(dw), None, stream())
+            call("gh_linear_bwd", ptr(x), ptr(wt), ptr(w), ptr(g), m, k, n, None, ptr(dw), None, stream())
 
     for _ in range(40):          # long warm-up: the clock ramps for several ms after idle
         run()

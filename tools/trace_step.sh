@@ -4,7 +4,7 @@ TAG=${1:-x}; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r2; mkdir -p $O
 rm -rf /tmp/trace_$TAG
-rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_$TAG -- python bench.py --steps 3 --warmup 2 --no-profile --no-cpu-baseline "$@" > $O/trace_bench_$TAG.json 2> $O/trace_$TAG.err
+rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_$TAG -- python bench.py --steps 3 --warmup 2 --no-profile --no-cpu-baseline --no-series "$@" > $O/trace_bench_$TAG.json 2> $O/trace_$TAG.err
 python - <<P > $O/trace_$TAG.txt
 import csv, glob
 f = glob.glob("/tmp/trace_$TAG/**/*kernel_trace.csv", recursive=True)[0]
