@@ -40,7 +40,7 @@ gemm_nt_kernel(const Launch L_byval) {
   constexpr int SA = (NAI + NW - 1) / NW, SB = (NBI + NW - 1) / NW; // ... per wave
   constexpr int STAGE = (BM + BN) * 64;
   constexpr int EP_PITCH = BN + 4;                                 // floats: 16-byte rows, 8 consecutive rows cover all banks
-  constexpr int EP_BYTES = 16 * WM * EP_PITCH * 4 + NW * 64 * 16;  // staged rows + row-reduction partials
+  constexpr int EP_BYTES = 16 * WM * EP_PITCH * 4 + NW * 64 * 16 + BN * 4;  // staged rows + row-reduction partials + bias
   constexpr int SMEM = 2 * STAGE > EP_BYTES ? 2 * STAGE : EP_BYTES;
   constexpr unsigned OOB = 0x80000000u;
   constexpr int NH = NI / 2;                                       // B fragment batches: X = tiles [0,NH), Y = [NH,NI)
@@ -193,22 +193,7 @@ gemm_nt_kernel(const Launch L_byval) {
   const int nv = min(NI, max(0, (N - wcol + 15) >> 4));
 #endif
   const int nvX = min(NH, nv), nvY = nv - nvX;
-  // CNT < 0: run-time count (odd shapes)
-  auto mma = [&](const f32x4* a, const f32x4* b, int ni0, auto CNT, int cnt_rt) __attribute__((always_inline)) {
-    constexpr int cnt = decltype(CNT)::value;
-    if constexpr (cnt >= 0) {
-      mma_n(a, b, ni0, CNT);
-    } else {
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < NI - NH; ++i)
-          if (i < cnt_rt)
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-              acc[mi][ni0 + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[i][s], a[mi][s], acc[mi][ni0 + i], 0, 0, 0);
-    }
-  };
+  auto mma = [&](const f32x4* a, const f32x4* b, int ni0, auto CNT) __attribute__((always_inline)) { mma_n(a, b, ni0, CNT); };
   // stateless input dropout (wrapper.py:189-190) on the A fragments of segment 0: element (row, k) of [rows][drop_ld]
   auto drop_a = [&](int t, f32x4* a) __attribute__((always_inline)) {
     const int tt = t + toff;
@@ -235,23 +220,23 @@ gemm_nt_kernel(const Launch L_byval) {
       read_a(st, aC);
       read_b(st, bX, 0, NH);
       __builtin_amdgcn_sched_barrier(0);
-      if (t > 0) mma(aP, bY, NH, CY, nvY);         // second half of tile t-1 covers the latency of the reads above
+      if (t > 0) mma(aP, bY, NH, CY);              // second half of tile t-1 covers the latency of the reads above
       __builtin_amdgcn_sched_barrier(0);
       read_b(st, bY, NH, NI - NH);
       if (drop_mode == 1) drop_a(t, aC);
       __builtin_amdgcn_sched_barrier(0);
-      mma(aC, bX, 0, CX, nvX);
+      mma(aC, bX, 0, CX);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) aP[mi] = aC[mi];
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
-    mma(aP, bY, NH, CY, nvY);
+    mma(aP, bY, NH, CY);
   };
-  if (nvX == NH && nvY == NI - NH) run(std::integral_constant<int, NH>{}, std::integral_constant<int, NI - NH>{});
-  else if (nvX == NH && nvY == NI - NH - 1) run(std::integral_constant<int, NH>{}, std::integral_constant<int, NI - NH - 1>{});
-  else run(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{});
+  // (any other count -- narrow problems, odd column blocks -- computes every tile: the B rows beyond N are zeros in LDS)
+  if (nvX == NH && nvY == NI - NH - 1) run(std::integral_constant<int, NH>{}, std::integral_constant<int, NI - NH - 1>{});
+  else run(std::integral_constant<int, NH>{}, std::integral_constant<int, NI - NH>{});
 
   // -------------------------------------------------------------------- epilogue on whole rows
   // Two passes (mi = 0, 1), each: accumulators (+bias) -> LDS, then a LINEAR pass over the 16*WM staged rows: item i
@@ -274,81 +259,116 @@ gemm_nt_kernel(const Launch L_byval) {
   const bool scorer = (epi == EPI_TANH_H) && (P.w2 != nullptr);
   const bool rowred = (epi == EPI_ATT) || scorer;
   float* ep = reinterpret_cast<float*>(smem);
+  float* const ep_bias_ptr = ep + 16 * WM * EP_PITCH + NW * 64 * 4;
   const int N4 = N >> 2;
   constexpr int C4 = EP_PITCH / 4;
   constexpr int ITEMS = 16 * WM * C4;
   constexpr int NIT = (ITEMS + NTHR - 1) / NTHR;
-  f32x4 bias4[NI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int col = wcol + ni * 16 + 4 * q;
-    bias4[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (bias && col < N) bias4[ni] = *reinterpret_cast<const f32x4*>(bias + col);
-    if (P.bias2 && col < N) bias4[ni] += *reinterpret_cast<const f32x4*>(P.bias2 + col);
+  const float* bias2 = P.bias2;
+  // bias (sum) staged in LDS behind the row-reduction partials: the linear pass reads it next to the staged row
+  float* bsum = ep_bias_ptr;
+  for (int c = tid; c < BN; c += NTHR) {
+    float bv = 0.f;
+    if (c < N) { if (bias) bv = bias[c]; if (bias2) bv += bias2[c]; }
+    bsum[c] = bv;
   }
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
+  auto epilogue_pass = [&](auto MIT) __attribute__((always_inline)) {
+    constexpr int mi = decltype(MIT)::value;
     if (mi > 0) __syncthreads();                  // previous pass consumed (the loop's last barrier covers pass 0)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
-      *reinterpret_cast<f32x4*>(ep + (wm * 16 + l15) * EP_PITCH + wcol + ni * 16 + 4 * q) = acc[mi][ni] + bias4[ni];
+      *reinterpret_cast<f32x4*>(ep + (wm * 16 + l15) * EP_PITCH + wcol + ni * 16 + 4 * q) = acc[mi][ni];
     __syncthreads();
-    // the pass holds, for every wave row b < WM, tile rows b*16*MI + mi*16 + [0,16)
+    // the pass holds, for every wave row b < WM, tile rows b*16*MI + mi*16 + [0,16).  Items are processed CH at a
+    // time: every load of the chunk (LDS + the epilogue's input streams) is issued before the first store -- the
+    // pointers may alias as far as the compiler knows, so a plain loop would serialise 11 memory round trips per pass.
+    auto pass = [&](auto EPI) __attribute__((always_inline)) {
+      constexpr int E = decltype(EPI)::value;
+      constexpr int CH = 4;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int i = tid + it * NTHR;
-      const int rr = i / C4, c4 = i - rr * C4;
-      const int row = m0 + (rr >> 4) * 16 * MI + mi * 16 + (rr & 15);
-      if ((ITEMS % NTHR == 0 || i < ITEMS) && c4 < N4 && row < M) {
-        const int col = 4 * c4;
-        const size_t o = (size_t)row * ldc + col;
-        float* sp = ep + rr * EP_PITCH + col;
-        float4 v = *reinterpret_cast<const float4*>(sp);
-        if (epi == EPI_STORE) {
-          if (drop_mode == 3)
-            v = drop4(v, drop_seed, (unsigned)row * (unsigned)drop_ld + (unsigned)(P.drop_col0 + col), drop_thresh, drop_scale);
-          if (accumulate) {
-            const float4 p = *reinterpret_cast<const float4*>(C + o);
-            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+      for (int it0 = 0; it0 < NIT; it0 += CH) {
+        float4 xa[CH], xb[CH], xc[CH];
+        auto where = [&](int j, int& row, int& col, float*& sp) __attribute__((always_inline)) {
+          const int i = tid + (it0 + j) * NTHR;
+          const int rr = i / C4, c4 = i - rr * C4;
+          row = m0 + (rr >> 4) * 16 * MI + mi * 16 + (rr & 15);
+          col = 4 * c4;
+          sp = ep + rr * EP_PITCH + col;
+          return (it0 + j < NIT) && (ITEMS % NTHR == 0 || i < ITEMS) && c4 < N4 && row < M;
+        };
+        if (E != EPI_SIGMOID_Z) {
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            int row, col; float* sp;
+            if (where(j, row, col, sp)) {
+              const size_t o = (size_t)row * ldc + col;
+              if (E == EPI_STORE) { if (accumulate) xa[j] = *reinterpret_cast<const float4*>(C + o); }
+              else if (E == EPI_SIGMOID_R) xa[j] = *reinterpret_cast<const float4*>(in0 + o);
+              else if (E == EPI_TANH_H) { xa[j] = *reinterpret_cast<const float4*>(in0 + o); xb[j] = *reinterpret_cast<const float4*>(in1 + o); }
+              else if (E == EPI_BWD_DRX) {
+                xa[j] = *reinterpret_cast<const float4*>(in0 + o);
+                xb[j] = *reinterpret_cast<const float4*>(in1 + o);
+                xc[j] = *reinterpret_cast<const float4*>(out1 + o);
+              } else if (E == EPI_ATT)
+                xa[j] = *reinterpret_cast<const float4*>(P.u + (size_t)(P.rowg ? P.rowg[row] : row / P.R) * P.ldu + col);
+            }
           }
-          *reinterpret_cast<float4*>(C + o) = v;
-        } else if (epi == EPI_SIGMOID_Z) {
-          *reinterpret_cast<float4*>(C + o) = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
-        } else if (epi == EPI_SIGMOID_R) {
-          const float4 x = *reinterpret_cast<const float4*>(in0 + o);
-          const float4 r4 = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
-          *reinterpret_cast<float4*>(C + o) = r4;
-          *reinterpret_cast<float4*>(out1 + o) = make_float4(r4.x * x.x, r4.y * x.y, r4.z * x.z, r4.w * x.w);
-        } else if (epi == EPI_TANH_H) {
-          const float4 z = *reinterpret_cast<const float4*>(in0 + o);
-          const float4 x = *reinterpret_cast<const float4*>(in1 + o);
-          const float4 h = make_float4(tanhf_(v.x), tanhf_(v.y), tanhf_(v.z), tanhf_(v.w));
-          float4 y = make_float4(h.x * z.x + x.x * (1.f - z.x), h.y * z.y + x.y * (1.f - z.y),
-                                 h.z * z.z + x.z * (1.f - z.z), h.w * z.w + x.w * (1.f - z.w));
-          *reinterpret_cast<float4*>(C + o) = h;
-          *reinterpret_cast<float4*>(out1 + o) = y;
-          if (scorer) {    // the word scorer sees dropout(out) (its own input dropout, wrapper.py:189-190)
-            if (drop_mode == 2)
-              y = drop4(y, drop_seed, (unsigned)row * (unsigned)drop_ld + (unsigned)col, drop_thresh, drop_scale);
-            *reinterpret_cast<float4*>(sp) = y;
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          int row, col; float* sp;
+          if (!where(j, row, col, sp)) continue;
+          const float4 v4 = *reinterpret_cast<const float4*>(sp);
+          const float4 b4 = *reinterpret_cast<const float4*>(bsum + col);
+          float4 w = make_float4(v4.x + b4.x, v4.y + b4.y, v4.z + b4.z, v4.w + b4.w);
+          const size_t o = (size_t)row * ldc + col;
+          if (E == EPI_STORE) {
+            if (drop_mode == 3)
+              w = drop4(w, drop_seed, (unsigned)row * (unsigned)drop_ld + (unsigned)(P.drop_col0 + col), drop_thresh, drop_scale);
+            if (accumulate) { w.x += xa[j].x; w.y += xa[j].y; w.z += xa[j].z; w.w += xa[j].w; }
+            *reinterpret_cast<float4*>(C + o) = w;
+          } else if (E == EPI_SIGMOID_Z) {
+            *reinterpret_cast<float4*>(C + o) = make_float4(sigmoidf_(w.x), sigmoidf_(w.y), sigmoidf_(w.z), sigmoidf_(w.w));
+          } else if (E == EPI_SIGMOID_R) {
+            const float4 x = xa[j];
+            const float4 r4 = make_float4(sigmoidf_(w.x), sigmoidf_(w.y), sigmoidf_(w.z), sigmoidf_(w.w));
+            *reinterpret_cast<float4*>(C + o) = r4;
+            *reinterpret_cast<float4*>(out1 + o) = make_float4(r4.x * x.x, r4.y * x.y, r4.z * x.z, r4.w * x.w);
+          } else if (E == EPI_TANH_H) {
+            const float4 z = xa[j], x = xb[j];
+            const float4 h = make_float4(tanhf_(w.x), tanhf_(w.y), tanhf_(w.z), tanhf_(w.w));
+            float4 y = make_float4(h.x * z.x + x.x * (1.f - z.x), h.y * z.y + x.y * (1.f - z.y),
+                                   h.z * z.z + x.z * (1.f - z.z), h.w * z.w + x.w * (1.f - z.w));
+            *reinterpret_cast<float4*>(C + o) = h;
+            *reinterpret_cast<float4*>(out1 + o) = y;
+            if (scorer) {    // the word scorer sees dropout(out) (its own input dropout, wrapper.py:189-190)
+              if (drop_mode == 2)
+                y = drop4(y, drop_seed, (unsigned)row * (unsigned)drop_ld + (unsigned)col, drop_thresh, drop_scale);
+              *reinterpret_cast<float4*>(sp) = y;
+            }
+          } else if (E == EPI_BWD_DRX) {
+            const float4 x = xa[j], r4 = xb[j];
+            float4 d = xc[j];
+            *reinterpret_cast<float4*>(C + o) =
+                make_float4(w.x * x.x * r4.x * (1.f - r4.x), w.y * x.y * r4.y * (1.f - r4.y),
+                            w.z * x.z * r4.z * (1.f - r4.z), w.w * x.w * r4.w * (1.f - r4.w));
+            d.x += w.x * r4.x; d.y += w.y * r4.y; d.z += w.z * r4.z; d.w += w.w * r4.w;
+            *reinterpret_cast<float4*>(out1 + o) = d;
+          } else if (E == EPI_ATT) {
+            const float4 u4 = xa[j];
+            const float4 t4 = make_float4(tanhf_(w.x + u4.x), tanhf_(w.y + u4.y), tanhf_(w.z + u4.z), tanhf_(w.w + u4.w));
+            *reinterpret_cast<float4*>(C + o) = t4;
+            *reinterpret_cast<float4*>(sp) = t4;
           }
-        } else if (epi == EPI_BWD_DRX) {
-          const float4 x = *reinterpret_cast<const float4*>(in0 + o);
-          const float4 r4 = *reinterpret_cast<const float4*>(in1 + o);
-          float4 d = *reinterpret_cast<const float4*>(out1 + o);
-          *reinterpret_cast<float4*>(C + o) =
-              make_float4(v.x * x.x * r4.x * (1.f - r4.x), v.y * x.y * r4.y * (1.f - r4.y),
-                          v.z * x.z * r4.z * (1.f - r4.z), v.w * x.w * r4.w * (1.f - r4.w));
-          d.x += v.x * r4.x; d.y += v.y * r4.y; d.z += v.z * r4.z; d.w += v.w * r4.w;
-          *reinterpret_cast<float4*>(out1 + o) = d;
-        } else if (epi == EPI_ATT) {
-          const float4 u4 = *reinterpret_cast<const float4*>(P.u + (size_t)(P.rowg ? P.rowg[row] : row / P.R) * P.ldu + col);
-          const float4 t4 = make_float4(tanhf_(v.x + u4.x), tanhf_(v.y + u4.y), tanhf_(v.z + u4.z), tanhf_(v.w + u4.w));
-          *reinterpret_cast<float4*>(C + o) = t4;
-          *reinterpret_cast<float4*>(sp) = t4;
         }
       }
-    }
+    };
+    if (epi == EPI_STORE) pass(std::integral_constant<int, EPI_STORE>{});
+    else if (epi == EPI_SIGMOID_Z) pass(std::integral_constant<int, EPI_SIGMOID_Z>{});
+    else if (epi == EPI_SIGMOID_R) pass(std::integral_constant<int, EPI_SIGMOID_R>{});
+    else if (epi == EPI_TANH_H) pass(std::integral_constant<int, EPI_TANH_H>{});
+    else if (epi == EPI_BWD_DRX) pass(std::integral_constant<int, EPI_BWD_DRX>{});
+    else if (epi == EPI_ATT) pass(std::integral_constant<int, EPI_ATT>{});
     if (rowred) {
       // e[row][c] = sum_k y[row][k] w2[c][k] for the 16*WM finished rows in LDS: a [16 x N] x [N x <=8] product per row
       // tile, on MFMA.  Wave (b, kp) takes row tile b and every KSPL-th K tile; partials meet in LDS (fixed order).
@@ -382,7 +402,9 @@ gemm_nt_kernel(const Launch L_byval) {
         }
       }
     }
-  }
+  };
+  epilogue_pass(std::integral_constant<int, 0>{});
+  epilogue_pass(std::integral_constant<int, 1>{});
 #endif
 }
 
