@@ -26,8 +26,16 @@
 namespace gh {
 
 __device__ __forceinline__ int nt_swz(int j) { return (0x78 >> (2 * j)) & 3; }     // {0,2,3,1}
+__device__ __forceinline__ unsigned nt_pack_bf16(float a, float b) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));     // v_cvt_pk_bf16_f32 (RNE)
+}
 
-template <int WM, int WN, int NI, int MI = 2>
+// BF: opt-in operand mode (gh_set_gemm_mode(1)): fragments are rounded to bf16 in registers (v_cvt_pk_bf16_f32, RNE) and
+// one v_mfma_f32_16x16x16_bf16 spans the K tile (a lane's four k values = its float4); storage and epilogues stay fp32.
+template <int WM, int WN, int NI, int MI = 2, bool BF = false>
 __global__ void __launch_bounds__(WM * WN * 64, 3)
 gemm_nt_kernel(const Launch L_byval) {
   (void)L_byval;
@@ -177,6 +185,24 @@ gemm_nt_kernel(const Launch L_byval) {
   // swapped operands: acc[mi][ni][r] = C[row = wrow + mi*16 + l15][col = wcol + ni*16 + 4*q + r]
   auto mma_n = [&](const f32x4* a, const f32x4* b, int ni0, auto CNT) __attribute__((always_inline)) {
     constexpr int cnt = decltype(CNT)::value;
+    if constexpr (BF) {
+      typedef short s16x4 __attribute__((ext_vector_type(4)));
+      s16x4 ab[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const uint2 u = make_uint2(nt_pack_bf16(a[mi][0], a[mi][1]), nt_pack_bf16(a[mi][2], a[mi][3]));
+        ab[mi] = __builtin_bit_cast(s16x4, u);
+      }
+#pragma unroll
+      for (int i = 0; i < cnt; ++i) {
+        const uint2 u = make_uint2(nt_pack_bf16(b[i][0], b[i][1]), nt_pack_bf16(b[i][2], b[i][3]));
+        const s16x4 bb = __builtin_bit_cast(s16x4, u);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[mi][ni0 + i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bb, ab[mi], acc[mi][ni0 + i], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll

@@ -86,11 +86,17 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
       if (L.p[i].epi == EPI_TANH_H && L.p[i].w2) return hipErrorInvalidValue;   // so does the fused scorer projection
   bool launched = false;
   if (fast && !tn) {
-    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, NI, 2>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
+    // gh_set_gemm_mode(1): bf16 operand rounding in the activation-sized (64x320 tile) launches only
+    if (g_gemm_mode == 1 && WM == 2 && WN == 2 && NI == 10) {
+      if constexpr (WM == 2 && WN == 2 && NI == 10)
+        hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 10, 2, true>), dim3(grid), dim3(256), 0, s, L);
+    } else
+      hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, NI, 2>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
     launched = true;
   } else if (fast && tn) {
     if constexpr (WM == 2 && WN == 2 && NI == 10) {        // weight gradients always take the 64x320 tile (Batch: big = tn || ...)
-      hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 10>), dim3(grid), dim3(256), 0, s, L);
+      if (g_gemm_mode == 1) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 10, true>), dim3(grid), dim3(256), 0, s, L);
+      else hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 10>), dim3(grid), dim3(256), 0, s, L);
       launched = true;
     }
   }
@@ -265,7 +271,9 @@ struct Batch {
   Batch(bool tn_, int rows_hint, hipStream_t s_) : tn(tn_), s(s_) {
     const Workspace w = workspace_for(s_);
     g_ws = w.p; g_ws_bytes = w.bytes;
-    big = tn_ || rows_hint >= 8192;      // 64x320 tile (2x2 waves) for the activation-sized GEMMs, 32x320 (1x4) for few-row ones
+    static int force_small = -1;
+    if (force_small < 0) { const char* e = getenv("GH_NT_FORCE_SMALL"); force_small = e ? atoi(e) : 0; }
+    big = tn_ || (rows_hint >= 8192 && !force_small);      // 64x320 tile (2x2 waves) for the activation-sized GEMMs, 32x320 (1x4) for few-row ones
     bm = big ? 64 : 32;
     bn = 320;
     reset();
@@ -374,7 +382,24 @@ struct Batch {
     reset();
   }
 
-  hipError_t launch_any() { return big ? launch_cfg<2, 2, 10>(L, tn, s) : launch_cfg<1, 4, 5>(L, tn, s); }
+  hipError_t launch_any() {
+    if (big && !tn && L.ksplit == 1) {
+      // Occupancy-aware tile choice.  The chip holds 768 workgroups of either configuration (3 per CU); a grid of 64-row
+      // tiles that ends in a thinly filled last round (e.g. 976 workgroups = 1.27 rounds, the node-compact single-problem
+      // launches) runs faster on 32-row tiles (1937 workgroups = 2.52 rounds): measured 83 vs 78 TF at K = 300.
+      static int mode = -1;
+      if (mode < 0) { const char* e = getenv("GH_NT_TILE_RULE"); mode = e ? atoi(e) : 1; }
+      const double r = (double)L.m_tiles * L.nprob / 768.0;
+      const double frac = r - (double)(long long)r;
+      if (mode == 1 && g_gemm_mode == 0 && r < 3.0 && frac > 0.02 && frac < 0.45) {
+        int mt = 0;
+        for (int i = 0; i < L.nprob; ++i) { const int t = (L.p[i].M + 31) / 32; if (t > mt) mt = t; }
+        L.m_tiles = mt;
+        return launch_cfg<1, 4, 5>(L, tn, s);
+      }
+    }
+    return big ? launch_cfg<2, 2, 10>(L, tn, s) : launch_cfg<1, 4, 5>(L, tn, s);
+  }
 
   // Few-row NT GEMMs (evidence level, head): too few row tiles to fill 256 CUs, so split K across
   // workgroups, keep the partial tiles in the workspace and finish with nt_finish_kernel.

@@ -20,7 +20,9 @@
 
 namespace gh {
 
-template <int WM, int WN, int NI>
+// BF: opt-in bf16 operand mode (see gemm_nt.hip.h): the four k-steps of a tile are packed into one bf16 MFMA operand
+// (slot s of lane q = k-row 4 s + q, for A and B alike), fp32 accumulate.
+template <int WM, int WN, int NI, bool BF = false>
 __global__ void __launch_bounds__(WM * WN * 64, 3)
 gemm_tn_kernel(const Launch L_byval) {
   (void)L_byval;
@@ -156,6 +158,43 @@ gemm_tn_kernel(const Launch L_byval) {
   dma_tile(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (BF) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    auto pk = [](float a, float b, float c, float d) __attribute__((always_inline)) {
+      return __builtin_bit_cast(s16x4, make_uint2(nt_pack_bf16(a, b), nt_pack_bf16(c, d)));
+    };
+    Frag f[4];
+    for (int t = 0; t < T; ++t) {
+      const int st = t & 1;
+      if (t + 1 < T) dma_tile(t + 1, st ^ 1);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) read_frag(st, s4, f[s4]);
+      s16x4 ab[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) ab[mi] = pk(f[0].a[mi], f[1].a[mi], f[2].a[mi], f[3].a[mi]);
+      if (colsum) csum += f[0].a + f[1].a + f[2].a + f[3].a;
+#pragma unroll
+      for (int g = 0; g < NG4; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const s16x4 bb = pk(f[0].b4[g][c], f[1].b4[g][c], f[2].b4[g][c], f[3].b4[g][c]);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[mi][4 * g + c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab[mi], bb, acc[mi][4 * g + c], 0, 0, 0);
+        }
+#pragma unroll
+      for (int g = 0; g < NG2; ++g)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const s16x4 bb = pk(f[0].b2[g][c], f[1].b2[g][c], f[2].b2[g][c], f[3].b2[g][c]);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[mi][4 * NG4 + 2 * g + c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab[mi], bb, acc[mi][4 * NG4 + 2 * g + c], 0, 0, 0);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
   Frag f0, f1;
   for (int t = 0; t < T; ++t) {
     const int st = t & 1;
@@ -173,6 +212,7 @@ gemm_tn_kernel(const Launch L_byval) {
     mma(f1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
   }
 
   if (colsum && wn == 0) {

@@ -491,7 +491,6 @@ scorer_gsl_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ d
   if (xs_in) {      // projection already done by the producing cell's epilogue (gh_ggnn_cell_fwd score_x): one float per node
     if (tid < R) xs[tid] = xs_in[(unsigned)(tid < NR ? row0 + tid : (pads_collapsed ? pad0 : pad0 + tid))];
   } else {
-#pragma unroll 4
   for (int j = wave; j < R; j += 4) {
     float acc = 0.f;
     const unsigned frow = (unsigned)(j < NR ? row0 + j : (pads_collapsed ? pad0 : pad0 + j));
