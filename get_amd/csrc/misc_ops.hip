@@ -286,7 +286,7 @@ int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m
 
 // ---------------------------------------------------------------------------- concat attention: masked softmax + weighted reduce
 // e [b][l][C] -> weights = softmax over l (two_branches_attention.py:142-146), attended[b][d][c] = sum_l right[b][l][d] w[l][c] (:147)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ mask, const float* __restrict__ right,
                        const int32_t* __restrict__ goff, int Lmax, int Dr, int C, float* __restrict__ weights,
                        float* __restrict__ attended) {
@@ -298,7 +298,8 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
   const int L = goff ? goff[b + 1] - row0 : Lmax;
   const float* eb = e + (size_t)row0 * C;
   const float* mb = mask + (size_t)row0;
-  for (int c = wave; c < C; c += 4) {
+  const int NT = blockDim.x, NWV = NT >> 6;
+  for (int c = wave; c < C; c += NWV) {
     float mx = -INFINITY;
     for (int l = lane; l < L; l += 64)
       if (mb[l] != 0.f) mx = fmaxf(mx, eb[l * C + c]);
@@ -315,10 +316,10 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
   }
   __syncthreads();
   if (blockIdx.y == 0)
-    for (int i = tid; i < L * C; i += 256) weights[(size_t)row0 * C + i] = ws[i];
+    for (int i = tid; i < L * C; i += NT) weights[(size_t)row0 * C + i] = ws[i];
   // attended[d][c] = sum_l right[l][d] w[l][c]: blockIdx.y owns a slab of 64 float4 columns, the four
   // waves take every fourth row (16-byte coalesced reads), partial sums meet in LDS
-  float* part = ws + Lmax * C;                   // [4][64][4][C] floats
+  float* part = ws + Lmax * C;                   // [NWV][64][4][C] floats
   const int D4 = Dr / 4;
   const int d4 = blockIdx.y * 64 + lane;
   float acc[4][8];
@@ -329,7 +330,7 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
   if (d4 < D4) {
     const float4* rb = reinterpret_cast<const float4*>(right + (size_t)row0 * Dr) + d4;
 #pragma unroll 4
-    for (int l = wave; l < L; l += 4) {
+    for (int l = wave; l < L; l += NWV) {
       const float4 rv = rb[(size_t)l * D4];
 #pragma unroll
       for (int c = 0; c < 8; ++c)
@@ -345,12 +346,12 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
     for (int c = 0; c < 8; ++c)
       if (c < C) part[((wave * 64 + lane) * 4 + k) * C + c] = acc[k][c];
   __syncthreads();
-  for (int i = tid; i < 64 * 4 * C; i += 256) {
+  for (int i = tid; i < 64 * 4 * C; i += NT) {
     const int ln = i / (4 * C), rem = i % (4 * C);     // rem = k*C + c -> output offset within the float4 column group
     const int dd = (blockIdx.y * 64 + ln) * 4 + rem / C;
     if (dd < Dr) {
       float v = 0.f;
-      for (int w = 0; w < 4; ++w) v += part[((w * 64 + ln) * 4) * C + rem];
+      for (int w = 0; w < NWV; ++w) v += part[((w * 64 + ln) * 4) * C + rem];
       if (L == 0) v = NAN;                      // no rows at all: the reference's softmax over an all -inf column
       attended[((size_t)b * Dr + dd) * C + rem % C] = v;
     }
@@ -360,10 +361,11 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
 int launch_att_softmax_fwd(const float* e, const float* mask, const float* right, const int32_t* goff, int m_real,
                            int b, int l, int dr, int heads, float* weights, float* attended, hipStream_t s) {
   GH_REQUIRE(dr % 4 == 0 && (reinterpret_cast<uintptr_t>(right) & 15) == 0, "att_softmax_fwd: right rows must be float4-shaped (dr=%d)", dr);
-  const size_t lds = ((size_t)l * heads + 4 * 64 * 4 * heads) * 4;
+  const int nthr = 256;      // (8 waves per pair measured no faster: the kernel is not parallelism-bound)
+  const size_t lds = ((size_t)l * heads + (nthr / 64) * 64 * 4 * heads) * 4;
   GH_REQUIRE(lds <= 64 * 1024, "att_softmax_fwd: sequence %d x heads %d too large", l, heads);
   prof_begin(s, PROF_ATT_SOFTMAX_FWD);
-  hipLaunchKernelGGL(att_softmax_fwd_kernel, dim3(b, (dr / 4 + 63) / 64), dim3(256), lds, s, e, mask, right, goff, l, dr,
+  hipLaunchKernelGGL(att_softmax_fwd_kernel, dim3(b, (dr / 4 + 63) / 64), dim3(nthr), lds, s, e, mask, right, goff, l, dr,
                      heads, weights, attended);
   const double rows = goff ? (double)m_real : (double)b * l;
   prof_end(PROF_ATT_SOFTMAX_FWD, 4.0 * (rows * dr + 2.0 * rows * heads + rows + (double)b * dr * heads), s);
@@ -373,7 +375,7 @@ int launch_att_softmax_fwd(const float* e, const float* mask, const float* right
 
 // backward of the softmax/reduce: dw[l][c] = sum_d right[l][d] g_att[d][c] (+ g_w) ; de = w (dw - sum_l w dw) ;
 // dright[l][d] = sum_c w[l][c] g_att[d][c]  (first contribution; the GEMM adds dpre W1r on top)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict__ weights,
                        const float* __restrict__ g_att, const float* __restrict__ g_w,
                        const int32_t* __restrict__ goff, int Lmax, int Dr, int C,
@@ -386,14 +388,15 @@ att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict_
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = goff ? goff[b] : b * Lmax;
   const int L = goff ? goff[b + 1] - row0 : Lmax;
-  for (int i = tid; i < Dr * C; i += 256) ga[(i % C) * Dr + i / C] = g_att[(size_t)b * Dr * C + i];
-  for (int i = tid; i < L * C; i += 256) ws[i] = weights[(size_t)row0 * C + i];
+  const int NT = blockDim.x, NWV = NT >> 6;
+  for (int i = tid; i < Dr * C; i += NT) ga[(i % C) * Dr + i / C] = g_att[(size_t)b * Dr * C + i];
+  for (int i = tid; i < L * C; i += NT) ws[i] = weights[(size_t)row0 * C + i];
   __syncthreads();
   const int D4 = Dr / 4;
   // two rows per wave in flight: both rows' loads are issued before either is consumed (a wave walks ~16 rows
   // one after the other, so the kernel is bound by the memory latency per row, not by bandwidth)
-  for (int l = wave; l < L; l += 8) {
-    const int lb = l + 4;
+  for (int l = wave; l < L; l += 2 * NWV) {
+    const int lb = l + NWV;
     const bool has_b = lb < L;
     const int lbc = has_b ? lb : l;
     float pa[8], pb[8], wa[8], wb[8];
@@ -434,7 +437,7 @@ att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict_
     }
   }
   __syncthreads();
-  for (int c = wave; c < C; c += 4) {
+  for (int c = wave; c < C; c += NWV) {
     float sum = 0.f;
     for (int l = lane; l < L; l += 64) sum += ws[l * C + c] * dw[l * C + c];
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -463,25 +466,34 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
 
 // dpre[m][n] = (sum_c de[m][c] w2[c][n]) (1 - t[m][n]^2) ; du[b][n] = sum_l dpre[b*L+l][n] ;
 // dw2 partial [b][c][n] = sum_l de[m][c] t[m][n]   (summed over b by reduce_partials afterwards).
-// One workgroup per pair: threads = (float4 column, row lane); row lanes take every RL-th row.
+// One workgroup per (pair, column slab of S4 float4): threads = (float4 column of the slab, row lane); row lanes take
+// every RL-th row.  Slabs triple the number of workgroups (2880 at the bench shape) and cut a thread's serial row walk
+// to a third -- the one-workgroup-per-pair version was latency-bound at 2.0 TB/s.
 __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __restrict__ w2, const float* __restrict__ t,
-                                const int32_t* __restrict__ goff, int Lmax, int Ha, int C, int RL,
+                                const int32_t* __restrict__ goff, int Lmax, int Ha, int C, int RL, int S4,
                                 float* __restrict__ dpre, float* __restrict__ du, float* __restrict__ dw2_part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-  float4* red = reinterpret_cast<float4*>(dsm);           // [RL][1 + C][n4]
+  float4* red = reinterpret_cast<float4*>(dsm);           // [RL][1 + C][S4]
   const int b = blockIdx.x;
   const int row0 = goff ? goff[b] : b * Lmax;
   const int L = goff ? goff[b + 1] - row0 : Lmax;
   const int n4 = Ha / 4;
-  const int c4 = threadIdx.x % n4, rl = threadIdx.x / n4;
+  float* des = reinterpret_cast<float*>(red + (size_t)RL * (1 + C) * S4);       // [L][C]: read once, not once per thread and row
+  for (int i = threadIdx.x; i < L * C; i += blockDim.x) des[i] = de[(size_t)row0 * C + i];
+  __syncthreads();
+  const int s0 = blockIdx.y * S4;                          // first float4 column of this slab
+  const int sw = min(S4, n4 - s0);
+  const int cl = threadIdx.x % S4, rl = threadIdx.x / S4;
+  const int c4 = s0 + cl;
+  const bool act = rl < RL && cl < sw;
   float4 wc[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) wc[c] = (c < C && rl < RL) ? reinterpret_cast<const float4*>(w2 + (size_t)c * Ha)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < 8; ++c) wc[c] = (c < C && act) ? reinterpret_cast<const float4*>(w2 + (size_t)c * Ha)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 dw[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) dw[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (rl < RL) {
+  if (act) {
 #pragma unroll 4
     for (int l = rl; l < L; l += RL) {
       const size_t m = (size_t)row0 + l;
@@ -490,7 +502,7 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
 #pragma unroll
       for (int c = 0; c < 8; ++c)
         if (c < C) {
-          const float e = de[m * C + c];
+          const float e = des[l * C + c];
           dt.x += e * wc[c].x; dt.y += e * wc[c].y; dt.z += e * wc[c].z; dt.w += e * wc[c].w;
           dw[c].x += e * tv.x; dw[c].y += e * tv.y; dw[c].z += e * tv.z; dw[c].w += e * tv.w;
         }
@@ -499,21 +511,23 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
       reinterpret_cast<float4*>(dpre + m * Ha)[c4] = dp;
       acc.x += dp.x; acc.y += dp.y; acc.z += dp.z; acc.w += dp.w;
     }
-    red[(rl * (1 + C) + 0) * n4 + c4] = acc;
+  }
+  if (rl < RL) {
+    red[(rl * (1 + C) + 0) * S4 + cl] = acc;
 #pragma unroll
     for (int c = 0; c < 8; ++c)
-      if (c < C) red[(rl * (1 + C) + 1 + c) * n4 + c4] = dw[c];
+      if (c < C) red[(rl * (1 + C) + 1 + c) * S4 + cl] = dw[c];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < (1 + C) * n4; i += blockDim.x) {
-    const int which = i / n4, cc = i % n4;
+  for (int i = threadIdx.x; i < (1 + C) * sw; i += blockDim.x) {
+    const int which = i / sw, cc = i % sw;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = 0; k < RL; ++k) {
-      const float4 x = red[(k * (1 + C) + which) * n4 + cc];
+      const float4 x = red[(k * (1 + C) + which) * S4 + cc];
       v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
     }
-    if (which == 0) reinterpret_cast<float4*>(du + (size_t)b * Ha)[cc] = v;
-    else if (dw2_part) reinterpret_cast<float4*>(dw2_part + ((size_t)b * C + (which - 1)) * Ha)[cc] = v;
+    if (which == 0) reinterpret_cast<float4*>(du + (size_t)b * Ha)[s0 + cc] = v;
+    else if (dw2_part) reinterpret_cast<float4*>(dw2_part + ((size_t)b * C + (which - 1)) * Ha)[s0 + cc] = v;
   }
 }
 
@@ -521,11 +535,15 @@ int launch_att_dpre(const float* de, const float* w2, const float* t, const int3
                     int ha, int heads, float* dpre, float* du, float* dw2_part, hipStream_t s) {
   GH_REQUIRE(ha % 4 == 0 && ha / 4 <= 256, "att_dpre: attention hidden %d must be a multiple of 4 and <= 1024", ha);
   const int n4 = ha / 4;
-  const int RL = (256 / n4) > 0 ? (256 / n4) : 1;
-  const int threads = ((n4 * RL + 63) / 64) * 64;
-  const size_t lds = (size_t)RL * (1 + heads) * n4 * 16;
+  // column slabs of <= 32 float4 (512 B of a row per lane group: whole 128-byte lines), ~3 slabs at ha = 300; few pairs
+  // (evidence level) keep one slab per 64 columns
+  const int nsl = (n4 + 31) / 32;
+  const int S4 = (n4 + nsl - 1) / nsl;
+  const int RL = (256 / S4) > 0 ? (256 / S4) : 1;
+  const int threads = ((S4 * RL + 63) / 64) * 64;
+  const size_t lds = (size_t)RL * (1 + heads) * S4 * 16 + (size_t)l * heads * 4;
   prof_begin(s, PROF_ATT_DPRE);
-  hipLaunchKernelGGL(att_dpre_kernel, dim3(b), dim3(threads), lds, s, de, w2, t, goff, l, ha, heads, RL, dpre, du, dw2_part);
+  hipLaunchKernelGGL(att_dpre_kernel, dim3(b, nsl), dim3(threads), lds, s, de, w2, t, goff, l, ha, heads, RL, S4, dpre, du, dw2_part);
   const double rows = goff ? (double)m_real : (double)b * l;
   prof_end(PROF_ATT_DPRE, 4.0 * (2.0 * rows * ha + rows * heads + (double)b * ha), s);
   GH_LAUNCH_CHECK();
@@ -660,7 +678,7 @@ template <typename TS>
 __global__ void __launch_bounds__(256)
 evd_assemble_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ offsets, const TS* __restrict__ sources,
                         float* __restrict__ d_avg, float* __restrict__ d_table, int n_slots, int n_max, int Xa, int Ds) {
-  extern __shared__ int sids[];
+  extern __shared__ __attribute__((aligned(16))) int sids[];
   const int me = blockIdx.x;
   const int b = me / n_max, slot = me % n_max;
   const int lo = offsets[b], cnt = min(offsets[b + 1] - lo, n_max);
@@ -680,10 +698,25 @@ evd_assemble_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__
     if (sids[i] == mine) earlier = 1;
   __syncthreads();
   if (earlier) return;                                            // an earlier slot owns this source's row
+  // later slots with the same source as a bit mask (ballot per 64 slots), then summed in slot order
+  const int nw = (n_slots + 63) / 64;
+  unsigned long long* match = reinterpret_cast<unsigned long long*>(sids + ((n_slots + 1) & ~1));
+  for (int w0 = (threadIdx.x >> 6); w0 < nw; w0 += (blockDim.x >> 6)) {
+    const int j = w0 * 64 + (threadIdx.x & 63);
+    const unsigned long long m = __ballot(j < n_slots && j >= me && sids[j] == mine);
+    if ((threadIdx.x & 63) == 0) match[w0] = m;
+  }
+  __syncthreads();
   for (int i = threadIdx.x; i < Ds; i += blockDim.x) {
     float acc = 0.f;
-    for (int j = me; j < n_slots; ++j)
-      if (sids[j] == mine) acc += g[(size_t)j * (Xa + Ds) + Xa + i];
+    for (int w0 = me >> 6; w0 < nw; ++w0) {
+      unsigned long long m = match[w0];
+      while (m) {
+        const int j = (w0 << 6) + __builtin_ctzll(m);
+        m &= m - 1;
+        acc += g[(size_t)j * (Xa + Ds) + Xa + i];
+      }
+    }
     d_table[(size_t)mine * Ds + i] += acc;
   }
 }
@@ -918,13 +951,14 @@ extern "C" int gh_evd_assemble_bwd(const float* g, const int32_t* offsets, const
                                    int xa, int ds, float* d_avg, float* d_table, gh_stream_t stream) {
   GH_REQUIRE(b > 0 && n_max > 0 && xa > 0 && ds >= 0, "evd_assemble_bwd: bad sizes");
   const int n_slots = b * n_max;
-  GH_REQUIRE((size_t)n_slots * 4 <= 60 * 1024, "evd_assemble_bwd: %d slots do not fit the source-id table in LDS", n_slots);
+  GH_REQUIRE(n_slots <= 12000, "evd_assemble_bwd: %d claim x evidence slots (max 12000 per call)", n_slots);
   hipStream_t s = (hipStream_t)stream;
+  const size_t lds_bytes = (size_t)((n_slots + 1) & ~1) * 4 + (size_t)((n_slots + 63) / 64) * 8;
   if (sources_i64)
-    hipLaunchKernelGGL((evd_assemble_bwd_kernel<int64_t>), dim3(n_slots), dim3(256), (size_t)n_slots * 4, s, g, offsets,
+    hipLaunchKernelGGL((evd_assemble_bwd_kernel<int64_t>), dim3(n_slots), dim3(256), lds_bytes, s, g, offsets,
                        (const int64_t*)sources, d_avg, d_table, n_slots, n_max, xa, ds);
   else
-    hipLaunchKernelGGL((evd_assemble_bwd_kernel<int32_t>), dim3(n_slots), dim3(256), (size_t)n_slots * 4, s, g, offsets,
+    hipLaunchKernelGGL((evd_assemble_bwd_kernel<int32_t>), dim3(n_slots), dim3(256), lds_bytes, s, g, offsets,
                        (const int32_t*)sources, d_avg, d_table, n_slots, n_max, xa, ds);
   GH_LAUNCH_CHECK();
   return 0;
