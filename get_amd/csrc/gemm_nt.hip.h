@@ -90,17 +90,23 @@ gemm_nt_kernel(const Launch L_byval) {
   const float* A1 = nseg > 1 ? P.seg[1].A : A0; const float* B1 = nseg > 1 ? P.seg[1].B : B0;
   const int lda1 = nseg > 1 ? P.seg[1].lda : lda0, ldb1 = nseg > 1 ? P.seg[1].ldb : ldb0;
   const int K1 = nseg > 1 ? P.seg[1].K : 0;
-  int kbeg = 0, kend = K0;
-  if (split) {
-    kbeg = ks * L.kchunk;
-    kend = min(K0, kbeg + L.kchunk);
-    if (kbeg >= kend) return;
-  }
-  const int nt0 = (kend - kbeg + BK - 1) / BK;
+  // K tiles are numbered over the concatenation of the segments; a K split (few-row GEMMs) gives this workgroup the tile
+  // range [tbeg, tend) of that sequence -- chunks of L.kchunk / 16 tiles
+  constexpr int kbeg = 0;
+  const int kend = K0;
+  const int nt0 = (K0 + BK - 1) / BK;
   // row tiles entirely at or beyond seg0_rows have an all-zero segment-0 operand (the aggregation of padding nodes in
   // the node-compact layout): start at the first tile of segment 1
-  const int toff = (nseg > 1 && P.seg0_rows > 0 && m0 >= P.seg0_rows) ? nt0 : 0;
-  const int T = (L.dbg & 2) ? 1 : nt0 + (nseg > 1 ? (K1 + BK - 1) / BK : 0) - toff;
+  const int toff = (nseg > 1 && P.seg0_rows > 0 && m0 >= P.seg0_rows && !split) ? nt0 : 0;
+  const int T_all = nt0 + (nseg > 1 ? (K1 + BK - 1) / BK : 0) - toff;
+  int tbeg = 0, tend = (L.dbg & 2) ? 1 : T_all;
+  if (split) {
+    const int ct = L.kchunk / BK;
+    tbeg = ks * ct;
+    tend = min(T_all, tbeg + ct);
+    if (tbeg >= tend) return;
+  }
+  const int T = tend - tbeg;
 
   // ---- DMA slots of this wave: lane L of instruction i fills linear chunk 64 i + L = (row 16 i + L/4, slot L%4)
   const int drow = lane >> 2;
@@ -135,7 +141,7 @@ gemm_nt_kernel(const Launch L_byval) {
   // one K tile: 16 k of BM rows of A and BN rows of B.  Invalid rows and k-quads at or beyond the segment's K carry
   // the out-of-range marker, for which the buffer range check returns 0 -> zeros land in LDS.
   auto dma_tile = [&](int t, int st) __attribute__((always_inline)) {
-    const int tt = t + toff;
+    const int tt = t + toff + tbeg;
     const bool s1 = tt >= nt0;
     const float* Ab = s1 ? A1 : A0;
     const float* Bb = s1 ? B1 : B0;
@@ -222,7 +228,7 @@ gemm_nt_kernel(const Launch L_byval) {
   auto mma = [&](const f32x4* a, const f32x4* b, int ni0, auto CNT) __attribute__((always_inline)) { mma_n(a, b, ni0, CNT); };
   // stateless input dropout (wrapper.py:189-190) on the A fragments of segment 0: element (row, k) of [rows][drop_ld]
   auto drop_a = [&](int t, f32x4* a) __attribute__((always_inline)) {
-    const int tt = t + toff;
+    const int tt = t + toff + tbeg;
     if (tt < nt0) {
       const int k = kbeg + tt * BK + 4 * q;
 #pragma unroll

@@ -190,11 +190,12 @@ reduce_partials_wave_kernel(const ReduceArgs R) {
   }
 }
 
-// Second half of an NT GEMM that was split over K: sum the partial tiles, then apply the real epilogue
-// (bias / accumulate, or the attention tanh + head scores).  One wave per output row.
+// Second half of an NT GEMM that was split over K: sum the partial tiles, then apply the problem's real epilogue
+// (any of gemm.hip.h's row epilogues).  One wave per output row.
 struct FinishItem {
   const float* ws; long long stride; int ks; int M, N, epi, accumulate, ldc;
-  float* C; const float* bias; const float* u; const float* w2; float* e; int ldu, R, heads;
+  float* C; const float* bias; const float* bias2; float* out1; const float* in0; const float* in1;
+  const float* u; const float* w2; float* e; int ldu, R, heads;
   const int32_t* rowg;
 };
 struct FinishArgs { FinishItem it[GH_MAX_PROBLEMS]; int n; };
@@ -217,7 +218,10 @@ nt_finish_kernel(const FinishArgs F) {
       const float4 x = *reinterpret_cast<const float4*>(p + (size_t)k * it.stride);
       v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
     }
-    float* o = it.C + (size_t)row * it.ldc + col;
+    const size_t oo = (size_t)row * it.ldc + col;
+    float* o = it.C + oo;
+    if (it.bias) { const float4 b4 = *reinterpret_cast<const float4*>(it.bias + col); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+    if (it.bias2) { const float4 b4 = *reinterpret_cast<const float4*>(it.bias2 + col); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
     if (it.epi == EPI_ATT) {
       const float4 u4 = *reinterpret_cast<const float4*>(it.u + (size_t)(it.rowg ? it.rowg[row] : row / it.R) * it.ldu + col);
       const float4 t = make_float4(tanhf_(v.x + u4.x), tanhf_(v.y + u4.y), tanhf_(v.z + u4.z), tanhf_(v.w + u4.w));
@@ -228,11 +232,29 @@ nt_finish_kernel(const FinishArgs F) {
           const float4 w = *reinterpret_cast<const float4*>(it.w2 + (size_t)c * it.N + col);
           pe[c] += t.x * w.x + t.y * w.y + t.z * w.z + t.w * w.w;
         }
+    } else if (it.epi == EPI_SIGMOID_Z) {
+      *reinterpret_cast<float4*>(o) = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+    } else if (it.epi == EPI_SIGMOID_R) {
+      const float4 x = *reinterpret_cast<const float4*>(it.in0 + oo);
+      const float4 r4 = make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+      *reinterpret_cast<float4*>(o) = r4;
+      *reinterpret_cast<float4*>(it.out1 + oo) = make_float4(r4.x * x.x, r4.y * x.y, r4.z * x.z, r4.w * x.w);
+    } else if (it.epi == EPI_TANH_H) {
+      const float4 z = *reinterpret_cast<const float4*>(it.in0 + oo);
+      const float4 x = *reinterpret_cast<const float4*>(it.in1 + oo);
+      const float4 h = make_float4(tanhf_(v.x), tanhf_(v.y), tanhf_(v.z), tanhf_(v.w));
+      *reinterpret_cast<float4*>(o) = h;
+      *reinterpret_cast<float4*>(it.out1 + oo) = make_float4(h.x * z.x + x.x * (1.f - z.x), h.y * z.y + x.y * (1.f - z.y),
+                                                             h.z * z.z + x.z * (1.f - z.z), h.w * z.w + x.w * (1.f - z.w));
+    } else if (it.epi == EPI_BWD_DRX) {
+      const float4 x = *reinterpret_cast<const float4*>(it.in0 + oo);
+      const float4 r4 = *reinterpret_cast<const float4*>(it.in1 + oo);
+      float4 d = *reinterpret_cast<const float4*>(it.out1 + oo);
+      *reinterpret_cast<float4*>(o) = make_float4(v.x * x.x * r4.x * (1.f - r4.x), v.y * x.y * r4.y * (1.f - r4.y),
+                                                  v.z * x.z * r4.z * (1.f - r4.z), v.w * x.w * r4.w * (1.f - r4.w));
+      d.x += v.x * r4.x; d.y += v.y * r4.y; d.z += v.z * r4.z; d.w += v.w * r4.w;
+      *reinterpret_cast<float4*>(it.out1 + oo) = d;
     } else {
-      if (it.bias) {
-        const float4 b4 = *reinterpret_cast<const float4*>(it.bias + col);
-        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-      }
       if (it.accumulate) {
         const float4 c4v = *reinterpret_cast<const float4*>(o);
         v.x += c4v.x; v.y += c4v.y; v.z += c4v.z; v.w += c4v.w;
@@ -406,19 +428,21 @@ struct Batch {
   bool nt_split_plan() {
     const int blocks = L.m_tiles * L.nprob;
     if (g_ws == nullptr || blocks >= 96 || !fast_ok(L, false)) return false;
-    int kmax = 0;
+    int tmax = 0;          // K tiles over the concatenated segments (every problem of a launch is split alike)
     for (int i = 0; i < L.nprob; ++i) {
       const Problem& q = L.p[i];
-      if (q.nseg != 1 || (q.epi != EPI_STORE && q.epi != EPI_ATT) || q.drop_mode == 3 || q.bias2) return false;
-      if (q.seg[0].K > kmax) kmax = q.seg[0].K;
+      if (q.epi == EPI_ATOMIC || q.drop_mode != 0 || (q.epi == EPI_TANH_H && q.w2) || q.seg0_rows > 0) return false;
+      int t = 0;
+      for (int j = 0; j < q.nseg; ++j) t += (q.seg[j].K + 15) / 16;
+      if (i > 0 && t != tmax) return false;
+      tmax = t;
     }
-    int ks = kmax / 64;
+    int ks = tmax / 4;
     const int want = (256 + blocks - 1) / blocks;
     if (ks > want) ks = want;
     if (ks < 2) return false;
-    int chunk = (kmax + ks - 1) / ks;
-    chunk = ((chunk + 15) / 16) * 16;
-    ks = (kmax + chunk - 1) / chunk;
+    const int ct = (tmax + ks - 1) / ks;     // tiles per chunk
+    ks = (tmax + ct - 1) / ct;
     if (ks < 2) return false;
     size_t need = 0;
     for (int i = 0; i < L.nprob; ++i) need += (size_t)ks * L.p[i].M * L.p[i].N * sizeof(float);
@@ -430,14 +454,14 @@ struct Batch {
     for (int i = 0; i < L.nprob; ++i) {
       Problem& q = L.p[i];
       F.it[i] = FinishItem{w, (long long)q.M * q.N, ks, q.M, q.N, q.epi, q.accumulate, q.ldc,
-                           q.C, q.bias, q.u, q.w2, q.e, q.ldu, q.R, q.heads, q.rowg};
-      q.C = w; q.ldc = q.N; q.epi = EPI_STORE; q.accumulate = 0; q.bias = nullptr;
+                           q.C, q.bias, q.bias2, q.out1, q.in0, q.in1, q.u, q.w2, q.e, q.ldu, q.R, q.heads, q.rowg};
+      q.C = w; q.ldc = q.N; q.epi = EPI_STORE; q.accumulate = 0; q.bias = nullptr; q.bias2 = nullptr;
       q.split_stride = (long long)q.M * q.N;
       w += (size_t)ks * q.M * q.N;
       if (q.M > max_m) max_m = q.M;
     }
     L.ksplit = ks;
-    L.kchunk = chunk;
+    L.kchunk = ct * 16;
     hipError_t e = launch_any();
     if (e != hipSuccess) err = e;
     hipLaunchKernelGGL(nt_finish_kernel, dim3((max_m + 3) / 4, F.n), dim3(256), 0, s, F);
@@ -651,7 +675,7 @@ extern "C" int gh_concat_att_fwd(const float* left, const float* right, const fl
     if (!one_block) {
       FinishArgs F;
       F.n = 1;
-      F.it[0] = FinishItem{t, 0, 1, M, ha, EPI_ATT, 0, ha, t, nullptr, u, w2, e, ha, l, heads, rowg};
+      F.it[0] = FinishItem{t, 0, 1, M, ha, EPI_ATT, 0, ha, t, nullptr, nullptr, nullptr, nullptr, nullptr, u, w2, e, ha, l, heads, rowg};
       hipLaunchKernelGGL(nt_finish_kernel, dim3((M + 3) / 4, 1), dim3(256), 0, s, F);
       GH_LAUNCH_CHECK();
     }

@@ -524,7 +524,8 @@ def test_compact_cell_with_dropout_vs_oracle():
         assert maxerr(q.grad.cpu(), go) <= 1e-3 * float(go.abs().max()) + 1e-5, name
     # real rows only (the second cell of GGNN_with_GSL): same numbers on the prefix
     out_r = ops.ggnn_cell(padj, xc.detach(), None, mod._params(), p_drop, seed, plan=plan, rows=plan.m_real)
-    assert torch.equal(out_r, out.detach()[:plan.m_real])
+    # (not bit-equal: few-row launches split K by the number of row tiles, so the summation order depends on the row count)
+    assert maxerr(out_r.detach().cpu(), out.detach()[:plan.m_real].cpu()) <= 2e-6
 
 
 def test_compact_scorer_gsl_and_attention_equal_padded():
