@@ -45,9 +45,10 @@ void prof_end(int tag, double work, hipStream_t s);
 // internal launchers implemented in graph_ops.hip / misc_ops.hip, used by the fused entry points
 // goff != NULL: node-compact layout (include/get_hip.h) -- graph g owns rows [goff[g], goff[g+1]); m_real = goff[n]
 int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const int32_t* goff,
-                int m_real, const float* x, float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s);
+                int m_real, const float* x, float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s,
+                int bf16 = 0);      // bf16: x and y hold bf16
 int launch_gate_bwd_pre(const float* g, const float* z, const float* hh, const float* xp, float* dhp, float* dzp,
-                        float* dxp, size_t count, hipStream_t s);
+                        float* dxp, size_t count, hipStream_t s, int bf16 = 0);   // bf16: everything but g holds bf16
 int launch_colsum3(const float* a, const float* b, const float* c, float* oa, float* ob, float* oc, int m, int h,
                    hipStream_t s, float* oa2 = nullptr, float* ob2 = nullptr, float* oc2 = nullptr);
 int launch_colsum(const float* a, float* oa, int m, int h, hipStream_t s);
@@ -56,7 +57,7 @@ int launch_colsum(const float* a, float* oa, int m, int h, hipStream_t s);
 struct Workspace { float* p; size_t bytes; float* cs; size_t cs_bytes; };
 Workspace workspace_for(hipStream_t s);
 int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m, int d, hipStream_t s,
-                       float drop_p = 0.f, unsigned drop_seed = 0);
+                       float drop_p = 0.f, unsigned drop_seed = 0, int bf16 = 0);   // bf16: table and dst hold bf16
 int launch_tiny_linear_fwd(const float* x, const float* w, const float* bias, float* y, int m, int k, int n, hipStream_t s);
 int launch_tiny_linear_bwd(const float* x, const float* w, const float* g, float* dx, float* dw, float* db, int m, int k, int n,
                            hipStream_t s);

@@ -64,6 +64,10 @@ struct Problem {
   //            input).  Fast kernel only.  (The weight-gradient GEMM gets its masked operand from gather_rows:
   //            hashing in the TN loader pushed that kernel over 168 VGPRs, i.e. from 3 to 2 waves per SIMD.)
   int drop_mode; int drop_ld; int drop_col0; unsigned drop_seed; unsigned drop_thresh; float drop_scale;
+  // bf16 storage pipeline (gemm_nt.hip.h MODE 2 / gemm_tn.hip.h bf16): elt = 1 -> A and B hold bf16 (lda/ldb/K in
+  // elements); io bits say which epilogue streams are bf16: 1 = C, 2 = out1, 4 = in0, 8 = in1; c32 (EPI_TANH_H): also
+  // write the fp32 value of out1 there (the cell output the fp32 consumers read)
+  int elt; int io; float* c32;
 };
 
 #define GH_MAX_PROBLEMS 8
@@ -406,10 +410,11 @@ inline Seg make_seg(const float* A, int lda, const float* B, int ldb, int K, int
   return s;
 }
 // NT: A [M][lda] (rows optionally gathered), B [N][ldb]; both rows hold the K contraction values contiguously
-inline Seg make_seg_nt(const float* A, int lda, const float* B, int ldb, int K, const int32_t* gatherA = nullptr) {
+inline Seg make_seg_nt(const float* A, int lda, const float* B, int ldb, int K, const int32_t* gatherA = nullptr, int elt = 0) {
   Seg s;
-  s.A = A; s.lda = lda; s.gatherA = gatherA; s.vecA = vec_ok(A, lda, K);
-  s.B = B; s.ldb = ldb; s.gatherB = nullptr; s.vecB = vec_ok(B, ldb, K);
+  const int q = elt ? 8 : 4;          // elements per 16 bytes
+  s.A = A; s.lda = lda; s.gatherA = gatherA; s.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && lda % q == 0 && K % q == 0;
+  s.B = B; s.ldb = ldb; s.gatherB = nullptr; s.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ldb % q == 0 && K % q == 0;
   s.K = K;
   return s;
 }

@@ -33,9 +33,13 @@ __device__ __forceinline__ unsigned nt_pack_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));     // v_cvt_pk_bf16_f32 (RNE)
 }
 
-// BF: opt-in operand mode (gh_set_gemm_mode(1)): fragments are rounded to bf16 in registers (v_cvt_pk_bf16_f32, RNE) and
-// one v_mfma_f32_16x16x16_bf16 spans the K tile (a lane's four k values = its float4); storage and epilogues stay fp32.
-template <int WM, int WN, int NI, int MI = 2, bool BF = false>
+// MODE 1: opt-in operand mode: fp32 storage, fragments rounded to bf16 in registers (v_cvt_pk_bf16_f32, RNE), one
+//         v_mfma_f32_16x16x16_bf16 per K tile (a lane's four k values = its float4); epilogues fp32.
+// MODE 2: bf16 STORAGE (BASELINE configs[4]): A and B are bf16 in HBM, the K tile is 32 deep -- the LDS image is the same
+//         64-byte rows ([row][32 k bf16]), one ds_read_b128 is a lane's 8 consecutive k, i.e. exactly the operand of
+//         v_mfma_f32_16x16x32_bf16 (one MFMA per 16x16 tile and K tile) -- fp32 accumulation and epilogue arithmetic,
+//         epilogue streams bf16 or fp32 per Problem::io.
+template <int WM, int WN, int NI, int MI = 2, int MODE = 0>
 __global__ void __launch_bounds__(WM * WN * 64, 3)
 gemm_nt_kernel(const Launch L_byval) {
   (void)L_byval;
@@ -43,7 +47,9 @@ gemm_nt_kernel(const Launch L_byval) {
   const GH_KARG Launch& L = *(const GH_KARG Launch*)__builtin_amdgcn_kernarg_segment_ptr();
   typedef __amdgpu_buffer_rsrc_t rsrc_t;
   constexpr int NW = WM * WN, NTHR = NW * 64;
-  constexpr int BM = 16 * MI * WM, BN = 16 * NI * WN, BK = 16;
+  constexpr bool BF = MODE == 1;
+  constexpr int ESZ = MODE == 2 ? 2 : 4, KQ = 16 / ESZ;          // element size, elements per 16-byte chunk
+  constexpr int BM = 16 * MI * WM, BN = 16 * NI * WN, BK = 4 * KQ;
   constexpr int NAI = BM / 16, NBI = BN / 16;                      // DMA instructions per K tile (1 KiB each)
   constexpr int SA = (NAI + NW - 1) / NW, SB = (NBI + NW - 1) / NW; // ... per wave
   constexpr int STAGE = (BM + BN) * 64;
@@ -121,16 +127,16 @@ gemm_nt_kernel(const Launch L_byval) {
     int s0 = gmc, s1 = gmc;
     if (P.seg[0].gatherA) s0 = P.seg[0].gatherA[gmc];              // embedding row id, read once per row
     if (nseg > 1 && P.seg[1].gatherA) s1 = P.seg[1].gatherA[gmc];
-    a_vo0[j] = ok ? (unsigned)s0 * (unsigned)lda0 * 4u + (unsigned)dkq * 16u : OOB;
-    a_vo1[j] = ok ? (unsigned)s1 * (unsigned)lda1 * 4u + (unsigned)dkq * 16u : OOB;
+    a_vo0[j] = ok ? (unsigned)s0 * (unsigned)lda0 * (unsigned)ESZ + (unsigned)dkq * 16u : OOB;
+    a_vo1[j] = ok ? (unsigned)s1 * (unsigned)lda1 * (unsigned)ESZ + (unsigned)dkq * 16u : OOB;
   }
 #pragma unroll
   for (int j = 0; j < SB; ++j) {
     const int ib = wave + NW * j;
     const int n = 16 * ib + drow;
     const bool ok = (NW * (j + 1) <= NBI || ib < NBI) && n < N;
-    b_vo0[j] = ok ? (unsigned)n * (unsigned)ldb0 * 4u + (unsigned)dkq * 16u : OOB;
-    b_vo1[j] = ok ? (unsigned)n * (unsigned)ldb1 * 4u + (unsigned)dkq * 16u : OOB;
+    b_vo0[j] = ok ? (unsigned)n * (unsigned)ldb0 * (unsigned)ESZ + (unsigned)dkq * 16u : OOB;
+    b_vo1[j] = ok ? (unsigned)n * (unsigned)ldb1 * (unsigned)ESZ + (unsigned)dkq * 16u : OOB;
   }
 
   const int drop_mode = P.drop_mode;
@@ -149,21 +155,21 @@ gemm_nt_kernel(const Launch L_byval) {
     const int klim = s1 ? K1 : kend;
     const rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0x7fffffff, 0x00020000);
     const rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, 0x7fffffff, 0x00020000);
-    const bool kok = 4 * dkq < klim - k0;
+    const bool kok = KQ * dkq < klim - k0;
     unsigned char* sb = smem + st * STAGE;
 #pragma unroll
     for (int j = 0; j < SA; ++j) {
       const int ia = wave + NW * j;
       if (NW * (j + 1) <= NAI || ia < NAI)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(sb + ia * 1024), 16,
-                                                 kok ? (s1 ? a_vo1[j] : a_vo0[j]) : OOB, k0 * 4, 0, 0);
+                                                 kok ? (s1 ? a_vo1[j] : a_vo0[j]) : OOB, k0 * ESZ, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < SB; ++j) {
       const int ib = wave + NW * j;
       if (NW * (j + 1) <= NBI || ib < NBI)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sb + BM * 64 + ib * 1024), 16,
-                                                 kok ? (s1 ? b_vo1[j] : b_vo0[j]) : OOB, k0 * 4, 0, 0);
+                                                 kok ? (s1 ? b_vo1[j] : b_vo0[j]) : OOB, k0 * ESZ, 0, 0);
     }
   };
 
@@ -191,6 +197,16 @@ gemm_nt_kernel(const Launch L_byval) {
   // swapped operands: acc[mi][ni][r] = C[row = wrow + mi*16 + l15][col = wcol + ni*16 + 4*q + r]
   auto mma_n = [&](const f32x4* a, const f32x4* b, int ni0, auto CNT) __attribute__((always_inline)) {
     constexpr int cnt = decltype(CNT)::value;
+    if constexpr (MODE == 2) {
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+      for (int i = 0; i < cnt; ++i)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[mi][ni0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[i]), __builtin_bit_cast(bf16x8, a[mi]),
+                                                                    acc[mi][ni0 + i], 0, 0, 0);
+      return;
+    }
     if constexpr (BF) {
       typedef short s16x4 __attribute__((ext_vector_type(4)));
       s16x4 ab[MI];
@@ -230,12 +246,24 @@ gemm_nt_kernel(const Launch L_byval) {
   auto drop_a = [&](int t, f32x4* a) __attribute__((always_inline)) {
     const int tt = t + toff + tbeg;
     if (tt < nt0) {
-      const int k = kbeg + tt * BK + 4 * q;
+      const int k = kbeg + tt * BK + KQ * q;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const unsigned idx = (unsigned)(m0 + wrow + mi * 16 + l15) * (unsigned)drop_ld + (unsigned)k;
-        const float4 v = drop4(make_float4(a[mi][0], a[mi][1], a[mi][2], a[mi][3]), drop_seed, idx, drop_thresh, drop_scale);
-        a[mi] = f32x4{v.x, v.y, v.z, v.w};
+        if constexpr (MODE == 2) {       // 8 bf16 per lane: the mask is exact in any precision (keep * 1/(1-p))
+          unsigned w[4] = {__builtin_bit_cast(unsigned, a[mi][0]), __builtin_bit_cast(unsigned, a[mi][1]),
+                           __builtin_bit_cast(unsigned, a[mi][2]), __builtin_bit_cast(unsigned, a[mi][3])};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float lo = __builtin_bit_cast(float, w[e] << 16), hi = __builtin_bit_cast(float, w[e] & 0xffff0000u);
+            lo = drop_hash(drop_seed, idx + 2 * e) >= drop_thresh ? lo * drop_scale : 0.f;
+            hi = drop_hash(drop_seed, idx + 2 * e + 1) >= drop_thresh ? hi * drop_scale : 0.f;
+            a[mi][e] = __builtin_bit_cast(float, nt_pack_bf16(lo, hi));
+          }
+        } else {
+          const float4 v = drop4(make_float4(a[mi][0], a[mi][1], a[mi][2], a[mi][3]), drop_seed, idx, drop_thresh, drop_scale);
+          a[mi] = f32x4{v.x, v.y, v.z, v.w};
+        }
       }
     }
   };
@@ -304,6 +332,28 @@ gemm_nt_kernel(const Launch L_byval) {
     if (c < N) { if (bias) bv = bias[c]; if (bias2) bv += bias2[c]; }
     bsum[c] = bv;
   }
+  // epilogue streams are fp32, or (MODE 2) bf16 per Problem::io
+  const int io = (MODE == 2) ? P.io : 0;
+  float* const c32 = (MODE == 2) ? P.c32 : nullptr;
+  auto ld4 = [&](const float* p, size_t o, bool bf) __attribute__((always_inline)) {
+    if constexpr (MODE == 2) {
+      if (bf) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p) + o);
+        return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                           __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+      }
+    }
+    return *reinterpret_cast<const float4*>(p + o);
+  };
+  auto st4 = [&](float* p, size_t o, const float4 v, bool bf) __attribute__((always_inline)) {
+    if constexpr (MODE == 2) {
+      if (bf) {
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p) + o) = make_uint2(nt_pack_bf16(v.x, v.y), nt_pack_bf16(v.z, v.w));
+        return;
+      }
+    }
+    *reinterpret_cast<float4*>(p + o) = v;
+  };
   auto epilogue_pass = [&](auto MIT) __attribute__((always_inline)) {
     constexpr int mi = decltype(MIT)::value;
     if (mi > 0) __syncthreads();                  // previous pass consumed (the loop's last barrier covers pass 0)
@@ -334,13 +384,13 @@ gemm_nt_kernel(const Launch L_byval) {
             int row, col; float* sp;
             if (where(j, row, col, sp)) {
               const size_t o = (size_t)row * ldc + col;
-              if (E == EPI_STORE) { if (accumulate) xa[j] = *reinterpret_cast<const float4*>(C + o); }
-              else if (E == EPI_SIGMOID_R) xa[j] = *reinterpret_cast<const float4*>(in0 + o);
-              else if (E == EPI_TANH_H) { xa[j] = *reinterpret_cast<const float4*>(in0 + o); xb[j] = *reinterpret_cast<const float4*>(in1 + o); }
+              if (E == EPI_STORE) { if (accumulate) xa[j] = ld4(C, o, io & 1); }
+              else if (E == EPI_SIGMOID_R) xa[j] = ld4(in0, o, io & 4);
+              else if (E == EPI_TANH_H) { xa[j] = ld4(in0, o, io & 4); xb[j] = ld4(in1, o, io & 8); }
               else if (E == EPI_BWD_DRX) {
-                xa[j] = *reinterpret_cast<const float4*>(in0 + o);
-                xb[j] = *reinterpret_cast<const float4*>(in1 + o);
-                xc[j] = *reinterpret_cast<const float4*>(out1 + o);
+                xa[j] = ld4(in0, o, io & 4);
+                xb[j] = ld4(in1, o, io & 8);
+                xc[j] = ld4(out1, o, io & 2);
               } else if (E == EPI_ATT)
                 xa[j] = *reinterpret_cast<const float4*>(P.u + (size_t)(P.rowg ? P.rowg[row] : row / P.R) * P.ldu + col);
             }
@@ -358,21 +408,22 @@ gemm_nt_kernel(const Launch L_byval) {
             if (drop_mode == 3)
               w = drop4(w, drop_seed, (unsigned)row * (unsigned)drop_ld + (unsigned)(P.drop_col0 + col), drop_thresh, drop_scale);
             if (accumulate) { w.x += xa[j].x; w.y += xa[j].y; w.z += xa[j].z; w.w += xa[j].w; }
-            *reinterpret_cast<float4*>(C + o) = w;
+            st4(C, o, w, io & 1);
           } else if (E == EPI_SIGMOID_Z) {
-            *reinterpret_cast<float4*>(C + o) = make_float4(sigmoidf_(w.x), sigmoidf_(w.y), sigmoidf_(w.z), sigmoidf_(w.w));
+            st4(C, o, make_float4(sigmoidf_(w.x), sigmoidf_(w.y), sigmoidf_(w.z), sigmoidf_(w.w)), io & 1);
           } else if (E == EPI_SIGMOID_R) {
             const float4 x = xa[j];
             const float4 r4 = make_float4(sigmoidf_(w.x), sigmoidf_(w.y), sigmoidf_(w.z), sigmoidf_(w.w));
-            *reinterpret_cast<float4*>(C + o) = r4;
-            *reinterpret_cast<float4*>(out1 + o) = make_float4(r4.x * x.x, r4.y * x.y, r4.z * x.z, r4.w * x.w);
+            st4(C, o, r4, io & 1);
+            st4(out1, o, make_float4(r4.x * x.x, r4.y * x.y, r4.z * x.z, r4.w * x.w), io & 2);
           } else if (E == EPI_TANH_H) {
             const float4 z = xa[j], x = xb[j];
             const float4 h = make_float4(tanhf_(w.x), tanhf_(w.y), tanhf_(w.z), tanhf_(w.w));
             float4 y = make_float4(h.x * z.x + x.x * (1.f - z.x), h.y * z.y + x.y * (1.f - z.y),
                                    h.z * z.z + x.z * (1.f - z.z), h.w * z.w + x.w * (1.f - z.w));
-            *reinterpret_cast<float4*>(C + o) = h;
-            *reinterpret_cast<float4*>(out1 + o) = y;
+            st4(C, o, h, io & 1);
+            st4(out1, o, y, io & 2);
+            if (c32) *reinterpret_cast<float4*>(c32 + o) = y;
             if (scorer) {    // the word scorer sees dropout(out) (its own input dropout, wrapper.py:189-190)
               if (drop_mode == 2)
                 y = drop4(y, drop_seed, (unsigned)row * (unsigned)drop_ld + (unsigned)col, drop_thresh, drop_scale);
@@ -381,11 +432,10 @@ gemm_nt_kernel(const Launch L_byval) {
           } else if (E == EPI_BWD_DRX) {
             const float4 x = xa[j], r4 = xb[j];
             float4 d = xc[j];
-            *reinterpret_cast<float4*>(C + o) =
-                make_float4(w.x * x.x * r4.x * (1.f - r4.x), w.y * x.y * r4.y * (1.f - r4.y),
-                            w.z * x.z * r4.z * (1.f - r4.z), w.w * x.w * r4.w * (1.f - r4.w));
+            st4(C, o, make_float4(w.x * x.x * r4.x * (1.f - r4.x), w.y * x.y * r4.y * (1.f - r4.y),
+                                  w.z * x.z * r4.z * (1.f - r4.z), w.w * x.w * r4.w * (1.f - r4.w)), io & 1);
             d.x += w.x * r4.x; d.y += w.y * r4.y; d.z += w.z * r4.z; d.w += w.w * r4.w;
-            *reinterpret_cast<float4*>(out1 + o) = d;
+            st4(out1, o, d, io & 2);
           } else if (E == EPI_ATT) {
             const float4 u4 = xa[j];
             const float4 t4 = make_float4(tanhf_(w.x + u4.x), tanhf_(w.y + u4.y), tanhf_(w.z + u4.z), tanhf_(w.w + u4.w));

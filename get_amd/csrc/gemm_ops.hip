@@ -11,6 +11,7 @@ namespace gh {
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+static bool s_lds_bad(const Problem& p) { return p.seg[0].lda % 8 || p.seg[0].ldb % 8; }
 // fast-path preconditions of gemm_nt.hip.h (NT: both operands contraction-contiguous) and gemm_tn.hip.h (TN); both LDS-DMA
 static bool fast_ok(const Launch& L, bool tn) {
   for (int i = 0; i < L.nprob; ++i) {
@@ -21,6 +22,7 @@ static bool fast_ok(const Launch& L, bool tn) {
       if (!s.vecA || !s.vecB || s.gatherB || s.K < 4) return false;
       if (tn && s.gatherA) return false;
     }
+    if (p.elt && tn && (p.M % 8 || p.N % 8 || s_lds_bad(p))) return false;
     if (!tn) {  // operands are addressed through buffer descriptors: 31-bit byte offsets
       for (int j = 0; j < p.nseg; ++j) {
         if (4.0 * (double)p.seg[j].ldb * (double)p.N >= 2147483648.0) return false;
@@ -85,7 +87,16 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
     for (int i = 0; i < L.nprob; ++i)
       if (L.p[i].epi == EPI_TANH_H && L.p[i].w2) return hipErrorInvalidValue;   // so does the fused scorer projection
   bool launched = false;
-  if (fast && !tn) {
+  bool any_elt = false, all_elt = true;
+  for (int i = 0; i < L.nprob; ++i) { any_elt = any_elt || L.p[i].elt; all_elt = all_elt && L.p[i].elt; }
+  if (any_elt) {      // bf16 storage pipeline: only on the 64x320 fast kernels, never mixed with fp32 problems
+    if (!fast || !all_elt) return hipErrorInvalidValue;
+    if constexpr (WM == 2 && WN == 2 && NI == 10) {
+      if (tn) hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 2, 10>), dim3(grid), dim3(256), 0, s, L);
+      else hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 10, 2, 2>), dim3(grid), dim3(256), 0, s, L);
+      launched = true;
+    } else return hipErrorInvalidValue;
+  } else if (fast && !tn) {
     // gh_set_gemm_mode(1): bf16 operand rounding in the activation-sized (64x320 tile) launches only
     if (g_gemm_mode == 1 && WM == 2 && WN == 2 && NI == 10) {
       if constexpr (WM == 2 && WN == 2 && NI == 10)
@@ -313,21 +324,24 @@ struct Batch {
     for (int n0 = 0; n0 < p.N; n0 += bn) {
       Problem q = p;
       q.N = (p.N - n0 < bn) ? p.N - n0 : bn;
+      auto adv = [](const float* ptr, size_t elems, bool bf) { return (const float*)((const char*)ptr + elems * (bf ? 2 : 4)); };
       for (int i = 0; i < q.nseg; ++i) {
         if (tn) {
-          q.seg[i].B += n0;
-          q.seg[i].vecB = vec_ok(q.seg[i].B, q.seg[i].ldb, q.N);
+          q.seg[i].B = adv(q.seg[i].B, (size_t)n0, q.elt);
+          q.seg[i].vecB = q.elt ? (((reinterpret_cast<uintptr_t>(q.seg[i].B) & 15) == 0) && q.seg[i].ldb % 8 == 0 && q.N % 8 == 0)
+                                : vec_ok(q.seg[i].B, q.seg[i].ldb, q.N);
         } else {
-          q.seg[i].B += (size_t)n0 * q.seg[i].ldb;       // B is [N][ldb]: a column block of C is a row block of B
+          q.seg[i].B = adv(q.seg[i].B, (size_t)n0 * q.seg[i].ldb, q.elt);       // B is [N][ldb]: a column block of C is a row block of B
         }
       }
-      q.C += n0;
+      q.C = (float*)adv(q.C, (size_t)n0, q.io & 1);
       q.drop_col0 = p.drop_col0 + n0;
       if (q.bias) q.bias += n0;
       if (q.bias2) q.bias2 += n0;
-      if (q.out1) q.out1 += n0;
-      if (q.in0) q.in0 += n0;
-      if (q.in1) q.in1 += n0;
+      if (q.out1) q.out1 = (float*)adv(q.out1, (size_t)n0, q.io & 2);
+      if (q.in0) q.in0 = adv(q.in0, (size_t)n0, q.io & 4);
+      if (q.in1) q.in1 = adv(q.in1, (size_t)n0, q.io & 8);
+      if (q.c32) q.c32 += n0;
       if (L.nprob == GH_MAX_PROBLEMS) flush();
       L.p[L.nprob++] = q;
       const int mt = (q.M + bm - 1) / bm;
@@ -348,7 +362,7 @@ struct Batch {
       if (ks > ks_max) ks = ks_max;
       if (ks < 1) ks = 1;
       int chunk = (k_total + ks - 1) / ks;
-      chunk = ((chunk + 15) / 16) * 16;
+      chunk = ((chunk + 31) / 32) * 32;
       L.kchunk = chunk;
       L.ksplit = (k_total + chunk - 1) / chunk;
       // partial tiles -> workspace when it is big enough and every output is float4-shaped
@@ -473,13 +487,14 @@ struct Batch {
 };
 
 static Problem gemm_problem(int M, int N, int epi, float* C, int ldc, const float* A, int lda, const float* B, int ldb,
-                            int K, const int32_t* gatherA = nullptr) {
+                            int K, const int32_t* gatherA = nullptr, int elt = 0) {
   Problem p = make_problem(M, N, epi, C, ldc);
-  p.seg[0] = make_seg_nt(A, lda, B, ldb, K, gatherA);
+  p.elt = elt;
+  p.seg[0] = make_seg_nt(A, lda, B, ldb, K, gatherA, elt);
   return p;
 }
 static void add_seg(Problem& p, const float* A, int lda, const float* B, int ldb, int K) {
-  p.seg[p.nseg++] = make_seg_nt(A, lda, B, ldb, K);
+  p.seg[p.nseg++] = make_seg_nt(A, lda, B, ldb, K, nullptr, p.elt);
 }
 static void set_dropout(Problem& p, int mode, int ld, float drop_p, unsigned seed) {
   if (drop_p <= 0.f) return;
@@ -489,9 +504,14 @@ static void set_dropout(Problem& p, int mode, int ld, float drop_p, unsigned see
   p.drop_scale = 1.0f / (1.0f - drop_p);
 }
 static Problem tn_problem(int I, int J, float* C, int ldc, const float* A, int lda, const float* B, int ldb, int K,
-                          const int32_t* gatherB = nullptr) {
+                          const int32_t* gatherB = nullptr, int elt = 0) {
   Problem p = make_problem(I, J, EPI_ATOMIC, C, ldc);
   p.seg[0] = make_seg_tn(A, lda, I, B, ldb, J, K, nullptr, gatherB);
+  p.elt = elt;
+  if (elt) {
+    p.seg[0].vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && lda % 8 == 0 && I % 8 == 0;
+    p.seg[0].vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ldb % 8 == 0 && J % 8 == 0;
+  }
   return p;
 }
 

@@ -256,4 +256,191 @@ gemm_tn_kernel(const Launch L_byval) {
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 STORAGE variant (BASELINE configs[4]): A [m][I] and B [m][J] hold bf16.  The K tile is 32 rows; the LDS image is
+// again the k-major rows as the DMA delivers them (A: 32 x 128 B, B: 32 x 640 B -- the same byte counts as the fp32 tile).
+// v_mfma_f32_16x16x32_bf16 wants 8 consecutive k per lane, i.e. the transpose of a k-major image: ds_read_b64_tr_b16
+// delivers it.  Measured semantics (tools/tr_probe.hip): within a 16-lane group, lane p reads 8 bytes at ITS address and
+// output lane i receives element (i & 3) of lanes (i >> 2) + 4 j, j = 0..3.  With lane p pointing at
+// X[k0 + (p >> 2)][c0 + 4 (p & 3) ..+3] the group reads a 4(k) x 16(c) block and lane i gets X[k0..k0+3][c0 + i]: four
+// consecutive k of ITS column.  Two such reads (k0 = 8 g, 8 g + 4 for lane group g) make one MFMA operand.
+template <int WM, int WN, int NI>
+__global__ void __launch_bounds__(WM * WN * 64, 3)
+gemm_tn_bf16_kernel(const Launch L_byval) {
+  (void)L_byval;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const GH_KARG Launch& L = *(const GH_KARG Launch*)__builtin_amdgcn_kernarg_segment_ptr();
+  typedef __amdgpu_buffer_rsrc_t rsrc_t;
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  constexpr int MI = 2;
+  constexpr int NW = WM * WN;
+  constexpr int BM = 16 * MI * WM, BN = 16 * NI * WN, BK = 32;
+  constexpr int A_BYTES = BK * BM * 2, B_BYTES = BK * BN * 2;
+  constexpr int NAI = A_BYTES / 1024, NBI = B_BYTES / 1024;
+  constexpr int SA = (NAI + NW - 1) / NW, SB = (NBI + NW - 1) / NW;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0, "whole DMA instructions");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int n_inner = L.m_tiles * L.nprob;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int ks = xcd + 8 * (slot / n_inner);
+  const int inner = slot % n_inner;
+  if (ks >= L.ksplit) return;
+  const int prob = inner % L.nprob;
+  const int m_tile = inner / L.nprob;
+  const GH_KARG Problem& P = L.p[prob];
+  const int M = P.M, N = P.N;
+  const int m0 = m_tile * BM;
+  if (m0 >= M) return;
+  const int kbeg = ks * L.kchunk;
+  const int kend = min(P.seg[0].K, kbeg + L.kchunk);
+  if (kbeg >= kend) return;
+  const int T = (kend - kbeg + BK - 1) / BK;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int wrow = wm * 16 * MI, wcol = wn * 16 * NI;
+  const int l15 = lane & 15, q = lane >> 4;
+
+  const float* A = P.seg[0].A; const float* B = P.seg[0].B;          // bf16 data behind float-typed descriptor fields
+  const int lda = P.seg[0].lda, ldb = P.seg[0].ldb;
+  const rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, kend * lda * 2, 0x00020000);
+  const rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, kend * ldb * 2, 0x00020000);
+
+  // DMA: linear 16-byte chunk c of the A image = (k-row c / (BM/8), 8 columns starting at 8 (c % (BM/8)))
+  unsigned a_vo[SA], b_vo[SB];
+#pragma unroll
+  for (int j = 0; j < SA; ++j) {
+    const int ia = wave + NW * j;
+    const int c = ia * 64 + lane;
+    const int krow = c / (BM / 8), col = m0 + 8 * (c % (BM / 8));
+    a_vo[j] = ((NW * (j + 1) <= NAI || ia < NAI) && col < M) ? ((unsigned)krow * (unsigned)lda + (unsigned)col) * 2u : OOB;
+  }
+#pragma unroll
+  for (int j = 0; j < SB; ++j) {
+    const int ib = wave + NW * j;
+    const int c = ib * 64 + lane;
+    const int krow = c / (BN / 8), col = 8 * (c % (BN / 8));
+    b_vo[j] = ((NW * (j + 1) <= NBI || ib < NBI) && col < N) ? ((unsigned)krow * (unsigned)ldb + (unsigned)col) * 2u : OOB;
+  }
+  auto dma_tile = [&](int t, int st) __attribute__((always_inline)) {
+    const int k0 = kbeg + t * BK;
+    unsigned char* sb = smem + st * STAGE;
+#pragma unroll
+    for (int j = 0; j < SA; ++j) {
+      const int ia = wave + NW * j;
+      if (NW * (j + 1) <= NAI || ia < NAI)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(sb + ia * 1024), 16, a_vo[j],
+                                                 k0 * lda * 2, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < SB; ++j) {
+      const int ib = wave + NW * j;
+      if (NW * (j + 1) <= NBI || ib < NBI)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sb + A_BYTES + ib * 1024), 16,
+                                                 b_vo[j], k0 * ldb * 2, 0, 0);
+    }
+  };
+
+  // transpose-read addresses: lane (p = l15, g = q) points at k-row 8 g + (p >> 2) (+4 for the second read), 4 columns at 4 (p & 3)
+  const unsigned lds0 = (unsigned)(uintptr_t)smem;
+  const unsigned a_ad = lds0 + (unsigned)(8 * q + (l15 >> 2)) * (BM * 2) + (unsigned)(wrow + 4 * (l15 & 3)) * 2u;
+  const unsigned b_ad = lds0 + (unsigned)A_BYTES + (unsigned)(8 * q + (l15 >> 2)) * (BN * 2) + (unsigned)(wcol + 4 * (l15 & 3)) * 2u;
+  auto tr_read = [&](unsigned addr) __attribute__((always_inline)) {
+    uint2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float csum[MI] = {0.f, 0.f};
+  float* const colsum = P.colsum;
+
+  dma_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const int st = t & 1;
+    if (t + 1 < T) dma_tile(t + 1, st ^ 1);
+    const unsigned so = (unsigned)st * STAGE;
+    uint2 alo[MI], ahi[MI], blo[NI], bhi[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) { alo[mi] = tr_read(a_ad + so + mi * 32); ahi[mi] = tr_read(a_ad + so + mi * 32 + 4 * (BM * 2)); }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) { blo[ni] = tr_read(b_ad + so + ni * 32); bhi[ni] = tr_read(b_ad + so + ni * 32 + 4 * (BN * 2)); }
+    // the reads are invisible to the compiler's counters: wait here, and make every destination an in/out operand of the
+    // wait so that no copy of a not-yet-landed register can be scheduled above it (cdna_hip_programming.md, inline-asm form ii)
+    static_assert(MI == 2 && NI == 10, "operand lists below");
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(alo[0]), "+v"(alo[1]), "+v"(ahi[0]), "+v"(ahi[1]), "+v"(blo[0]), "+v"(blo[1]), "+v"(blo[2]), "+v"(blo[3]),
+                   "+v"(blo[4]), "+v"(blo[5]), "+v"(blo[6]), "+v"(blo[7]), "+v"(blo[8]), "+v"(blo[9])
+                 :: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(bhi[0]), "+v"(bhi[1]), "+v"(bhi[2]), "+v"(bhi[3]), "+v"(bhi[4]), "+v"(bhi[5]), "+v"(bhi[6]), "+v"(bhi[7]),
+                   "+v"(bhi[8]), "+v"(bhi[9])
+                 :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 af[MI], bfr[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) af[mi] = make_uint4(alo[mi].x, alo[mi].y, ahi[mi].x, ahi[mi].y);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bfr[ni] = make_uint4(blo[ni].x, blo[ni].y, bhi[ni].x, bhi[ni].y);
+    // swapped operands: acc[mi][ni][r] = C[i = wrow + 16 mi + l15][j = wcol + 16 ni + 4 q + r]
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[ni]), __builtin_bit_cast(bf16x8, af[mi]),
+                                                              acc[mi][ni], 0, 0, 0);
+    if (colsum) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const unsigned w[4] = {af[mi].x, af[mi].y, af[mi].z, af[mi].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[mi] += __builtin_bit_cast(float, w[e] << 16) + __builtin_bit_cast(float, w[e] & 0xffff0000u);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  if (colsum && wn == 0) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      float v = csum[mi];
+      v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+      const int c = m0 + wrow + 16 * mi + l15;
+      if (q == 0 && c < M) colsum[(size_t)ks * (size_t)P.colsum_stride + c] = v;
+    }
+  }
+  const int ldc = P.ldc;
+  float* const C = P.C + (size_t)ks * (size_t)P.split_stride;
+  const bool atomic = P.epi == EPI_ATOMIC;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int row = m0 + wrow + 16 * mi + l15;
+    if (row >= M) continue;
+    float* crow = C + (size_t)row * ldc;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int col = wcol + 16 * ni + 4 * q;
+      if (col < N) {
+        const float4 v = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+        if (atomic) { atomicAdd(crow + col, v.x); atomicAdd(crow + col + 1, v.y); atomicAdd(crow + col + 2, v.z); atomicAdd(crow + col + 3, v.w); }
+        else *reinterpret_cast<float4*>(crow + col) = v;
+      }
+    }
+  }
+#endif
+}
+
 }  // namespace gh

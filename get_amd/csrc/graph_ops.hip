@@ -132,7 +132,20 @@ adj_unpack_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ d
 // feature rows), the refined neighbour bit-rows and dinv sit beside it, and every output float4
 // walks its row's set bits with ctz -- each feature row leaves HBM exactly once per slab.
 // ------------------------------------------------------------------------------------------------
-template <int V>   // V = 4: float4 columns, V = 1: scalar columns
+__device__ __forceinline__ float4 bf4_to_f4(uint2 u) {
+  return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                     __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned pack_bf2(float a, float b) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ uint2 f4_to_bf4(float4 v) { return make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); }
+
+// BF (with V = 4): x and y hold bf16 (the bf16 storage pipeline); the slab is widened to fp32 when it is staged
+template <int V, bool BF = false>   // V = 4: float4 columns, V = 1: scalar columns
 __global__ void __launch_bounds__(256)
 spmm_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
             const uint64_t* __restrict__ keep, const int32_t* __restrict__ goff, const float* __restrict__ x,
@@ -172,7 +185,8 @@ spmm_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, c
       for (int k = 0; k < SL; ++k) {
         const int it = min(base + k * 256, total - 1);
         const int i = it / ncol, c = it % ncol;
-        if (V == 4) tmp[k] = reinterpret_cast<const float4*>(xg + (size_t)i * H)[c0 + c];
+        if (BF) tmp[k] = bf4_to_f4(reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x) + ((size_t)row0 + i) * H)[c0 + c]);
+        else if (V == 4) tmp[k] = reinterpret_cast<const float4*>(xg + (size_t)i * H)[c0 + c];
         else tmp[k].x = xg[(size_t)i * H + c0 + c];
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -218,7 +232,11 @@ spmm_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, c
         }
       }
     }
-    if (V == 4) {
+    if (BF) {
+      uint2* o = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(y) + ((size_t)row0 + i) * H) + c0 + c;
+      if (accumulate) { const float4 p = bf4_to_f4(*o); acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+      *o = f4_to_bf4(acc);
+    } else if (V == 4) {
       float4* o = reinterpret_cast<float4*>(yg + (size_t)i * H) + c0 + c;
       if (accumulate) { const float4 p = *o; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
       *o = acc;
@@ -356,11 +374,12 @@ spmm_wave_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
 }
 
 int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const int32_t* goff,
-                int m_real, const float* x, float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s) {
+                int m_real, const float* x, float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s, int bf16) {
   GH_REQUIRE(r <= MAX_R, "spmm: padded graph size %d > %d", r, MAX_R);
   GH_REQUIRE(vals || dinv, "spmm: need dinv or vals");
   const int W = words_for(r);
   const bool v4 = (h % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+  GH_REQUIRE(!bf16 || v4, "spmm: the bf16 variant needs h %% 4 == 0 and 16-byte aligned rows");
   const int V = v4 ? 4 : 1;
   const int hv = h / V;
   // slab: <= 32 float4 (or 128 scalars) per row, as even as possible
@@ -375,7 +394,7 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   dim3 grid(n, nslab);
   // algorithmic bytes: x in + y out (+ y in when accumulating) + bit rows + dinv (or the touched dense values)
   const double rows = goff ? (double)m_real : (double)n * r;
-  const double alg_bytes = (2.0 + (accumulate ? 1.0 : 0.0)) * rows * h * 4.0 +
+  const double alg_bytes = (2.0 + (accumulate ? 1.0 : 0.0)) * rows * h * (bf16 ? 2.0 : 4.0) +
                            (double)n * ((double)r * W * 8.0 + (vals ? (double)r * r * 4.0 : (double)r * 4.0));
   // 0 (default): LDS-staged slab kernel -- every feature row leaves HBM exactly once (FETCH ~= algorithmic bytes);
   // 1 / 2: LDS-free gather variants (thread-per-float4 / wave-per-row).  Measured equal or slower on MI355X: with
@@ -383,7 +402,11 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("GH_SPMM_VARIANT"); variant = e ? atoi(e) : 0; }
   prof_begin(s, PROF_SPMM);
-  if (v4 && variant == 2 && h / 4 <= 128 && !goff) {
+  if (bf16) {
+    static bool attrb = false;
+    if (!attrb && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)spmm_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrb = true; }
+    hipLaunchKernelGGL((spmm_kernel<4, true>), grid, dim3(256), lds, s, bits, dinv, vals, keep, goff, x, y, r, h, slab, transpose, accumulate);
+  } else if (v4 && variant == 2 && h / 4 <= 128 && !goff) {
     constexpr int RPW = 5;
     const int wpg = (r + RPW - 1) / RPW;
     hipLaunchKernelGGL(spmm_wave_kernel<RPW>, dim3((n * wpg + 3) / 4), dim3(256), 0, s, bits, dinv, vals, keep, x, y, r, h,
@@ -609,7 +632,7 @@ extern "C" int gh_spmm(const uint64_t* bits, const float* dinv, const float* val
                        const int32_t* goff, int m_real, const float* x, float* y, int n, int r, int h, int transpose,
                        int accumulate, gh_stream_t stream) {
   if (n <= 0) return 0;
-  return launch_spmm(bits, dinv, vals, keep, goff, m_real, x, y, n, r, h, transpose, accumulate, (hipStream_t)stream);
+  return launch_spmm(bits, dinv, vals, keep, goff, m_real, x, y, n, r, h, transpose, accumulate, (hipStream_t)stream, 0);
 }
 
 extern "C" int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const int32_t* goff,

@@ -118,9 +118,50 @@ gate_bwd_pre_scalar_kernel(const float* __restrict__ g, const float* __restrict_
   }
 }
 
+__device__ __forceinline__ float4 mbf4_to_f4(uint2 u) {
+  return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                     __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned mpack_bf2(float a, float b) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// bf16 storage pipeline: g fp32, every other stream bf16 (4 elements = 8 bytes per item)
+__global__ void __launch_bounds__(256)
+gate_bwd_pre_bf16_kernel(const float4* __restrict__ g, const uint2* __restrict__ z, const uint2* __restrict__ hh,
+                         const uint2* __restrict__ xp, uint2* __restrict__ dhp, uint2* __restrict__ dzp,
+                         uint2* __restrict__ dxp, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 G = g[i], Z = mbf4_to_f4(z[i]), Hh = mbf4_to_f4(hh[i]), X = mbf4_to_f4(xp[i]);
+    float4 a, b, c;
+#define GH_ONE(f)                                      \
+    a.f = G.f * Z.f * (1.f - Hh.f * Hh.f);             \
+    b.f = G.f * (Hh.f - X.f) * Z.f * (1.f - Z.f);      \
+    c.f = G.f * (1.f - Z.f);
+    GH_ONE(x) GH_ONE(y) GH_ONE(z) GH_ONE(w)
+#undef GH_ONE
+    dhp[i] = make_uint2(mpack_bf2(a.x, a.y), mpack_bf2(a.z, a.w));
+    dzp[i] = make_uint2(mpack_bf2(b.x, b.y), mpack_bf2(b.z, b.w));
+    dxp[i] = make_uint2(mpack_bf2(c.x, c.y), mpack_bf2(c.z, c.w));
+  }
+}
+
 int launch_gate_bwd_pre(const float* g, const float* z, const float* hh, const float* xp, float* dhp, float* dzp,
-                        float* dxp, size_t count, hipStream_t s) {
+                        float* dxp, size_t count, hipStream_t s, int bf16) {
   if (count == 0) return 0;
+  if (bf16) {
+    GH_REQUIRE(count % 4 == 0, "gate_bwd_pre: the bf16 variant needs a multiple of 4 elements");
+    const size_t n4 = count / 4;
+    const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    prof_begin(s, PROF_GATE_BWD_PRE);
+    hipLaunchKernelGGL(gate_bwd_pre_bf16_kernel, dim3(grid), dim3(256), 0, s, (const float4*)g, (const uint2*)z, (const uint2*)hh,
+                       (const uint2*)xp, (uint2*)dhp, (uint2*)dzp, (uint2*)dxp, n4);
+    prof_end(PROF_GATE_BWD_PRE, (4.0 + 6.0 * 2.0) * (double)count, s);
+    GH_LAUNCH_CHECK();
+    return 0;
+  }
   const uintptr_t al = (uintptr_t)g | (uintptr_t)z | (uintptr_t)hh | (uintptr_t)xp | (uintptr_t)dhp | (uintptr_t)dzp | (uintptr_t)dxp;
   if (count % 4 == 0 && (al & 15) == 0) {
     const size_t n4 = count / 4;
@@ -272,9 +313,32 @@ gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ 
     }
   }
 }
+// bf16 storage pipeline: table rows and dst hold bf16
+__global__ void __launch_bounds__(256)
+gather_rows_bf16_kernel(const unsigned short* __restrict__ table, const int32_t* __restrict__ ids, unsigned short* __restrict__ dst,
+                        int m, int d, unsigned drop_thresh, float drop_scale, unsigned drop_seed) {
+  const int per = d / 4;
+  for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < (size_t)m * per; it += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(it / per), c = 4 * (int)(it % per);
+    float4 v = mbf4_to_f4(*reinterpret_cast<const uint2*>(table + (size_t)(ids ? ids[r] : r) * d + c));
+    if (drop_thresh) v = drop4(v, drop_seed, (unsigned)r * (unsigned)d + (unsigned)c, drop_thresh, drop_scale);
+    *reinterpret_cast<uint2*>(dst + (size_t)r * d + c) = make_uint2(mpack_bf2(v.x, v.y), mpack_bf2(v.z, v.w));
+  }
+}
+
 int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m, int d, hipStream_t s, float drop_p,
-                       unsigned drop_seed) {
+                       unsigned drop_seed, int bf16) {
   if (m <= 0) return 0;
+  if (bf16) {
+    GH_REQUIRE(d % 4 == 0, "gather_rows: the bf16 variant needs d %% 4 == 0");
+    const size_t n = (size_t)m * (d / 4);
+    const double th = (double)drop_p * 4294967296.0;
+    const unsigned thresh = drop_p > 0.f ? (th >= 4294967295.0 ? 4294967295u : (unsigned)th) : 0u;
+    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s,
+                       (const unsigned short*)table, ids, (unsigned short*)dst, m, d, thresh, 1.0f / (1.0f - drop_p), drop_seed);
+    GH_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t n = (size_t)m * ((d + 3) / 4);
   const double th = (double)drop_p * 4294967296.0;
   const unsigned thresh = drop_p > 0.f ? (th >= 4294967295.0 ? 4294967295u : (unsigned)th) : 0u;
