@@ -32,6 +32,8 @@ SIGNATURES = {
     "gh_transpose_batch": [_I, _P, _P, _P, _P, _P],
     "gh_ggnn_cell_fwd": [_P] * 5 + [_I, _I] + [_P] * 2 + [_I] * 4 + [_P] * 13 + [_P] * 7 + [_F, _U, _P, _P, _F, _U, _P],
     "gh_ggnn_cell_bwd": [_P] * 5 + [_I] + [_P] * 2 + [_I] * 4 + [_P] * 7 + [_P] * 7 + [_P] * 5 + [_P] * 14 + [_F, _U, _P],
+    "gh_ggnn_cell_fwd_bf16": [_P] * 5 + [_I, _I] + [_P] * 2 + [_I] * 4 + [_P] * 13 + [_P] * 8 + [_F, _U, _P, _P, _F, _U, _P],
+    "gh_ggnn_cell_bwd_bf16": [_P] * 5 + [_I] + [_P] * 2 + [_I] * 4 + [_P] * 7 + [_P] * 7 + [_P] * 5 + [_P] * 14 + [_F, _U, _P],
     "gh_scorer_gsl": [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _F, _U, _P],
     "gh_gsl_topk": [_P, _I, _I, _I, _P, _P],
     "gh_adj_unpack": [_P, _P, _P, _P, _I, _I, _P, _P],
@@ -76,9 +78,20 @@ def profile_collect() -> dict:
     return {name: {"ms": buf[3 * i], "work": buf[3 * i + 1], "launches": int(buf[3 * i + 2])}
             for i, name in enumerate(PROFILE_ROWS)}
 
+_GEMM_MODE = "fp32"
+
+
 def set_gemm_mode(mode: str):
-    """"fp32" (default, exact fp32 MFMA) or "bf16" (bf16 operands / fp32 accumulate in the big NT/NN GEMMs)."""
+    """"fp32" (default, exact fp32 MFMA everywhere) or "bf16" (BASELINE configs[4]): the evidence cells run the bf16
+    STORAGE pipeline (bf16 activations/weights in HBM, v_mfma_f32_16x16x32_bf16, fp32 accumulate) where their shape
+    allows it, every other activation-sized GEMM rounds its operands to bf16 in registers."""
+    global _GEMM_MODE
     call("gh_set_gemm_mode", {"fp32": 0, "bf16": 1}[mode])
+    _GEMM_MODE = mode
+
+
+def gemm_mode() -> str:
+    return _GEMM_MODE
 
 
 def gemm_path_counters(reset: bool = False) -> dict:

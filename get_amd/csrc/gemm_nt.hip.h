@@ -251,15 +251,16 @@ gemm_nt_kernel(const Launch L_byval) {
       for (int mi = 0; mi < MI; ++mi) {
         const unsigned idx = (unsigned)(m0 + wrow + mi * 16 + l15) * (unsigned)drop_ld + (unsigned)k;
         if constexpr (MODE == 2) {       // 8 bf16 per lane: the mask is exact in any precision (keep * 1/(1-p))
-          unsigned w[4] = {__builtin_bit_cast(unsigned, a[mi][0]), __builtin_bit_cast(unsigned, a[mi][1]),
-                           __builtin_bit_cast(unsigned, a[mi][2]), __builtin_bit_cast(unsigned, a[mi][3])};
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 w = __builtin_bit_cast(u32x4, a[mi]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float lo = __builtin_bit_cast(float, w[e] << 16), hi = __builtin_bit_cast(float, w[e] & 0xffff0000u);
             lo = drop_hash(drop_seed, idx + 2 * e) >= drop_thresh ? lo * drop_scale : 0.f;
             hi = drop_hash(drop_seed, idx + 2 * e + 1) >= drop_thresh ? hi * drop_scale : 0.f;
-            a[mi][e] = __builtin_bit_cast(float, nt_pack_bf16(lo, hi));
+            w[e] = nt_pack_bf16(lo, hi);
           }
+          a[mi] = __builtin_bit_cast(f32x4, w);
         } else {
           const float4 v = drop4(make_float4(a[mi][0], a[mi][1], a[mi][2], a[mi][3]), drop_seed, idx, drop_thresh, drop_scale);
           a[mi] = f32x4{v.x, v.y, v.z, v.w};

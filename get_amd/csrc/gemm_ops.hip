@@ -374,7 +374,7 @@ struct Batch {
         need += (size_t)L.ksplit * L.p[i].M * L.p[i].N * sizeof(float);
         if (cs_out[i]) { need += (size_t)L.ksplit * L.p[i].M * sizeof(float); any_cs = true; }
       }
-      if (any_cs && !(ws_ok && need <= g_ws_bytes && fast_ok(L, true) && g_gemm_mode == 0)) any_cs = false;   // caller runs the column-sum kernels
+      if (any_cs && !(ws_ok && need <= g_ws_bytes && fast_ok(L, true) && (g_gemm_mode == 0 || L.p[0].elt))) any_cs = false;   // caller runs the column-sum kernels
       if (ws_ok && need <= g_ws_bytes) {
         ReduceArgs R;
         R.n = L.nprob;
@@ -419,7 +419,7 @@ struct Batch {
   }
 
   hipError_t launch_any() {
-    if (big && !tn && L.ksplit == 1) {
+    if (big && !tn && L.ksplit == 1 && !L.p[0].elt) {
       // Occupancy-aware tile choice.  The chip holds 768 workgroups of either configuration (3 per CU); a grid of 64-row
       // tiles that ends in a thinly filled last round (e.g. 976 workgroups = 1.27 rounds, the node-compact single-problem
       // launches) runs faster on 32-row tiles (1937 workgroups = 2.52 rounds): measured 83 vs 78 TF at K = 300.
@@ -519,7 +519,9 @@ static Problem tn_problem(int I, int J, float* C, int ldc, const float* A, int l
 
 using namespace gh;
 
-extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+// bf: bf16 storage pipeline -- x (or the table behind ids), the weights and xp/a/z/rr/rx/hh/out hold bf16 (pointers typed
+// float* all the same); out32 then receives the fp32 copy of the cell output.  Biases, score_w and score_x stay fp32.
+static int cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
                                 const int32_t* goff, int m_real, int m_rows,
                                 const float* x, const int32_t* ids, int n, int r, int din, int h,
                                 const float* w_p, const float* w_z0, const float* w_z1, const float* w_r0,
@@ -532,6 +534,7 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
                                 gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   GH_REQUIRE(n > 0 && r > 0 && din > 0 && h > 0, "ggnn_cell_fwd: bad sizes n=%d r=%d din=%d h=%d", n, r, din, h);
+  GH_REQUIRE(!bf || (din % 8 == 0 && h % 8 == 0 && out32), "ggnn_cell_fwd_bf16: needs din %% 8 == 0, h %% 8 == 0 (din=%d h=%d) and out32", din, h);
   if (!goff) { m_real = n * r; m_rows = n * r; }
   GH_REQUIRE(m_real >= 0 && m_real <= m_rows && m_rows <= n * r, "ggnn_cell_fwd: node-compact rows %d/%d do not fit n*r=%d", m_real, m_rows, n * r);
   const int M = m_rows;
@@ -541,22 +544,25 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
   GH_REQUIRE(score_drop_p >= 0.f && score_drop_p < 1.f, "ggnn_cell_fwd: scorer dropout p=%f not in [0,1)", score_drop_p);
   {  // xp = dropout(x) Wp^T   (wrapper.py:189-191); embedding rows gathered by the loader, the dropout mask applied to the fragments
     Batch b(false, M, s);
-    Problem p = gemm_problem(M, h, EPI_STORE, xp, h, x, din, w_p, din, din, ids);
+    Problem p = gemm_problem(M, h, EPI_STORE, xp, h, x, din, w_p, din, din, ids, bf);
+    p.io = bf ? 1 : 0;
     set_dropout(p, 1, din, drop_p, drop_seed);
     b.add(p);
     b.flush();
     GH_REQUIRE(b.err != hipErrorInvalidValue || drop_p == 0.f, "ggnn_cell_fwd: fused dropout needs float4-shaped rows (din=%d, h=%d)", din, h);
     GH_CHECK_HIP(b.err);
   }
-  if (int e = launch_spmm(bits, dinv, vals, keep, goff, m_real, xp, a, n, r, h, 0, 0, s)) return e;   // a = A_hat xp (:192)
+  if (int e = launch_spmm(bits, dinv, vals, keep, goff, m_real, xp, a, n, r, h, 0, 0, s, bf)) return e;   // a = A_hat xp (:192)
   if (m_rows > m_real)   // padding rows of the node-compact layout have no neighbours
-    GH_CHECK_HIP(hipMemsetAsync(a + (size_t)m_real * h, 0, sizeof(float) * (size_t)(m_rows - m_real) * h, s));
+    GH_CHECK_HIP(hipMemsetAsync((char*)a + (size_t)m_real * h * (bf ? 2 : 4), 0, (size_t)(bf ? 2 : 4) * (size_t)(m_rows - m_real) * h, s));
   {  // z, r gates (:194-200): [a | xp] . [W?0 | W?1]^T as two K segments
     Batch b(false, M, s);
-    Problem pz = gemm_problem(M, h, EPI_SIGMOID_Z, z, h, a, h, w_z0, h, h);
+    Problem pz = gemm_problem(M, h, EPI_SIGMOID_Z, z, h, a, h, w_z0, h, h, nullptr, bf);
+    pz.io = bf ? 1 : 0;
     add_seg(pz, xp, h, w_z1, h, h);
     pz.bias = b_z0; pz.bias2 = b_z1;
-    Problem pr = gemm_problem(M, h, EPI_SIGMOID_R, rr, h, a, h, w_r0, h, h);
+    Problem pr = gemm_problem(M, h, EPI_SIGMOID_R, rr, h, a, h, w_r0, h, h, nullptr, bf);
+    pr.io = bf ? 7 : 0;
     add_seg(pr, xp, h, w_r1, h, h);
     pr.bias = b_r0; pr.bias2 = b_r1; pr.out1 = rx; pr.in0 = xp;
     if (m_rows > m_real) pz.seg0_rows = pr.seg0_rows = (m_real > 0 ? m_real : 1);
@@ -566,7 +572,8 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
   }
   {  // h gate and the convex update (:202-206); optionally the GSL word scorer's projection of the result (:167)
     Batch b(false, M, s);
-    Problem ph = gemm_problem(M, h, EPI_TANH_H, hh, h, a, h, w_h0, h, h);
+    Problem ph = gemm_problem(M, h, EPI_TANH_H, hh, h, a, h, w_h0, h, h, nullptr, bf);
+    ph.io = bf ? 15 : 0; ph.c32 = bf ? out32 : nullptr;
     add_seg(ph, rx, h, w_h1, h, h);
     ph.bias = b_h0; ph.bias2 = b_h1; ph.out1 = out; ph.in0 = z; ph.in1 = xp;
     if (m_rows > m_real) ph.seg0_rows = (m_real > 0 ? m_real : 1);
@@ -582,7 +589,43 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
   return 0;
 }
 
-extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                                const int32_t* goff, int m_real, int m_rows,
+                                const float* x, const int32_t* ids, int n, int r, int din, int h,
+                                const float* w_p, const float* w_z0, const float* w_z1, const float* w_r0,
+                                const float* w_r1, const float* w_h0, const float* w_h1,
+                                const float* b_z0, const float* b_z1, const float* b_r0, const float* b_r1,
+                                const float* b_h0, const float* b_h1,
+                                float* xp, float* a, float* z, float* rr, float* rx, float* hh, float* out,
+                                float drop_p, uint32_t drop_seed,
+                                const float* score_w, float* score_x, float score_drop_p, uint32_t score_drop_seed,
+                                gh_stream_t stream) {
+  return cell_fwd_impl(0, nullptr, bits, dinv, vals, keep, goff, m_real, m_rows, x, ids, n, r, din, h, w_p, w_z0, w_z1, w_r0, w_r1,
+                       w_h0, w_h1, b_z0, b_z1, b_r0, b_r1, b_h0, b_h1, xp, a, z, rr, rx, hh, out, drop_p, drop_seed, score_w,
+                       score_x, score_drop_p, score_drop_seed, stream);
+}
+
+extern "C" int gh_ggnn_cell_fwd_bf16(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                                     const int32_t* goff, int m_real, int m_rows,
+                                     const void* x, const int32_t* ids, int n, int r, int din, int h,
+                                     const void* w_p, const void* w_z0, const void* w_z1, const void* w_r0,
+                                     const void* w_r1, const void* w_h0, const void* w_h1,
+                                     const float* b_z0, const float* b_z1, const float* b_r0, const float* b_r1,
+                                     const float* b_h0, const float* b_h1,
+                                     void* xp, void* a, void* z, void* rr, void* rx, void* hh, void* out, float* out32,
+                                     float drop_p, uint32_t drop_seed,
+                                     const float* score_w, float* score_x, float score_drop_p, uint32_t score_drop_seed,
+                                     gh_stream_t stream) {
+  typedef const float* cf;
+  typedef float* mf;
+  return cell_fwd_impl(1, out32, bits, dinv, vals, keep, goff, m_real, m_rows, (cf)x, ids, n, r, din, h, (cf)w_p, (cf)w_z0, (cf)w_z1,
+                       (cf)w_r0, (cf)w_r1, (cf)w_h0, (cf)w_h1, b_z0, b_z1, b_r0, b_r1, b_h0, b_h1, (mf)xp, (mf)a, (mf)z, (mf)rr,
+                       (mf)rx, (mf)hh, (mf)out, drop_p, drop_seed, score_w, score_x, score_drop_p, score_drop_seed, stream);
+}
+
+// bf: bf16 storage pipeline -- x / table, wt_*, the saved xp..hh and the scratch dhp..da hold bf16; g, dx and every weight /
+// bias gradient stay fp32.
+static int cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
                                 const int32_t* goff, int m_real,
                                 const float* x, const int32_t* ids, int n, int r, int din, int h,
                                 const float* wt_p, const float* wt_z0, const float* wt_z1, const float* wt_r0,
@@ -596,37 +639,40 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
                                 gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   GH_REQUIRE(n > 0 && r > 0 && din > 0 && h > 0, "ggnn_cell_bwd: bad sizes");
+  GH_REQUIRE(!bf || (din % 8 == 0 && h % 8 == 0 && din <= h), "ggnn_cell_bwd_bf16: needs din %% 8 == 0, h %% 8 == 0, din <= h (din=%d h=%d)", din, h);
   if (!goff) m_real = n * r;
   GH_REQUIRE(m_real >= 0 && m_real <= n * r, "ggnn_cell_bwd: node-compact rows %d do not fit n*r=%d", m_real, n * r);
   const int M = m_real;      // padding rows receive no gradient and contribute none
   if (M == 0) return 0;
   // out = h z + xp (1-z):  dhp = g z (1-h^2), dzp = g (h-xp) z (1-z), dxp = g (1-z)
-  if (int e = launch_gate_bwd_pre(g, z, hh, xp, dhp, dzp, dxp, (size_t)M * h, s)) return e;
+  if (int e = launch_gate_bwd_pre(g, z, hh, xp, dhp, dzp, dxp, (size_t)M * h, s, bf)) return e;
   {  // hp = a Wh0^T + (r xp) Wh1^T:  da = dhp Wh0 ; d(r xp) = dhp Wh1 -> drp, dxp += .
     Batch b(false, M, s);
-    Problem p0 = gemm_problem(M, h, EPI_STORE, da, h, dhp, h, wt_h0, h, h);
-    Problem p1 = gemm_problem(M, h, EPI_BWD_DRX, drp, h, dhp, h, wt_h1, h, h);
+    Problem p0 = gemm_problem(M, h, EPI_STORE, da, h, dhp, h, wt_h0, h, h, nullptr, bf);
+    Problem p1 = gemm_problem(M, h, EPI_BWD_DRX, drp, h, dhp, h, wt_h1, h, h, nullptr, bf);
     p1.out1 = dxp; p1.in0 = xp; p1.in1 = rr;
+    p0.io = bf ? 1 : 0; p1.io = bf ? 15 : 0;
     b.add(p0); b.add(p1);
     b.flush();
     GH_CHECK_HIP(b.err);
   }
   {  // da += dzp Wz0 + drp Wr0 ; dxp += dzp Wz1 + drp Wr1
     Batch b(false, M, s);
-    Problem p0 = gemm_problem(M, h, EPI_STORE, da, h, dzp, h, wt_z0, h, h);
+    Problem p0 = gemm_problem(M, h, EPI_STORE, da, h, dzp, h, wt_z0, h, h, nullptr, bf);
     add_seg(p0, drp, h, wt_r0, h, h);
     p0.accumulate = 1;
-    Problem p1 = gemm_problem(M, h, EPI_STORE, dxp, h, dzp, h, wt_z1, h, h);
+    Problem p1 = gemm_problem(M, h, EPI_STORE, dxp, h, dzp, h, wt_z1, h, h, nullptr, bf);
     add_seg(p1, drp, h, wt_r1, h, h);
     p1.accumulate = 1;
+    p0.io = p1.io = bf ? 1 : 0;
     b.add(p0); b.add(p1);
     b.flush();
     GH_CHECK_HIP(b.err);
   }
-  if (int e = launch_spmm(bits, dinv, vals, keep, goff, m_real, da, dxp, n, r, h, 1, 1, s)) return e;   // dxp += A_hat^T da
+  if (int e = launch_spmm(bits, dinv, vals, keep, goff, m_real, da, dxp, n, r, h, 1, 1, s, bf)) return e;   // dxp += A_hat^T da
   if (dx) {  // dx = (dxp Wp) . mask/(1-p)
     Batch b(false, M, s);
-    Problem p = gemm_problem(M, din, EPI_STORE, dx, din, dxp, h, wt_p, h, h);
+    Problem p = gemm_problem(M, din, EPI_STORE, dx, din, dxp, h, wt_p, h, h, nullptr, bf);      // dx itself is fp32
     set_dropout(p, 3, din, drop_p, drop_seed);
     b.add(p);
     b.flush();
@@ -636,18 +682,18 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
      // sums of dzp / drp / dhp: they ride along with the first GEMM that streams each of them (no separate
      // column-sum pass over 3 x M x h values) whenever the launch takes the workspace path.
     Batch b(true, M, s);
-    const bool cs = (h % 4 == 0) && (h <= 320);
-    b.add(tn_problem(h, h, dw_z0, h, dzp, h, a, h, M));  if (cs) b.want_colsum(db_z, db_z1);
-    b.add(tn_problem(h, h, dw_z1, h, dzp, h, xp, h, M));
-    b.add(tn_problem(h, h, dw_r0, h, drp, h, a, h, M));  if (cs) b.want_colsum(db_r, db_r1);
-    b.add(tn_problem(h, h, dw_r1, h, drp, h, xp, h, M));
-    b.add(tn_problem(h, h, dw_h0, h, dhp, h, a, h, M));  if (cs) b.want_colsum(db_h, db_h1);
-    b.add(tn_problem(h, h, dw_h1, h, dhp, h, rx, h, M));
-    if ((ids || drop_p > 0.f) && din <= h) {
+    const bool cs = bf ? true : ((h % 4 == 0) && (h <= 320));
+    b.add(tn_problem(h, h, dw_z0, h, dzp, h, a, h, M, nullptr, bf));  if (cs) b.want_colsum(db_z, db_z1);
+    b.add(tn_problem(h, h, dw_z1, h, dzp, h, xp, h, M, nullptr, bf));
+    b.add(tn_problem(h, h, dw_r0, h, drp, h, a, h, M, nullptr, bf));  if (cs) b.want_colsum(db_r, db_r1);
+    b.add(tn_problem(h, h, dw_r1, h, drp, h, xp, h, M, nullptr, bf));
+    b.add(tn_problem(h, h, dw_h0, h, dhp, h, a, h, M, nullptr, bf));  if (cs) b.want_colsum(db_h, db_h1);
+    b.add(tn_problem(h, h, dw_h1, h, dhp, h, rx, h, M, nullptr, bf));
+    if ((ids || drop_p > 0.f || bf) && din <= h) {
       // operand rows materialised once into the (now free) `da` scratch -- embedding gather and/or the forward's
       // dropout mask applied in that one streaming pass -- so the split-K GEMM loader stays a plain copy
-      if (int e = launch_gather_rows(x, ids, da, M, din, s, drop_p, drop_seed)) return e;
-      b.add(tn_problem(h, din, dw_p, din, dxp, h, da, din, M));
+      if (int e = launch_gather_rows(x, ids, da, M, din, s, drop_p, drop_seed, bf)) return e;
+      b.add(tn_problem(h, din, dw_p, din, dxp, h, da, din, M, nullptr, bf));
     } else {
       GH_REQUIRE(drop_p == 0.f, "ggnn_cell_bwd: fused dropout needs din (%d) <= h (%d)", din, h);
       b.add(tn_problem(h, din, dw_p, din, dxp, h, x, din, M, ids));
@@ -656,7 +702,45 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
     GH_CHECK_HIP(b.err);
     if (b.colsum_fused) return 0;
   }
+  GH_REQUIRE(!bf, "ggnn_cell_bwd_bf16: the bias gradients need the split-K workspace (gh_set_workspace)");
   return launch_colsum3(dzp, drp, dhp, db_z, db_r, db_h, M, h, s, db_z1, db_r1, db_h1);
+}
+
+extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                                const int32_t* goff, int m_real,
+                                const float* x, const int32_t* ids, int n, int r, int din, int h,
+                                const float* wt_p, const float* wt_z0, const float* wt_z1, const float* wt_r0,
+                                const float* wt_r1, const float* wt_h0, const float* wt_h1,
+                                const float* xp, const float* a, const float* z, const float* rr, const float* rx,
+                                const float* hh, const float* g,
+                                float* dhp, float* dzp, float* drp, float* dxp, float* da,
+                                float* dx, float* dw_p, float* dw_z0, float* dw_z1, float* dw_r0, float* dw_r1,
+                                float* dw_h0, float* dw_h1, float* db_z, float* db_r, float* db_h,
+                                float* db_z1, float* db_r1, float* db_h1, float drop_p, uint32_t drop_seed,
+                                gh_stream_t stream) {
+  return cell_bwd_impl(0, bits, dinv, vals, keep, goff, m_real, x, ids, n, r, din, h, wt_p, wt_z0, wt_z1, wt_r0, wt_r1, wt_h0, wt_h1,
+                       xp, a, z, rr, rx, hh, g, dhp, dzp, drp, dxp, da, dx, dw_p, dw_z0, dw_z1, dw_r0, dw_r1, dw_h0, dw_h1,
+                       db_z, db_r, db_h, db_z1, db_r1, db_h1, drop_p, drop_seed, stream);
+}
+
+extern "C" int gh_ggnn_cell_bwd_bf16(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                                     const int32_t* goff, int m_real,
+                                     const void* x, const int32_t* ids, int n, int r, int din, int h,
+                                     const void* wt_p, const void* wt_z0, const void* wt_z1, const void* wt_r0,
+                                     const void* wt_r1, const void* wt_h0, const void* wt_h1,
+                                     const void* xp, const void* a, const void* z, const void* rr, const void* rx,
+                                     const void* hh, const float* g,
+                                     void* dhp, void* dzp, void* drp, void* dxp, void* da,
+                                     float* dx, float* dw_p, float* dw_z0, float* dw_z1, float* dw_r0, float* dw_r1,
+                                     float* dw_h0, float* dw_h1, float* db_z, float* db_r, float* db_h,
+                                     float* db_z1, float* db_r1, float* db_h1, float drop_p, uint32_t drop_seed,
+                                     gh_stream_t stream) {
+  typedef const float* cf;
+  typedef float* mf;
+  return cell_bwd_impl(1, bits, dinv, vals, keep, goff, m_real, (cf)x, ids, n, r, din, h, (cf)wt_p, (cf)wt_z0, (cf)wt_z1, (cf)wt_r0,
+                       (cf)wt_r1, (cf)wt_h0, (cf)wt_h1, (cf)xp, (cf)a, (cf)z, (cf)rr, (cf)rx, (cf)hh, g, (mf)dhp, (mf)dzp, (mf)drp,
+                       (mf)dxp, (mf)da, dx, dw_p, dw_z0, dw_z1, dw_r0, dw_r1, dw_h0, dw_h1, db_z, db_r, db_h, db_z1, db_r1,
+                       db_h1, drop_p, drop_seed, stream);
 }
 
 extern "C" int gh_concat_att_fwd(const float* left, const float* right, const float* mask, const int32_t* goff,

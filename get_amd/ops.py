@@ -22,7 +22,8 @@ def bump_weight_epoch():
     global _WEIGHT_EPOCH
     _WEIGHT_EPOCH += 1
     _WT_CACHE.clear()
-    _DERIVED_CACHE.clear()
+    for k in [k for k, v in _DERIVED_CACHE.items() if v[0][-1] != -1]:
+        del _DERIVED_CACHE[k]
 
 
 def _direct(p) -> bool:
@@ -63,12 +64,13 @@ def transposed(w: torch.Tensor) -> torch.Tensor:
 _DERIVED_CACHE: dict = {}
 
 
-def derived(tag: str, tensors, fn):
+def derived(tag: str, tensors, fn, frozen: bool = False):
     """Small per-parameter-set cache for values derived from weights (bias sums, packed scalar gates): recomputed only
     when one of the source tensors was replaced, modified in place (``_version``) or the weight epoch moved on (the
     fused optimiser updates parameters through raw pointers).  Saves a dozen tiny elementwise launches per step."""
     key = (tag,) + tuple(id(t) for t in tensors)
-    sig = tuple((t.data_ptr(), t._version) for t in tensors) + (_WEIGHT_EPOCH,)
+    # frozen: the sources are never touched by the optimiser (requires_grad False), so the weight epoch does not matter
+    sig = tuple((t.data_ptr(), t._version) for t in tensors) + ((-1,) if frozen else (_WEIGHT_EPOCH,))
     hit = _DERIVED_CACHE.get(key)
     if hit is not None and hit[0] == sig and all(r() is t for r, t in zip(hit[1], tensors)):
         return hit[2]
@@ -275,6 +277,46 @@ class _GGNNCell(torch.autograd.Function):
         ws = [_f32(w.detach()) for w in (w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1)]
         wts = [transposed(w) for w in (w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1)]
         bs = [_f32(t.detach()) for t in (b_z0, b_z1, b_r0, b_r1, b_h0, b_h1)]      # the epilogues add b?0 + b?1
+        # bf16 STORAGE pipeline (BASELINE configs[4], _lib.set_gemm_mode("bf16")): activations and weights of the cell live
+        # in HBM as bf16, the GEMMs run v_mfma_f32_16x16x32_bf16 with fp32 accumulation; the fp32 cell output is kept for the
+        # consumers outside the cell.  Only for shapes the bf16 kernels take (16-byte rows, activation-sized launches).
+        bf = bf16_cell_ok(din, h, m, mb)
+        ctx.bf = bf
+        if bf:
+            wkeys = (w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1)
+            ws_b = derived("cell_w_bf16", wkeys, lambda: tuple(t.to(torch.bfloat16) for t in ws))
+            wts_b = derived("cell_wt_bf16", wkeys, lambda: tuple(t.to(torch.bfloat16) for t in wts))
+            if ids is not None:
+                xb = derived("table_bf16", (x,), lambda: x.detach().to(torch.bfloat16), frozen=not x.requires_grad)
+            else:
+                xb = getattr(x, "_gh_bf16", None)
+                if xb is None or xb.shape != x.shape:
+                    xb = x.detach().to(torch.bfloat16)
+            bufb = torch.empty((7, m, h), device=dev, dtype=torch.bfloat16)
+            xp, a, z, rr, rx, hh, outb = bufb.unbind(0)
+            out = torch.empty((m, h), device=dev, dtype=torch.float32)
+            sx = None
+            sc = (None, None, 0.0, 0)
+            if score is not None:
+                sw, sp, sseed = score
+                sx = torch.empty((m,), device=dev, dtype=torch.float32)
+                sc = (ptr(_f32(sw.detach().reshape(-1))), ptr(sx), float(sp), int(sseed))
+            call("gh_ggnn_cell_fwd_bf16", *adj._args(), *_plan_args(plan), m, ptr(xb), ptr(ids), n, r, din, h,
+                 *[ptr(t) for t in ws_b], *[ptr(t) for t in bs],
+                 ptr(xp), ptr(a), ptr(z), ptr(rr), ptr(rx), ptr(hh), ptr(outb), ptr(out), float(drop_p), int(drop_seed), *sc,
+                 stream())
+            ctx.adj, ctx.ids, ctx.dims, ctx.plan, ctx.rows = adj, ids, (n, r, din, h), plan, (m, mb)
+            ctx.drop = (float(drop_p), int(drop_seed))
+            ctx.params = (w_p, w_z0, b_z0, w_z1, b_z1, w_r0, b_r0, w_r1, b_r1, w_h0, b_h0, w_h1, b_h1)
+            ctx.save_for_backward(xb, bufb, *wts_b)
+            ctx.x_needs_grad = ctx.needs_input_grad[0]
+            ctx.x_shape = tuple(x.shape)
+            res = out.view(n, r, h) if plan is None else out
+            res._gh_bf16 = outb.view(n, r, h) if plan is None else outb        # bf16 twin for a following bf16 cell
+            if score is not None:
+                ctx.mark_non_differentiable(sx)
+                return res, sx
+            return res
         buf = torch.empty((7, m, h), device=dev, dtype=torch.float32)
         xp, a, z, rr, rx, hh, out = buf.unbind(0)
         sx = None
@@ -307,13 +349,16 @@ class _GGNNCell(torch.autograd.Function):
         dev = g.device
         g = _f32(g).reshape(m_fwd, h)
         _lib.ensure_workspace(dev)
-        scratch = torch.empty((5, max(m, 1), h), device=dev, dtype=torch.float32)
+        bf = getattr(ctx, "bf", False)
+        scratch = torch.empty((5, max(m, 1), h), device=dev, dtype=torch.bfloat16 if bf else torch.float32)
         dhp, dzp, drp, dxp, da = scratch.unbind(0)
         ids = ctx.ids
         want_dx = ctx.x_needs_grad
         dx = None
         if want_dx:
             x_rows = m if ids is not None else x.shape[0] if plan is not None else m
+            if bf and ids is None and plan is None:
+                x_rows = m
             dx = torch.empty((x_rows, din), device=dev, dtype=torch.float32)
             if x_rows > m:
                 dx[m:].zero_()               # padding rows (and unused tail rows of x) get no gradient
@@ -329,18 +374,18 @@ class _GGNNCell(torch.autograd.Function):
             dbs = torch.zeros((3, h), device=dev, dtype=torch.float32)
             gw = [dw_p] + [dws[i] for i in range(6)]
             gb = [dbs[0], dbs[1], dbs[2], None, None, None]
-        call("gh_ggnn_cell_bwd", *ctx.adj._args(), *_plan_args(plan), ptr(x), ptr(ids), n, r, din, h,
+        call("gh_ggnn_cell_bwd_bf16" if bf else "gh_ggnn_cell_bwd", *ctx.adj._args(), *_plan_args(plan), ptr(x), ptr(ids), n, r, din, h,
              ptr(w_p), ptr(w_z0), ptr(w_z1), ptr(w_r0), ptr(w_r1), ptr(w_h0), ptr(w_h1),
              ptr(xp), ptr(a), ptr(z), ptr(rr), ptr(rx), ptr(hh), ptr(g),
              ptr(dhp), ptr(dzp), ptr(drp), ptr(dxp), ptr(da),
              ptr(dx), *[ptr(t) for t in gw], *[ptr(t) for t in gb], ctx.drop[0], ctx.drop[1], stream())
         if want_dx:
             if ids is not None:      # trainable embedding table: scatter the row gradients
-                demb = torch.zeros_like(x)
+                demb = torch.zeros(x.shape, device=dev, dtype=torch.float32)
                 demb.index_add_(0, ids[:m].long(), dx)
                 dx = demb
             else:
-                dx = dx.view(x.shape)
+                dx = dx.view(ctx.x_shape if bf else x.shape)
         if direct:
             return (dx, None, None) + (None,) * 18
         dz0, dz1, dr0, dr1, dh0, dh1 = dws.unbind(0)
@@ -359,6 +404,11 @@ def ggnn_cell(adj: PackedAdj, x, ids, params, drop_p: float = 0.0, drop_seed: in
     if plan is not None and not rows:
         rows = plan.m_real
     return _GGNNCell.apply(x, ids, adj, *params, drop_p, drop_seed, plan, rows, score)
+
+
+def bf16_cell_ok(din: int, h: int, m_fwd: int, m_bwd: int) -> bool:
+    """True when a cell call takes the bf16 storage pipeline: mode "bf16", 16-byte bf16 rows, activation-sized launches."""
+    return (_lib.gemm_mode() == "bf16" and din % 8 == 0 and h % 8 == 0 and din <= h and min(m_fwd, m_bwd) >= 8192)
 
 
 def scorer_fusable(h: int) -> bool:

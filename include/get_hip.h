@@ -146,6 +146,37 @@ int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const float* vals,
                      float* dw_h0, float* dw_h1, float* db_z, float* db_r, float* db_h,
                      float* db_z1, float* db_r1, float* db_h1, float drop_p, uint32_t drop_seed, gh_stream_t stream);
 
+/* ---- bf16 STORAGE variant of the cell (BASELINE configs[4]: "h=768 bf16 ... MFMA projections") ----
+ * Same computation and argument order as gh_ggnn_cell_fwd / _bwd with these tensors holding bf16 instead of fp32:
+ *   forward : x (rows, or the embedding table behind ids), the seven weights, xp a z rr rx hh, out;
+ *             out32 [m][h] fp32 additionally receives the cell output for the fp32 consumers (attention, scorer stays fused)
+ *   backward: x / table, the seven TRANSPOSED weights, the saved xp..hh, the scratch dhp dzp drp dxp da
+ * Biases, g, dx, score_w/score_x and every weight/bias gradient stay fp32; all arithmetic accumulates in fp32
+ * (v_mfma_f32_16x16x32_bf16; gate math in fp32 registers).  Needs din % 8 == 0, h % 8 == 0, din <= h, at least 8192 rows
+ * and the split-K workspace.  Results follow the fp32 path to bf16 accuracy (tests/test_gpu_model.py states the tolerances). */
+int gh_ggnn_cell_fwd_bf16(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                          const int32_t* goff, int m_real, int m_rows,
+                          const void* x, const int32_t* ids, int n, int r, int din, int h,
+                          const void* w_p, const void* w_z0, const void* w_z1, const void* w_r0,
+                          const void* w_r1, const void* w_h0, const void* w_h1,
+                          const float* b_z0, const float* b_z1, const float* b_r0, const float* b_r1,
+                          const float* b_h0, const float* b_h1,
+                          void* xp, void* a, void* z, void* rr, void* rx, void* hh, void* out, float* out32,
+                          float drop_p, uint32_t drop_seed,
+                          const float* score_w, float* score_x, float score_drop_p, uint32_t score_drop_seed,
+                          gh_stream_t stream);
+int gh_ggnn_cell_bwd_bf16(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                          const int32_t* goff, int m_real,
+                          const void* x, const int32_t* ids, int n, int r, int din, int h,
+                          const void* wt_p, const void* wt_z0, const void* wt_z1, const void* wt_r0,
+                          const void* wt_r1, const void* wt_h0, const void* wt_h1,
+                          const void* xp, const void* a, const void* z, const void* rr, const void* rx,
+                          const void* hh, const float* g,
+                          void* dhp, void* dzp, void* drp, void* dxp, void* da,
+                          float* dx, float* dw_p, float* dw_z0, float* dw_z1, float* dw_r0, float* dw_r1,
+                          float* dw_h0, float* dw_h1, float* db_z, float* db_r, float* db_h,
+                          float* db_z1, float* db_r1, float* db_h1, float drop_p, uint32_t drop_seed, gh_stream_t stream);
+
 /* ---- a2(300->1) + a3  word scorer + GSL top-k: wrapper.py:167-168, GSL.forward :215-227 ----
  * feat [n][r][h]; w_p[h] = scorer proj.linear.weight; gate[12] = {wz0,bz0,wz1,bz1,wr0,br0,wr1,br1,
  * wh0,bh0,wh1,bh1} (the six 1x1 linears).  k = int(rate * r) computed by the caller.
@@ -189,7 +220,7 @@ int gh_concat_att_bwd(const float* left, const float* right, const int32_t* goff
 
 /* ---- GEMM arithmetic mode (process-wide, default 0) ----
  * 0: exact fp32 MFMA everywhere -- the mode every parity claim and the headline benchmark are made in.
- * 1: the big-tile GEMMs (cell gates, dX, attention projections with >= 8192 rows, and the split-K weight gradients)
+ * 1: (the host layer additionally routes the evidence cells through gh_ggnn_cell_*_bf16 in this mode) the big-tile GEMMs (cell gates, dX, attention projections with >= 8192 rows, and the split-K weight gradients)
  *    round their operands to bf16 while staging them in LDS and use v_mfma_f32_16x16x16_bf16 with fp32 accumulation;
  *    storage, epilogues, bias gradients and all small GEMMs stay fp32.  For BASELINE configs[4] ("h=768 bf16"); results then
  *    match the fp32 oracle to bf16 accuracy only (~1e-2 relative on logits). */

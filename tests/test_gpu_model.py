@@ -289,7 +289,7 @@ def test_h768_bf16_gemm_mode_tracks_the_fp32_oracle():
     still sum to one, and switching back restores the fp32 result bit for bit."""
     from get_amd import _lib, ops
     from get_amd.synth import SynthConfig
-    cfg = SynthConfig(batch=6, n_evd=30, hidden=768, word_heads=8, evd_heads=2, window=5, gsl_rate=0.8, vocab=900,
+    cfg = SynthConfig(batch=6, n_evd=30, emb_dim=768, hidden=768, word_heads=8, evd_heads=2, window=5, gsl_rate=0.8, vocab=900,
                       n_article_src=40, n_claim_src=10)
     seed = 769
     model = build_model(cfg, seed)
@@ -315,6 +315,22 @@ def test_h768_bf16_gemm_mode_tracks_the_fp32_oracle():
     assert float((ww16 - ww32).abs().max()) <= 2e-2
     assert torch.allclose(ww16.sum(1), torch.ones_like(ww16.sum(1)), atol=1e-5)
     assert torch.allclose(ew16.sum(1), torch.ones_like(ew16.sum(1)), atol=1e-5)
+    # training step in both modes: every live gradient of the bf16 storage pipeline stays within 6e-2 of the fp32 one
+    # (relative to that gradient's largest entry) -- the stated tolerance of the configs[4] path
+    labels = torch.from_numpy(inp["labels"]).to(DEV)
+    grads = {}
+    for mode in ("fp32", "bf16"):
+        model.zero_grad(set_to_none=True)
+        _lib.set_gemm_mode(mode)
+        try:
+            torch.nn.functional.cross_entropy(model(q, d, **{k: v for k, v in kargs.items() if k != "output_ranking"}), labels).backward()
+        finally:
+            _lib.set_gemm_mode("fp32")
+        grads[mode] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    assert set(grads["fp32"]) == set(grads["bf16"]) and len(grads["fp32"]) >= 40
+    for k, g32 in grads["fp32"].items():
+        err = float((grads["bf16"][k] - g32).abs().max())
+        assert err <= 6e-2 * float(g32.abs().max()) + 1e-7, (k, err, float(g32.abs().max()))
 
 
 def test_ragged_realistic_batch_properties():

@@ -610,3 +610,46 @@ def test_bf16_mode_linear_matches_bf16_rounded_reference(bf16_mode, m, k, n):
     # and the mode really is different from fp32
     full = x.detach() @ w.detach().t() + b.detach()
     assert maxerr(y.detach().cpu(), full.cpu()) > 1e-4
+
+
+@pytest.mark.parametrize("compact", [False, True])
+@pytest.mark.parametrize("drop_p", [0.0, 0.2])
+def test_bf16_storage_cell_tracks_fp32(bf16_mode, compact, drop_p):
+    """BASELINE configs[4] path: gh_ggnn_cell_fwd/bwd_bf16 (bf16 activations and weights in HBM, v_mfma_f32_16x16x32_bf16, the
+    transpose-read weight-gradient kernel) against the fp32 cell on the same inputs and the same dropout mask.
+    Stated tolerance: outputs 3e-2 absolute (|out| <= ~2), gradients 5e-2 of their largest entry."""
+    from get_amd import _lib, modules, ops
+    rng = np.random.default_rng(77)
+    n, r, d, h = (300 if compact else 100), 100, 128, 256
+    from get_amd.synth import make_tokens
+    toks, lens = make_tokens(rng, n, r, 5000, r // 2, r)
+    padj, node_ids, nn = ops.graph_build(T(toks), T(lens), 3)
+    plan = ops.RaggedPlan(nn, node_ids, int(nn.sum().item())) if compact else None
+    assert (plan.m_real if compact else n * r) >= 8192
+    x = rng.standard_normal((n, r, d)).astype(np.float32) * 0.5
+    gw = rng.standard_normal((n, r, h)).astype(np.float32)
+    prm = cases.cell_params(rng, d, h)
+    mod = modules.GGNN(d, h, dropout=0.0)
+    _load_cell(mod, prm)
+    mod = mod.to(DEV)
+    res = {}
+    for mode in ("fp32", "bf16"):
+        _lib.set_gemm_mode(mode)
+        for p_ in mod.parameters():
+            p_.grad = None
+        if compact:
+            xc = plan.from_padded(T(x))[:plan.m_real].clone().requires_grad_(True)
+            out = ops.ggnn_cell(padj, xc, None, mod._params(), drop_p, 4242, plan=plan, rows=plan.m_real)
+            (out * plan.from_padded(T(gw))[:plan.m_real]).sum().backward()
+        else:
+            xc = T(x, grad=True)
+            out = ops.ggnn_cell(padj, xc, None, mod._params(), drop_p, 4242)
+            (out * T(gw)).sum().backward()
+        res[mode] = (out.detach().clone(), xc.grad.clone(), {k: q.grad.clone() for k, q in mod.named_parameters()})
+    assert getattr(res["bf16"][0], "dtype") == torch.float32
+    o32, dx32, g32 = res["fp32"]
+    o16, dx16, g16 = res["bf16"]
+    assert 1e-6 < float((o16 - o32).abs().max()) <= 3e-2
+    assert float((dx16 - dx32).abs().max()) <= 5e-2 * float(dx32.abs().max())
+    for k in g32:
+        assert float((g16[k] - g32[k]).abs().max()) <= 5e-2 * float(g32[k].abs().max()) + 1e-6, k
