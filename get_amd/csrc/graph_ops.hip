@@ -373,6 +373,203 @@ spmm_wave_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
   }
 }
 
+// Edge-list variant of the slab kernel (the default for float4-shaped rows).  The bit-walk version above spends ~25
+// VALU instructions per (output float4, neighbour) -- 64-bit ctz / clear-lowest-bit / weight product per lane -- and was
+// VALU-issue-bound (1.4 G lane-instructions per launch at the bench shape = 35 us of a 47 us launch).  Here the
+// refined bit rows of the graph are expanded ONCE per workgroup into an LDS edge list {j, w_ij} (row-start offsets by a
+// workgroup scan of the popcounts), and every thread owns CPT float4 columns of one row, so the inner loop per
+// neighbour is one 8-byte list read, one address mad and CPT x (ds_read_b128 + 4 FMA).  Graphs whose edge count
+// exceeds the list capacity (dense hand-overs) fall back to the bit walk inside the same kernel.
+template <bool BF, int CPT>
+__global__ void __launch_bounds__(256)
+spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
+                 const uint64_t* __restrict__ keep, const int32_t* __restrict__ goff, const float* __restrict__ x,
+                 float* __restrict__ y, int R, int H, int slab, int cap, int transpose, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  const int W = (R + 63) / 64;
+  float4* xs = reinterpret_cast<float4*>(dsm);                                                // [R][slab]
+  uint2* ent = reinterpret_cast<uint2*>(xs + (size_t)R * slab);                               // [cap] {j, w}
+  unsigned long long* rb = reinterpret_cast<unsigned long long*>(ent);                        // [R][W] refined bit rows (fallback only; cap >= R*W)
+  int* st = reinterpret_cast<int*>(ent + cap);                                                // [R + 1] row starts
+  float* dv = reinterpret_cast<float*>(st + R + 1);                                           // [R]
+  __shared__ int wsum[4];
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.y * slab;
+  // exact n / d for n, d < 2^16 by one multiply-high (a runtime integer division costs ~20 VALU instructions)
+  auto magic_of = [](int d) { return (unsigned)(0xFFFFFFFFu / (unsigned)d) + 1u; };
+  auto fdiv = [](int n, unsigned magic) { return (int)__umulhi((unsigned)n, magic); };
+  const int H4 = H / 4;
+  const int ncol = min(slab, H4 - c0);
+  const int row0 = goff ? goff[g] : g * R;
+  const int NR = goff ? goff[g + 1] - row0 : R;
+  if (NR <= 0) return;
+  // ---- stage.  Issue order = completion order on the vector-memory counter: the few small loads of this thread's row
+  // (bit words, keep words, dinv) go first, the slab's 16-byte loads after them, so the list is built from the former
+  // while the latter are still in flight.  sched_barrier pins that order.
+  constexpr int SL = 12;
+  const int total = NR * ncol;
+  const unsigned mg_ncol = magic_of(ncol);
+  const int trow = min(tid, R - 1);
+  unsigned long long mrow[4] = {0ull, 0ull, 0ull, 0ull}, kwd[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+#pragma unroll
+  for (int w = 0; w < 4; ++w)
+    if (w < W) {
+      mrow[w] = bits[((size_t)g * R + trow) * W + w];
+      if (keep) kwd[w] = keep[(size_t)g * W + w];
+    }
+  const float dvv = vals ? 0.f : dinv[(size_t)g * R + trow];
+  __builtin_amdgcn_sched_barrier(0);
+  float4 tmp[BF ? SL : 1];
+  if (BF) {
+#pragma unroll
+    for (int k = 0; k < SL; ++k) {
+      const int it = min(tid + k * 256, total - 1);
+      const int i = fdiv(it, mg_ncol), c = it - i * ncol;
+      tmp[BF ? k : 0] = bf4_to_f4(reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x) + ((size_t)row0 + i) * H)[c0 + c]);
+    }
+  } else {
+    // fp32: LDS-DMA (buffer_load_dwordx4 ... lds): the LDS image is linear in it = i * ncol + c, so a wave's 64 lanes
+    // land in 1 KB of consecutive LDS; no staging registers, no ds_write
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)row0 * H), 0, 0x7fffffff, 0x00020000);
+    for (int base = 0; base < total; base += 256) {
+      const int it = base + tid;
+      if (it < total) {
+        const int i = fdiv(it, mg_ncol), c = it - i * ncol;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + base + wave * 64), 16,
+                                                 (i * H + (c0 + c) * 4) * 4, 0, 0, 0);
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // this thread's row (tid < NR): refined words, degree
+  int deg = 0;
+  {
+    bool ki = true;
+    if (keep) {
+      unsigned long long kw = kwd[0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) if ((trow >> 6) == w) kw = kwd[w];
+      ki = (kw >> (trow & 63)) & 1ull;
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      unsigned long long m = (w < W && tid < NR) ? mrow[w] : 0ull;
+      if (!ki) m &= kwd[w];                                    // edge survives iff keep(i) || keep(j)
+      mrow[w] = m;
+      deg += __popcll(m);
+    }
+  }
+  if (tid < R) dv[tid] = dvv;
+  // exclusive scan of deg over the 256 threads
+  int inc = deg;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(inc, o);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) if (w < wave) base += wsum[w];
+  const int nnz = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  const int start = base + inc - deg;
+  const bool listed = nnz <= cap;                 // workgroup-uniform
+  if (tid <= R) st[tid] = (tid < NR) ? start : nnz;
+  if (R >= 256 && tid == 0) st[R] = nnz;
+  if (tid < NR) {
+    if (listed) {
+      const float di = dvv;
+      int e = start;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (w < W) {
+          unsigned long long m = mrow[w];
+          while (m) {
+            const int j = (w << 6) + __builtin_ctzll(m);
+            m &= m - 1;
+            const float wt = vals ? (transpose ? vals[((size_t)g * R + j) * R + tid] : vals[((size_t)g * R + tid) * R + j])
+                                  : di * dv[j];
+            ent[e++] = make_uint2((unsigned)j, __builtin_bit_cast(unsigned, wt));
+          }
+        }
+    } else {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) if (w < W) rb[tid * W + w] = mrow[w];
+    }
+  }
+  if (BF) {
+#pragma unroll
+    for (int k = 0; k < SL; ++k) xs[min(tid + k * 256, total - 1)] = tmp[BF ? k : 0];   // LDS pitch == ncol: linear in `it`
+    for (int it = tid + SL * 256; it < total; it += 256) {
+      const int i = fdiv(it, mg_ncol), c = it - i * ncol;
+      xs[it] = bf4_to_f4(reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x) + ((size_t)row0 + i) * H)[c0 + c]);
+    }
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  // ---- aggregate: thread = (row i, column group q); columns q, q + TPR, ...
+  const int TPR = (ncol + CPT - 1) / CPT;
+  const int nit = NR * TPR;
+  const unsigned mg_tpr = magic_of(TPR);
+  const float* vg = vals ? vals + (size_t)g * R * R : nullptr;
+  for (int it = tid; it < nit; it += 256) {
+    const int i = fdiv(it, mg_tpr), q = it - i * TPR;
+    int cc[CPT];
+    float4 acc[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) { cc[k] = min(q + k * TPR, ncol - 1); acc[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    if (listed) {
+      const int e1 = st[i + 1];
+      for (int e = st[i]; e < e1; e += 2) {
+        const uint2 ea = ent[e];
+        const bool two = e + 1 < e1;
+        const uint2 eb = ent[two ? e + 1 : e];
+        const float wa = __builtin_bit_cast(float, ea.y);
+        const float wb = two ? __builtin_bit_cast(float, eb.y) : 0.f;
+        float4 xa[CPT], xb[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) { xa[k] = xs[ea.x * ncol + cc[k]]; xb[k] = xs[eb.x * ncol + cc[k]]; }
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+          acc[k].x += wa * xa[k].x; acc[k].y += wa * xa[k].y; acc[k].z += wa * xa[k].z; acc[k].w += wa * xa[k].w;
+          acc[k].x += wb * xb[k].x; acc[k].y += wb * xb[k].y; acc[k].z += wb * xb[k].z; acc[k].w += wb * xb[k].w;
+        }
+      }
+    } else {
+      const float di = vals ? 0.f : dv[i];
+      for (int w = 0; w < W; ++w) {
+        unsigned long long m = rb[i * W + w];
+        while (m) {
+          const int j = (w << 6) + __builtin_ctzll(m);
+          m &= m - 1;
+          const float wt = vg ? (transpose ? vg[(size_t)j * R + i] : vg[(size_t)i * R + j]) : di * dv[j];
+#pragma unroll
+          for (int k = 0; k < CPT; ++k) {
+            const float4 xv = xs[j * ncol + cc[k]];
+            acc[k].x += wt * xv.x; acc[k].y += wt * xv.y; acc[k].z += wt * xv.z; acc[k].w += wt * xv.w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      if (q + k * TPR >= ncol) break;
+      float4 a = acc[k];
+      if (BF) {
+        uint2* o = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(y) + ((size_t)row0 + i) * H) + c0 + cc[k];
+        if (accumulate) { const float4 p = bf4_to_f4(*o); a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w; }
+        *o = f4_to_bf4(a);
+      } else {
+        float4* o = reinterpret_cast<float4*>(y + ((size_t)row0 + i) * H) + c0 + cc[k];
+        if (accumulate) { const float4 p = *o; a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w; }
+        *o = a;
+      }
+    }
+  }
+}
+
 int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const int32_t* goff,
                 int m_real, const float* x, float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s, int bf16) {
   GH_REQUIRE(r <= MAX_R, "spmm: padded graph size %d > %d", r, MAX_R);
@@ -396,13 +593,30 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   const double rows = goff ? (double)m_real : (double)n * r;
   const double alg_bytes = (2.0 + (accumulate ? 1.0 : 0.0)) * rows * h * (bf16 ? 2.0 : 4.0) +
                            (double)n * ((double)r * W * 8.0 + (vals ? (double)r * r * 4.0 : (double)r * 4.0));
-  // 0 (default): LDS-staged slab kernel -- every feature row leaves HBM exactly once (FETCH ~= algorithmic bytes);
+  // 4 (default; 3 / 5: one / three columns per thread): edge-list slab kernel, LDS-DMA staging -- 62 us vs 69 us for the
+  // bit-walk slab kernel (0) on 960 x 100 x 300 Zipf word graphs, 50 vs 61 us on hub-free graphs;
+  // (a graph-per-workgroup pipeline over two LDS buffers, next slab's DMA in flight during the aggregation, measured
+  // slower -- 74-85 us at two workgroups per CU -- and was dropped);
   // 1 / 2: LDS-free gather variants (thread-per-float4 / wave-per-row).  Measured equal or slower on MI355X: with
   // ~8K waves in flight their sliding-window working set (~49 MB) thrashes the 32 MB of L2 (hit rate 32 %).
   static int variant = -1;
-  if (variant < 0) { const char* e = getenv("GH_SPMM_VARIANT"); variant = e ? atoi(e) : 0; }
+  if (variant < 0) { const char* e = getenv("GH_SPMM_VARIANT"); variant = e ? atoi(e) : 4; if (variant > 5) variant = 4; }
   prof_begin(s, PROF_SPMM);
-  if (bf16) {
+  if (v4 && variant >= 3 && r <= 256) {
+    // edge-list kernel; variant 3: one column per thread, 4 (default): two, 5: three.  LDS pitch = slab columns.
+    const int cap = 11 * r;                        // edges per graph the list holds (a window-5 word graph has <= 9 R)
+    const size_t llds = (size_t)r * slab * 16 + (size_t)cap * 8 + (size_t)(r + 1) * 4 + (size_t)r * 4;
+    const void* fn;
+    const int lv = variant > 5 ? 5 : variant;
+    if (bf16) fn = lv == 3 ? (const void*)spmm_list_kernel<true, 1> : lv == 5 ? (const void*)spmm_list_kernel<true, 3> : (const void*)spmm_list_kernel<true, 2>;
+    else fn = lv == 3 ? (const void*)spmm_list_kernel<false, 1> : lv == 5 ? (const void*)spmm_list_kernel<false, 3> : (const void*)spmm_list_kernel<false, 2>;
+    static bool attrl[6] = {false, false, false, false, false, false};
+    const int ai = (bf16 ? 3 : 0) + (lv - 3);
+    if (!attrl[ai] && llds > 64 * 1024) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrl[ai] = true; }
+    void* args[] = {(void*)&bits, (void*)&dinv, (void*)&vals, (void*)&keep, (void*)&goff, (void*)&x, (void*)&y, (void*)&r, (void*)&h,
+                    (void*)&slab, (void*)&cap, (void*)&transpose, (void*)&accumulate};
+    (void)hipLaunchKernel(fn, grid, dim3(256), args, llds, s);
+  } else if (bf16) {
     static bool attrb = false;
     if (!attrb && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)spmm_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrb = true; }
     hipLaunchKernelGGL((spmm_kernel<4, true>), grid, dim3(256), lds, s, bits, dinv, vals, keep, goff, x, y, r, h, slab, transpose, accumulate);

@@ -380,9 +380,22 @@ class Graph_basedSemantiStructure(nn.Module):
         seg = ops.Segments(kargs[K.EvidenceCountPerQuery], b1, n_max)
 
         # claim branch (:144-155): GGNN -> masked mean over the unique claim nodes -> one row per pair
-        q_hid = self.ggnn4claim_1.forward_ids(kargs[K.Query_Adj], self.embedding, query)
-        q_repr = ops.masked_mean(q_hid, query, kargs[K.Query_lens])            # (B, H)
-        query_repr = ops.seg_broadcast(q_repr, seg)                            # (B1, H)
+        def claim_branch():
+            q_hid = self.ggnn4claim_1.forward_ids(kargs[K.Query_Adj], self.embedding, query)
+            q = ops.masked_mean(q_hid, query, kargs[K.Query_lens])             # (B, H)
+            return q, ops.seg_broadcast(q, seg)                                # (B1, H)
+
+        # The claim branch is a chain of few-row launches (B x L rows) that is independent of the evidence branch until
+        # the word attention: on a ROCm device it runs on a side stream underneath the evidence cells' GEMMs.  It is
+        # issued AFTER the evidence branch so that autograd (which replays nodes newest-first, each on its forward
+        # stream) also starts the claim backward before the evidence cells' backward.
+        side = ops.side_stream(query.device) if ops.CLAIM_SIDE_STREAM and query.is_cuda else None
+        if side is None:
+            q_repr, query_repr = claim_branch()
+        else:
+            main = torch.cuda.current_stream(query.device)
+            inputs_ready = torch.cuda.Event()
+            inputs_ready.record(main)
 
         # evidence branch (:107): GGNN -> scorer + GSL -> GGNN on the refined graph.  A PackedAdj that carries a
         # node-compact plan (NativeBatch) takes the fast path that skips the padding nodes wherever they cannot
@@ -390,6 +403,14 @@ class Graph_basedSemantiStructure(nn.Module):
         d_adj = kargs[K.Evd_Docs_Adj]
         plan = d_adj.plan if isinstance(d_adj, PackedAdj) else None
         doc_out = self.ggnn_with_gsl.forward_ids(d_adj, self.embedding, doc, plan=plan)
+
+        if side is not None:
+            side.wait_event(inputs_ready)
+            with torch.cuda.stream(side):
+                q_repr, query_repr = claim_branch()
+            main.wait_stream(side)
+            q_repr.record_stream(main)
+            query_repr.record_stream(main)
 
         # word-level attention (:173-193); the claim vector WITHOUT its source embedding (:110)
         if plan is None:

@@ -5,6 +5,7 @@ step runs in libget_hip.so.  All tensors are fp32/contiguous on a ROCm device.
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Optional
 
@@ -12,6 +13,22 @@ import torch
 
 from . import _lib
 from ._lib import call, ptr, stream
+
+# GET_AMD_CLAIM_STREAM=0 keeps the claim branch on the caller's stream (modules.Graph_basedSemantiStructure.forward)
+CLAIM_SIDE_STREAM = os.environ.get("GET_AMD_CLAIM_STREAM", "1") != "0"
+_SIDE_STREAMS: dict = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """One auxiliary HIP stream per device for work that is independent of the main chain of launches."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = _SIDE_STREAMS.get(idx)
+    if s is None:
+        s = torch.cuda.Stream(device=idx)
+        _SIDE_STREAMS[idx] = s
+    return s
+
 
 _WEIGHT_EPOCH = 0
 _WT_CACHE: dict = {}

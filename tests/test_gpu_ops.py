@@ -157,6 +157,26 @@ def test_spmm_pattern_asymmetric_adjacency(r):
         assert maxerr(prm.grad.cpu(), po[k].grad) <= 1e-3 * float(po[k].grad.abs().max()) + 1e-6, k
 
 
+@pytest.mark.parametrize("r,h", [(100, 300), (64, 32), (200, 64)])
+def test_spmm_dense_adjacency_beyond_the_edge_list(r, h):
+    """A dense hand-over with far more edges than the aggregation kernel's LDS edge list holds (11 R): the kernel's
+    in-place bit-walk fallback must give the same product, forward and transposed."""
+    from get_amd import ops
+    rng = np.random.default_rng(77 + r)
+    n = 3
+    a = rng.standard_normal((n, r, r)) * (rng.random((n, r, r)) < 0.4)
+    a[1] = np.eye(r)                                   # a sparse graph in the same launch takes the list path
+    x = rng.standard_normal((n, r, h)).astype(np.float32)
+    g = rng.standard_normal((n, r, h)).astype(np.float32)
+    xt = T(x, grad=True)
+    y = ops.spmm(ops.PackedAdj.from_dense(T(a)), xt)
+    ref = torch.from_numpy(a).float() @ torch.from_numpy(x)
+    assert maxerr(y.detach().cpu(), ref) <= 4e-6 * max(1.0, float(ref.abs().max()))
+    (y * T(g)).sum().backward()
+    refg = torch.from_numpy(a).float().transpose(1, 2) @ torch.from_numpy(g)
+    assert maxerr(xt.grad.cpu(), refg) <= 4e-6 * max(1.0, float(refg.abs().max()))
+
+
 # ---------------------------------------------------------------- a2 GGNN cell (G2)
 def _load_cell(mod, p, prefix=""):
     sd = {k[len(prefix):]: torch.from_numpy(v) for k, v in p.items() if k.startswith(prefix)}

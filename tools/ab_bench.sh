@@ -1,14 +1,14 @@
 #!/bin/bash
-# bench.py under several environment settings on ONE box, interleaved twice.  usage: tools/ab_bench.sh "ENV1" "ENV2" ...  ("-" = none)
+# pairs/s of the default bench workload under different environment settings.  usage: tools/ab_bench.sh "ENV1" "ENV2" ...  ("-" = none)
 cd $GRAFT_REPO_ROOT
-for rep in 1 2; do
-  for e in "$@"; do
-    if [ "$e" = "-" ]; then timeout 200 python bench.py --no-cpu-baseline --no-series > /tmp/ab.json 2>/dev/null; else env $e timeout 200 python bench.py --no-cpu-baseline --no-series > /tmp/ab.json 2>/dev/null; fi
-    python - "$e" <<'P'
-import json, sys
-d = json.load(open("/tmp/ab.json"))
-k = d["kernels"]
-print("%-28s %8.0f pairs/s  %.3f ms  big %.3f  tn %.3f  small %.3f" % (sys.argv[1], d["value"], d["ms_per_step"], k["gemm_big"]["ms_per_step"], k["gemm_big_tn"]["ms_per_step"], k["gemm_small"]["ms_per_step"]))
-P
+mkdir -p gpurun_out/r2
+for e in "$@"; do
+  if [ "$e" = "-" ]; then e="GH_NONE=1"; fi
+  for rep in 1 2; do
+    env $e python bench.py --steps 30 --warmup 8 --no-cpu-baseline --no-series --no-profile 2> gpurun_out/r2/ab_err.log | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$e', 'pairs/s %.0f  ms/step %.4f  parity %s' % (d['value'], d['ms_per_step'], d.get('parity', {}).get('max_abs_logit_diff_vs_cpu_oracle')))
+" || tail -5 gpurun_out/r2/ab_err.log
   done
 done
