@@ -225,9 +225,13 @@ nt_finish_kernel(const FinishArgs F) {
     const int col = 4 * c4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* p = it.ws + (size_t)row * it.N + col;
-    for (int k = 0; k < it.ks; ++k) {
-      const float4 x = *reinterpret_cast<const float4*>(p + (size_t)k * it.stride);
-      v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+    for (int k0 = 0; k0 < it.ks; k0 += 8) {            // eight partial tiles in flight, added in split order
+      float4 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(p + (size_t)min(k0 + u, it.ks - 1) * it.stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + u < it.ks) { v.x += x[u].x; v.y += x[u].y; v.z += x[u].z; v.w += x[u].w; }
     }
     const size_t oo = (size_t)row * it.ldc + col;
     float* o = it.C + oo;

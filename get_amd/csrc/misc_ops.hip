@@ -363,6 +363,26 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
   const float* eb = e + (size_t)row0 * C;
   const float* mb = mask + (size_t)row0;
   const int NT = blockDim.x, NWV = NT >> 6;
+  // The right tile is what the kernel streams (L rows x Dr floats per pair): the first batch of this wave's rows is
+  // requested BEFORE the softmax (its latency hides behind the exp / shuffle work), and every later batch before the
+  // previous one is consumed -- RB rows = RB KB per wave in flight instead of the one-row-at-a-time walk that kept the
+  // kernel latency-bound at 1.9 TB/s.
+  constexpr int RB = 8;
+  const int D4 = Dr / 4;
+  const int d4 = blockIdx.y * 64 + lane;
+  const bool colok = d4 < D4;
+  const float4* rb = reinterpret_cast<const float4*>(right + (size_t)row0 * Dr) + (colok ? d4 : 0);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // (unconditional loads from clamped rows: a `cond ? load : 0` select makes the compiler route the load through a flat
+  // pointer to a zero in scratch; rows beyond L are loaded twice and never consumed)
+  float4 nxt[RB];
+  if (L > 0) {
+#pragma unroll
+    for (int u = 0; u < RB; ++u) nxt[u] = rb[(size_t)min(wave + u * NWV, L - 1) * D4];
+  } else {
+#pragma unroll
+    for (int u = 0; u < RB; ++u) nxt[u] = zero4;
+  }
   for (int c = wave; c < C; c += NWV) {
     float mx = -INFINITY;
     for (int l = lane; l < L; l += 64)
@@ -381,27 +401,34 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
   __syncthreads();
   if (blockIdx.y == 0)
     for (int i = tid; i < L * C; i += NT) weights[(size_t)row0 * C + i] = ws[i];
-  // attended[d][c] = sum_l right[l][d] w[l][c]: blockIdx.y owns a slab of 64 float4 columns, the four
-  // waves take every fourth row (16-byte coalesced reads), partial sums meet in LDS
+  // attended[d][c] = sum_l right[l][d] w[l][c]: blockIdx.y owns a slab of 64 float4 columns, the waves take every
+  // NWV-th row (16-byte coalesced reads), partial sums meet in LDS
   float* part = ws + Lmax * C;                   // [NWV][64][4][C] floats
-  const int D4 = Dr / 4;
-  const int d4 = blockIdx.y * 64 + lane;
   float acc[4][8];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
-  if (d4 < D4) {
-    const float4* rb = reinterpret_cast<const float4*>(right + (size_t)row0 * Dr) + d4;
-#pragma unroll 4
-    for (int l = wave; l < L; l += NWV) {
-      const float4 rv = rb[(size_t)l * D4];
+  for (int l0 = wave; l0 < L; l0 += RB * NWV) {
+    float4 cur[RB];
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
-        if (c < C) {
-          const float w = ws[l * C + c];
-          acc[0][c] += rv.x * w; acc[1][c] += rv.y * w; acc[2][c] += rv.z * w; acc[3][c] += rv.w * w;
-        }
+    for (int u = 0; u < RB; ++u) cur[u] = nxt[u];
+    if (l0 + RB * NWV < L) {
+#pragma unroll
+      for (int u = 0; u < RB; ++u) nxt[u] = rb[(size_t)min(l0 + (RB + u) * NWV, L - 1) * D4];
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int l = l0 + u * NWV;
+      if (l < L && colok) {
+        const float4 rv = cur[u];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < C) {
+            const float w = ws[l * C + c];
+            acc[0][c] += rv.x * w; acc[1][c] += rv.y * w; acc[2][c] += rv.z * w; acc[3][c] += rv.w * w;
+          }
+      }
     }
   }
 #pragma unroll
@@ -520,8 +547,9 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
   static bool attr = false;
   if (!attr && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)att_softmax_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
   prof_begin(s, PROF_ATT_SOFTMAX_BWD);
-  hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(b), dim3(256), lds, s, right, weights, g_att, g_w, goff, l, dr, heads, de,
-                     dright);
+  // few pairs (evidence level: one workgroup per claim): eight waves share the rows of a pair
+  hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(b), dim3(b < 512 ? 512 : 256), lds, s, right, weights, g_att, g_w, goff, l, dr,
+                     heads, de, dright);
   const double rows = goff ? (double)m_real : (double)b * l;
   prof_end(PROF_ATT_SOFTMAX_BWD, 4.0 * (2.0 * rows * dr + 3.0 * rows * heads + (double)b * dr * heads), s);
   GH_LAUNCH_CHECK();
@@ -543,37 +571,61 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
   const int L = goff ? goff[b + 1] - row0 : Lmax;
   const int n4 = Ha / 4;
   float* des = reinterpret_cast<float*>(red + (size_t)RL * (1 + C) * S4);       // [L][C]: read once, not once per thread and row
-  for (int i = threadIdx.x; i < L * C; i += blockDim.x) des[i] = de[(size_t)row0 * C + i];
-  __syncthreads();
   const int s0 = blockIdx.y * S4;                          // first float4 column of this slab
   const int sw = min(S4, n4 - s0);
   const int cl = threadIdx.x % S4, rl = threadIdx.x / S4;
   const int c4 = s0 + cl;
   const bool act = rl < RL && cl < sw;
+  // RB rows per thread and trip with all loads ahead of the math; the first trip's rows are requested before `de` is
+  // staged (loads unconditional from clamped rows / columns; clamped duplicates are never consumed)
+  constexpr int RB = 4;
+  const int c4c = min(c4, n4 - 1);
+  const float4* tb = reinterpret_cast<const float4*>(t + (size_t)row0 * Ha) + c4c;
+  float4 nxt[RB];
+  if (L > 0) {
+#pragma unroll
+    for (int u = 0; u < RB; ++u) nxt[u] = tb[(size_t)min(rl + u * RL, L - 1) * n4];
+  }
+  for (int i = threadIdx.x; i < L * C; i += blockDim.x) des[i] = de[(size_t)row0 * C + i];
   float4 wc[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) wc[c] = (c < C && act) ? reinterpret_cast<const float4*>(w2 + (size_t)c * Ha)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < 8; ++c) {
+    wc[c] = reinterpret_cast<const float4*>(w2 + (size_t)min(c, C - 1) * Ha)[c4c];
+    if (c >= C || !act) wc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 dw[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) dw[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (act) {
-#pragma unroll 4
-    for (int l = rl; l < L; l += RL) {
-      const size_t m = (size_t)row0 + l;
-      const float4 tv = reinterpret_cast<const float4*>(t + m * Ha)[c4];
-      float4 dt = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l0 = rl; l0 < L; l0 += RB * RL) {
+      float4 cur[RB];
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
-        if (c < C) {
-          const float e = des[l * C + c];
-          dt.x += e * wc[c].x; dt.y += e * wc[c].y; dt.z += e * wc[c].z; dt.w += e * wc[c].w;
-          dw[c].x += e * tv.x; dw[c].y += e * tv.y; dw[c].z += e * tv.z; dw[c].w += e * tv.w;
-        }
-      const float4 dp = make_float4(dt.x * (1.f - tv.x * tv.x), dt.y * (1.f - tv.y * tv.y), dt.z * (1.f - tv.z * tv.z),
-                                    dt.w * (1.f - tv.w * tv.w));
-      reinterpret_cast<float4*>(dpre + m * Ha)[c4] = dp;
-      acc.x += dp.x; acc.y += dp.y; acc.z += dp.z; acc.w += dp.w;
+      for (int u = 0; u < RB; ++u) cur[u] = nxt[u];
+      if (l0 + RB * RL < L) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) nxt[u] = tb[(size_t)min(l0 + (RB + u) * RL, L - 1) * n4];
+      }
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int l = l0 + u * RL;
+        if (l >= L) break;
+        const size_t m = (size_t)row0 + l;
+        const float4 tv = cur[u];
+        float4 dt = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < C) {
+            const float e = des[l * C + c];
+            dt.x += e * wc[c].x; dt.y += e * wc[c].y; dt.z += e * wc[c].z; dt.w += e * wc[c].w;
+            dw[c].x += e * tv.x; dw[c].y += e * tv.y; dw[c].z += e * tv.z; dw[c].w += e * tv.w;
+          }
+        const float4 dp = make_float4(dt.x * (1.f - tv.x * tv.x), dt.y * (1.f - tv.y * tv.y), dt.z * (1.f - tv.z * tv.z),
+                                      dt.w * (1.f - tv.w * tv.w));
+        reinterpret_cast<float4*>(dpre + m * Ha)[c4] = dp;
+        acc.x += dp.x; acc.y += dp.y; acc.z += dp.z; acc.w += dp.w;
+      }
     }
   }
   if (rl < RL) {
@@ -650,9 +702,16 @@ __global__ void __launch_bounds__(256)
 seg_sum_kernel(const float* __restrict__ src, const int32_t* __restrict__ offsets, float* __restrict__ dst, int X) {
   const int b = blockIdx.x;
   const int lo = offsets[b], hi = offsets[b + 1];
+  // (few workgroups, a serial walk over <= n_max rows: eight row loads in flight per trip, added in row order)
   for (int i = threadIdx.x; i < X; i += blockDim.x) {
     float acc = 0.f;
-    for (int p = lo; p < hi; ++p) acc += src[(size_t)p * X + i];
+    for (int p = lo; p < hi; p += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(p + u, hi - 1) * X + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (p + u < hi) acc += v[u];
+    }
     dst[(size_t)b * X + i] = acc;
   }
 }
@@ -690,8 +749,18 @@ masked_mean_fwd_kernel(const float* __restrict__ hid, const int32_t* __restrict_
   const float inv = 1.f / lens[b];
   for (int i = threadIdx.x; i < H; i += blockDim.x) {
     float acc = 0.f;
-    for (int l = 0; l < L; ++l)
-      if (ids[b * L + l] > 0) acc += hid[((size_t)b * L + l) * H + i];
+    for (int l = 0; l < L; l += 8) {
+      float v[8];
+      int id[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int lc = min(l + u, L - 1);
+        id[u] = ids[b * L + lc];
+        v[u] = hid[((size_t)b * L + lc) * H + i];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (l + u < L && id[u] > 0) acc += v[u];
+    }
     dst[(size_t)b * H + i] = acc * inv;
   }
 }
@@ -818,13 +887,20 @@ tiny_linear_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
     float wc[8], dwc[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) { wc[c] = c < n ? w[(size_t)c * k + i] : 0.f; dwc[c] = 0.f; }
-    for (int r = 0; r < m; ++r) {
-      const float xv = x[(size_t)r * k + i];
-      float d = 0.f;
+    for (int r0 = 0; r0 < m; r0 += 8) {
+      float xv[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
-        if (c < n) { const float gv = g[(size_t)r * n + c]; d += gv * wc[c]; dwc[c] += gv * xv; }
-      if (dx) dx[(size_t)r * k + i] = d;
+      for (int u = 0; u < 8; ++u) xv[u] = x[(size_t)min(r0 + u, m - 1) * k + i];       // eight rows in flight
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u;
+        if (r >= m) break;
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < n) { const float gv = g[(size_t)r * n + c]; d += gv * wc[c]; dwc[c] += gv * xv[u]; }
+        if (dx) dx[(size_t)r * k + i] = d;
+      }
     }
     if (dw)
 #pragma unroll
@@ -845,7 +921,7 @@ int launch_tiny_linear_fwd(const float* x, const float* w, const float* bias, fl
 }
 int launch_tiny_linear_bwd(const float* x, const float* w, const float* g, float* dx, float* dw, float* db, int m, int k, int n,
                            hipStream_t s) {
-  hipLaunchKernelGGL(tiny_linear_bwd_kernel, dim3((k + 255) / 256), dim3(256), 0, s, x, w, g, dx, dw, db, m, k, n);
+  hipLaunchKernelGGL(tiny_linear_bwd_kernel, dim3((k + 63) / 64), dim3(64), 0, s, x, w, g, dx, dw, db, m, k, n);
   GH_LAUNCH_CHECK();
   return 0;
 }
