@@ -39,8 +39,12 @@ __device__ __forceinline__ unsigned nt_pack_bf16(float a, float b) {
 //         64-byte rows ([row][32 k bf16]), one ds_read_b128 is a lane's 8 consecutive k, i.e. exactly the operand of
 //         v_mfma_f32_16x16x32_bf16 (one MFMA per 16x16 tile and K tile) -- fp32 accumulation and epilogue arithmetic,
 //         epilogue streams bf16 or fp32 per Problem::io.
+// MI = 4 (bf16 storage only: <2, 2, 8, 4, 2> = a 128 x 256 tile): at h = 768 the 64 x 320 tile wastes a fifth of its
+//         columns (768 = 2.4 x 320) and re-reads the 320-row weight panel from L2 for every 64 rows; 128 x 256 covers 768
+//         exactly, halves the weight traffic per FLOP and needs 12 instead of 24 ds_read_b128 per 32 MFMAs.  128
+//         accumulator registers per lane -> two workgroups per CU.
 template <int WM, int WN, int NI, int MI = 2, int MODE = 0>
-__global__ void __launch_bounds__(WM * WN * 64, 3)
+__global__ void __launch_bounds__(WM * WN * 64, MI == 4 ? 2 : 3)
 gemm_nt_kernel(const Launch L_byval) {
   (void)L_byval;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -55,11 +59,19 @@ gemm_nt_kernel(const Launch L_byval) {
   constexpr int STAGE = (BM + BN) * 64;
   constexpr int EP_PITCH = BN + 4;                                 // floats: 16-byte rows, 8 consecutive rows cover all banks
   constexpr int EP_BYTES = 16 * WM * EP_PITCH * 4 + NW * 64 * 16 + BN * 4;  // staged rows + row-reduction partials + bias
-  constexpr int SMEM = 2 * STAGE > EP_BYTES ? 2 * STAGE : EP_BYTES;
+  // K-loop LDS stages.  fp32: a K tile is ~2560 MFMA cycles per wave (~1 us), about one DMA round trip, so two stages
+  // (prefetch distance 1) suffice.  The 128 x 256 bf16 tile computes a K tile in 512 cycles (~0.2 us): with distance 1 every
+  // tile waits most of a DMA latency (PMC: waves parked 55 % of the time), so it runs three stages / distance 2, waits
+  // with vmcnt(DMA instructions of ONE tile) and synchronises with a bare s_barrier (a __syncthreads() would drain the
+  // newest tile's DMA as well).  73.5 KB of LDS -> dynamic allocation.
+  constexpr int NST = (MI == 4) ? 3 : 2;
+  constexpr int SMEM = NST * STAGE > EP_BYTES ? NST * STAGE : EP_BYTES;
   constexpr unsigned OOB = 0x80000000u;
   constexpr int NH = NI / 2;                                       // B fragment batches: X = tiles [0,NH), Y = [NH,NI)
-  static_assert(MI == 2, "two 16-row tiles per wave");
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  static_assert(MI == 2 || (MI == 4 && MODE == 2), "two 16-row tiles per wave (four in the 128 x 256 bf16 configuration)");
+  extern __shared__ __attribute__((aligned(16))) unsigned char nt_dyn_smem[];
+  __shared__ __attribute__((aligned(16))) unsigned char nt_static_smem[NST == 2 ? SMEM : 16];
+  unsigned char* const smem = NST == 2 ? nt_static_smem : nt_dyn_smem;
 
   // ---- XCD-aware work decode (as gemm.hip.h): the problems of one row tile run back to back on one XCD
   const int n_inner = L.nprob * L.ksplit;
@@ -272,6 +284,39 @@ gemm_nt_kernel(const Launch L_byval) {
   // ---- main loop: 2 LDS stages, one barrier per K tile.  Instantiated for the common tile counts so that the MFMA
   //      stream is branch-free: every column tile valid / the last one of the Y batch all padding (N = 300).
   auto run = [&](auto CX, auto CY) __attribute__((always_inline)) {
+    if constexpr (NST == 3) {
+      static_assert(SA * NW == NAI && SB * NW == NBI && SA + SB == 6, "vmcnt(6) below = the DMA instructions of one K tile per wave");
+      dma_tile(0, 0);
+      if (T > 1) dma_tile(1, 1);
+      if (T > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int st = 0;
+      for (int t = 0; t < T; ++t) {
+        const int st2 = st == 0 ? 2 : st - 1;            // (st + 2) % 3: the stage tile t-1 was read from, free since the last barrier
+        if (t + 2 < T) dma_tile(t + 2, st2);
+        read_a(st, aC);
+        read_b(st, bX, 0, NH);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t > 0) mma(aP, bY, NH, CY);
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(st, bY, NH, NI - NH);
+        if (drop_mode == 1) drop_a(t, aC);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(aC, bX, 0, CX);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) aP[mi] = aC[mi];
+        // tile t+1 landed (the newest tile may stay in flight), this wave's LDS reads of tile t are done
+        if (t + 2 < T) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        st = st == 2 ? 0 : st + 1;
+      }
+      mma(aP, bY, NH, CY);
+      __syncthreads();
+      return;
+    }
     dma_tile(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -305,7 +350,7 @@ gemm_nt_kernel(const Launch L_byval) {
   // touches one contiguous run of a row in every epilogue stream.  Row reductions (attention head scores, the GSL
   // scorer's projection) read the finished rows back from LDS, one wave per row, in a fixed order (deterministic).
   if (L.dbg & 1) {
-    if (acc[0][0][0] == 12345.678f && acc[1][NI - 1][3] == 1.f) P.C[0] = 0.f;
+    if (acc[0][0][0] == 12345.678f && acc[MI - 1][NI - 1][3] == 1.f) P.C[0] = 0.f;
     return;
   }
   const int epi = P.epi;
@@ -488,6 +533,10 @@ gemm_nt_kernel(const Launch L_byval) {
   };
   epilogue_pass(std::integral_constant<int, 0>{});
   epilogue_pass(std::integral_constant<int, 1>{});
+  if constexpr (MI == 4) {
+    epilogue_pass(std::integral_constant<int, 2>{});
+    epilogue_pass(std::integral_constant<int, 3>{});
+  }
 #endif
 }
 

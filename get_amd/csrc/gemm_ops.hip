@@ -54,7 +54,7 @@ static bool wants_dropout(const Launch& L) {
 static long long g_path_counts[3] = {0, 0, 0};
 static int g_gemm_mode = 0;       // 0: fp32 MFMA everywhere (default); 1: bf16 MFMA in the big-tile NT/NN GEMMs (gh_set_gemm_mode)
 
-template <int WM, int WN, int NI>
+template <int WM, int WN, int NI, int MI = 2>
 static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
   const bool fast = fast_ok(L, tn);
   {
@@ -75,7 +75,7 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
       for (int j = 0; j < L.p[i].nseg; ++j) {
         int rows = L.p[i].M;       // segment 0 is skipped by the row tiles at or beyond seg0_rows: do not count it
         if (j == 0 && !tn && L.p[i].nseg > 1 && L.p[i].seg0_rows > 0) {
-          const int bm = 32 * WM, cut = ((L.p[i].seg0_rows + bm - 1) / bm) * bm;
+          const int bm = 16 * MI * WM, cut = ((L.p[i].seg0_rows + bm - 1) / bm) * bm;
           if (cut < rows) rows = cut;
         }
         flops += 2.0 * rows * L.p[i].N * (double)L.p[i].seg[j].K;
@@ -95,7 +95,16 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
       if (tn) hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 2, 10>), dim3(grid), dim3(256), 0, s, L);
       else hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 10, 2, 2>), dim3(grid), dim3(256), 0, s, L);
       launched = true;
+    } else if constexpr (WM == 2 && WN == 2 && NI == 8 && MI == 4) {      // 128 x 256 tile (NT only)
+      if (tn) return hipErrorInvalidValue;
+      constexpr int kLds = 3 * (128 + 256) * 64;          // three K-loop stages (the epilogue staging fits inside)
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 2, 8, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); attr = true; }
+      hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 8, 4, 2>), dim3(grid), dim3(256), kLds, s, L);
+      launched = true;
     } else return hipErrorInvalidValue;
+  } else if (MI == 4) {
+    return hipErrorInvalidValue;          // the 128 x 256 tile exists for the bf16 storage pipeline only
   } else if (fast && !tn) {
     // gh_set_gemm_mode(1): bf16 operand rounding in the activation-sized (64x320 tile) launches only
     if (g_gemm_mode == 1 && WM == 2 && WN == 2 && NI == 10) {
@@ -305,7 +314,9 @@ struct Batch {
 
   float* g_ws = nullptr;
   size_t g_ws_bytes = 0;
-  Batch(bool tn_, int rows_hint, hipStream_t s_) : tn(tn_), s(s_) {
+  bool wide = false;      // 128 x 256 bf16 tile (launch_cfg<2, 2, 8, 4>)
+  // wide_bf16: every problem of this batch is a bf16-storage NT problem whose widths are multiples of 256 (h = 768)
+  Batch(bool tn_, int rows_hint, hipStream_t s_, bool wide_bf16 = false) : tn(tn_), s(s_) {
     const Workspace w = workspace_for(s_);
     g_ws = w.p; g_ws_bytes = w.bytes;
     static int force_small = -1;
@@ -313,6 +324,9 @@ struct Batch {
     big = tn_ || (rows_hint >= 8192 && !force_small);      // 64x320 tile (2x2 waves) for the activation-sized GEMMs, 32x320 (1x4) for few-row ones
     bm = big ? 64 : 32;
     bn = 320;
+    static int no_wide = -1;
+    if (no_wide < 0) { const char* e = getenv("GH_BF16_TILE"); no_wide = (e && atoi(e) == 320) ? 1 : 0; }
+    if (wide_bf16 && big && !tn_ && !no_wide) { wide = true; bm = 128; bn = 256; }
     reset();
   }
   void reset() {
@@ -438,6 +452,7 @@ struct Batch {
         return launch_cfg<1, 4, 5>(L, tn, s);
       }
     }
+    if (wide) return launch_cfg<2, 2, 8, 4>(L, tn, s);
     return big ? launch_cfg<2, 2, 10>(L, tn, s) : launch_cfg<1, 4, 5>(L, tn, s);
   }
 
@@ -449,7 +464,7 @@ struct Batch {
     int tmax = 0;          // K tiles over the concatenated segments (every problem of a launch is split alike)
     for (int i = 0; i < L.nprob; ++i) {
       const Problem& q = L.p[i];
-      if (q.epi == EPI_ATOMIC || q.drop_mode != 0 || (q.epi == EPI_TANH_H && q.w2) || q.seg0_rows > 0) return false;
+      if (q.epi == EPI_ATOMIC || q.drop_mode != 0 || (q.epi == EPI_TANH_H && q.w2) || q.seg0_rows > 0 || q.elt) return false;   // (fp32 problems only)
       int t = 0;
       for (int j = 0; j < q.nseg; ++j) t += (q.seg[j].K + 15) / 16;
       if (i > 0 && t != tmax) return false;
@@ -546,8 +561,9 @@ static int cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float
   GH_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ggnn_cell_fwd: dropout p=%f not in [0,1)", drop_p);
   GH_REQUIRE((score_w == nullptr) == (score_x == nullptr), "ggnn_cell_fwd: score_w and score_x come together");
   GH_REQUIRE(score_drop_p >= 0.f && score_drop_p < 1.f, "ggnn_cell_fwd: scorer dropout p=%f not in [0,1)", score_drop_p);
+  const bool wide = bf && h % 256 == 0;      // 128 x 256 bf16 tiles cover the width exactly (h = 768)
   {  // xp = dropout(x) Wp^T   (wrapper.py:189-191); embedding rows gathered by the loader, the dropout mask applied to the fragments
-    Batch b(false, M, s);
+    Batch b(false, M, s, wide);
     Problem p = gemm_problem(M, h, EPI_STORE, xp, h, x, din, w_p, din, din, ids, bf);
     p.io = bf ? 1 : 0;
     set_dropout(p, 1, din, drop_p, drop_seed);
@@ -560,7 +576,7 @@ static int cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float
   if (m_rows > m_real)   // padding rows of the node-compact layout have no neighbours
     GH_CHECK_HIP(hipMemsetAsync((char*)a + (size_t)m_real * h * (bf ? 2 : 4), 0, (size_t)(bf ? 2 : 4) * (size_t)(m_rows - m_real) * h, s));
   {  // z, r gates (:194-200): [a | xp] . [W?0 | W?1]^T as two K segments
-    Batch b(false, M, s);
+    Batch b(false, M, s, wide);
     Problem pz = gemm_problem(M, h, EPI_SIGMOID_Z, z, h, a, h, w_z0, h, h, nullptr, bf);
     pz.io = bf ? 1 : 0;
     add_seg(pz, xp, h, w_z1, h, h);
@@ -575,7 +591,7 @@ static int cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float
     GH_CHECK_HIP(b.err);
   }
   {  // h gate and the convex update (:202-206); optionally the GSL word scorer's projection of the result (:167)
-    Batch b(false, M, s);
+    Batch b(false, M, s, wide && !score_w);
     Problem ph = gemm_problem(M, h, EPI_TANH_H, hh, h, a, h, w_h0, h, h, nullptr, bf);
     ph.io = bf ? 15 : 0; ph.c32 = bf ? out32 : nullptr;
     add_seg(ph, rx, h, w_h1, h, h);
@@ -650,8 +666,9 @@ static int cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const 
   if (M == 0) return 0;
   // out = h z + xp (1-z):  dhp = g z (1-h^2), dzp = g (h-xp) z (1-z), dxp = g (1-z)
   if (int e = launch_gate_bwd_pre(g, z, hh, xp, dhp, dzp, dxp, (size_t)M * h, s, bf)) return e;
+  const bool wide = bf && h % 256 == 0;
   {  // hp = a Wh0^T + (r xp) Wh1^T:  da = dhp Wh0 ; d(r xp) = dhp Wh1 -> drp, dxp += .
-    Batch b(false, M, s);
+    Batch b(false, M, s, wide);
     Problem p0 = gemm_problem(M, h, EPI_STORE, da, h, dhp, h, wt_h0, h, h, nullptr, bf);
     Problem p1 = gemm_problem(M, h, EPI_BWD_DRX, drp, h, dhp, h, wt_h1, h, h, nullptr, bf);
     p1.out1 = dxp; p1.in0 = xp; p1.in1 = rr;
@@ -661,7 +678,7 @@ static int cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const 
     GH_CHECK_HIP(b.err);
   }
   {  // da += dzp Wz0 + drp Wr0 ; dxp += dzp Wz1 + drp Wr1
-    Batch b(false, M, s);
+    Batch b(false, M, s, wide);
     Problem p0 = gemm_problem(M, h, EPI_STORE, da, h, dzp, h, wt_z0, h, h, nullptr, bf);
     add_seg(p0, drp, h, wt_r0, h, h);
     p0.accumulate = 1;
@@ -675,7 +692,7 @@ static int cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const 
   }
   if (int e = launch_spmm(bits, dinv, vals, keep, goff, m_real, da, dxp, n, r, h, 1, 1, s, bf)) return e;   // dxp += A_hat^T da
   if (dx) {  // dx = (dxp Wp) . mask/(1-p)
-    Batch b(false, M, s);
+    Batch b(false, M, s, wide && din % 256 == 0);
     Problem p = gemm_problem(M, din, EPI_STORE, dx, din, dxp, h, wt_p, h, h, nullptr, bf);      // dx itself is fp32
     set_dropout(p, 3, din, drop_p, drop_seed);
     b.add(p);
