@@ -412,7 +412,10 @@ gemm_nt_kernel(const Launch L_byval) {
     // pointers may alias as far as the compiler knows, so a plain loop would serialise 11 memory round trips per pass.
     auto pass = [&](auto EPI) __attribute__((always_inline)) {
       constexpr int E = decltype(EPI)::value;
-      constexpr int CH = 4;
+#ifndef GH_EPI_CH
+#define GH_EPI_CH 4
+#endif
+      constexpr int CH = GH_EPI_CH;
 #pragma unroll
       for (int it0 = 0; it0 < NIT; it0 += CH) {
         float4 xa[CH], xb[CH], xc[CH];

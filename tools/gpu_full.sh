@@ -11,7 +11,7 @@ python - <<P
 import json
 for f in ("bench_full_$TAG", "bench_2rank_gloo_$TAG", "bench_2rank_gloo_gb64_$TAG"):
     try:
-        d = json.load(open("$O/" + f + ".json"))
+        d = json.loads([l for l in open("$O/" + f + ".json").read().splitlines() if l.startswith("{")][-1])   # (gloo prints its rank banner on stdout)
     except Exception as e:
         print(f, "FAILED", e); continue
     print(f, "pairs/s %.0f ms/step %.3f n_gpus %d scaling %s claims/s %.0f" % (d["value"], d["ms_per_step"], d["n_gpus"], d["scaling"], d["claims_per_s"]))
