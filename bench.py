@@ -475,6 +475,10 @@ def main():
                 if name.startswith("gemm"):
                     pk = PEAK_BF16_MFMA_TFLOPS if (args.gemm_mode == "bf16" and name == "gemm_big") else PEAK_F32_MFMA_TFLOPS
                     entry.update(bound="mfma", achieved_tflops=rate / 1e12, frac=rate / 1e12 / pk)
+                elif name == "few_row_streams":
+                    # claim-side aggregation / gate kernels and the evidence-level attention kernels: a few MB per launch, bound
+                    # by launch latency, kept apart so that they do not dilute the activation-sized launches' rates
+                    entry.update(bound="latency", achieved_gbps=rate / 1e9, frac=rate / 1e9 / PEAK_HBM_GBPS)
                 else:
                     entry.update(bound="hbm", achieved_gbps=rate / 1e9, frac=rate / 1e9 / PEAK_HBM_GBPS)
                 kernels[name] = entry

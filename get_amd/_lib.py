@@ -61,7 +61,8 @@ SIGNATURES = {
 }
 
 PROFILE_ROWS = ["gemm_big", "gemm_big_tn", "gemm_small", "gemm_small_tn", "spmm", "scorer_gsl",
-                "graph_build", "att_softmax_fwd", "att_softmax_bwd", "att_dpre", "gate_bwd_pre", "colsum", "adam"]
+                "graph_build", "att_softmax_fwd", "att_softmax_bwd", "att_dpre", "gate_bwd_pre", "colsum", "adam",
+                "few_row_streams"]
 
 
 def profile_enable(on: bool, only=None):

@@ -36,8 +36,12 @@ inline int words_for(int r) { return (r + 63) / 64; }
 enum ProfTag : int {
   PROF_GEMM_BIG = 0, PROF_GEMM_BIG_TN, PROF_GEMM_SMALL, PROF_GEMM_SMALL_TN,
   PROF_SPMM, PROF_SCORER_GSL, PROF_GRAPH_BUILD, PROF_ATT_SOFTMAX_FWD, PROF_ATT_SOFTMAX_BWD, PROF_ATT_DPRE,
-  PROF_GATE_BWD_PRE, PROF_COLSUM, PROF_ADAM, PROF_NTAGS
+  PROF_GATE_BWD_PRE, PROF_COLSUM, PROF_ADAM,
+  PROF_FEW_ROWS,      // claim-side / evidence-level launches of the streaming kernels (a few MB each: launch-latency-bound)
+  PROF_NTAGS
 };
+// streaming-kernel launches over fewer than this many graphs / pairs are booked under PROF_FEW_ROWS
+constexpr int PROF_FEW_GROUPS = 256;
 bool prof_enabled();
 void prof_begin(hipStream_t s, int tag);   // events are recorded only for tags selected by gh_profile_select
 void prof_end(int tag, double work, hipStream_t s);

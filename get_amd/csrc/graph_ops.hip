@@ -601,7 +601,8 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   // ~8K waves in flight their sliding-window working set (~49 MB) thrashes the 32 MB of L2 (hit rate 32 %).
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("GH_SPMM_VARIANT"); variant = e ? atoi(e) : 4; if (variant > 5) variant = 4; }
-  prof_begin(s, PROF_SPMM);
+  const int ptag = n < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_SPMM;
+  prof_begin(s, ptag);
   if (v4 && variant >= 3 && r <= 256) {
     // edge-list kernel; variant 3: one column per thread, 4 (default): two, 5: three.  LDS pitch = slab columns.
     const int cap = 11 * r;                        // edges per graph the list holds (a window-5 word graph has <= 9 R)
@@ -638,7 +639,7 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
     if (!attr1 && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)spmm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
     hipLaunchKernelGGL(spmm_kernel<1>, grid, dim3(256), lds, s, bits, dinv, vals, keep, goff, x, y, r, h, slab, transpose, accumulate);
   }
-  prof_end(PROF_SPMM, alg_bytes, s);
+  prof_end(ptag, alg_bytes, s);
   GH_LAUNCH_CHECK();
   return 0;
 }

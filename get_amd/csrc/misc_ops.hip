@@ -166,10 +166,11 @@ int launch_gate_bwd_pre(const float* g, const float* z, const float* hh, const f
   if (count % 4 == 0 && (al & 15) == 0) {
     const size_t n4 = count / 4;
     const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-    prof_begin(s, PROF_GATE_BWD_PRE);
+    const int ptag = count < ((size_t)1 << 21) ? PROF_FEW_ROWS : PROF_GATE_BWD_PRE;      // (claim-side cells: 960 x 300)
+    prof_begin(s, ptag);
     hipLaunchKernelGGL(gate_bwd_pre_kernel, dim3(grid), dim3(256), 0, s, (const float4*)g, (const float4*)z,
                        (const float4*)hh, (const float4*)xp, (float4*)dhp, (float4*)dzp, (float4*)dxp, n4);
-    prof_end(PROF_GATE_BWD_PRE, 7.0 * 4.0 * (double)count, s);
+    prof_end(ptag, 7.0 * 4.0 * (double)count, s);
   } else {
     const int grid = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
     hipLaunchKernelGGL(gate_bwd_pre_scalar_kernel, dim3(grid), dim3(256), 0, s, g, z, hh, xp, dhp, dzp, dxp, count);
@@ -455,17 +456,32 @@ int launch_att_softmax_fwd(const float* e, const float* mask, const float* right
   const int nthr = 256;      // (8 waves per pair measured no faster: the kernel is not parallelism-bound)
   const size_t lds = ((size_t)l * heads + (nthr / 64) * 64 * 4 * heads) * 4;
   GH_REQUIRE(lds <= 64 * 1024, "att_softmax_fwd: sequence %d x heads %d too large", l, heads);
-  prof_begin(s, PROF_ATT_SOFTMAX_FWD);
+  prof_begin(s, b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_SOFTMAX_FWD);
   hipLaunchKernelGGL(att_softmax_fwd_kernel, dim3(b, (dr / 4 + 63) / 64), dim3(nthr), lds, s, e, mask, right, goff, l, dr,
                      heads, weights, attended);
   const double rows = goff ? (double)m_real : (double)b * l;
-  prof_end(PROF_ATT_SOFTMAX_FWD, 4.0 * (rows * dr + 2.0 * rows * heads + rows + (double)b * dr * heads), s);
+  prof_end(b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_SOFTMAX_FWD, 4.0 * (rows * dr + 2.0 * rows * heads + rows + (double)b * dr * heads), s);
   GH_LAUNCH_CHECK();
   return 0;
 }
 
+// Sum over the 64 lanes of a wave on the VALU's DPP path (row shifts + row broadcasts, gfx9 wave64): six VALU
+// instructions, no LDS crossbar traffic -- __shfl_xor compiles to ds_bpermute_b32 (an LDS instruction plus a wait per
+// step), which made the five head reductions per row the largest cost of the word-level softmax backward.  The total
+// lands in lane 63 (returned to every lane through readlane).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));   // row_shr:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xe, true));   // row_shr:4, banks 1-3
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xc, true));   // row_shr:8, banks 2-3
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true));   // row_bcast:15 -> rows 1, 3
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, true));   // row_bcast:31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // backward of the softmax/reduce: dw[l][c] = sum_d right[l][d] g_att[d][c] (+ g_w) ; de = w (dw - sum_l w dw) ;
 // dright[l][d] = sum_c w[l][c] g_att[d][c]  (first contribution; the GEMM adds dpre W1r on top)
+template <int CT>     // compile-time bound on the number of heads
 __global__ void __launch_bounds__(512)
 att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict__ weights,
                        const float* __restrict__ g_att, const float* __restrict__ g_w,
@@ -480,51 +496,125 @@ att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict_
   const int row0 = goff ? goff[b] : b * Lmax;
   const int L = goff ? goff[b + 1] - row0 : Lmax;
   const int NT = blockDim.x, NWV = NT >> 6;
+  const int D4 = Dr / 4;
+  constexpr int NCH = 2;                         // float4 columns per lane on the register path (Dr <= 512)
+  const bool reg_path = D4 <= 64 * NCH;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  int dcl[NCH];                                  // clamped column of this lane (loads stay unconditional)
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) dcl[h] = min(lane + 64 * h, D4 - 1);
+  // two rows per wave and trip; the first trip's rows are requested before g_att / the weights are staged
+  float4 na[NCH], nb[NCH];
+  if (reg_path && L > 0) {
+    const float4* ra_ = reinterpret_cast<const float4*>(right + ((size_t)row0 + min(wave, L - 1)) * Dr);
+    const float4* rb_ = reinterpret_cast<const float4*>(right + ((size_t)row0 + min(wave + NWV, L - 1)) * Dr);
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) { na[h] = ra_[dcl[h]]; nb[h] = rb_[dcl[h]]; }
+  }
   for (int i = tid; i < Dr * C; i += NT) ga[(i % C) * Dr + i / C] = g_att[(size_t)b * Dr * C + i];
   for (int i = tid; i < L * C; i += NT) ws[i] = weights[(size_t)row0 * C + i];
   __syncthreads();
-  const int D4 = Dr / 4;
-  // two rows per wave in flight: both rows' loads are issued before either is consumed (a wave walks ~16 rows
-  // one after the other, so the kernel is bound by the memory latency per row, not by bandwidth)
-  for (int l = wave; l < L; l += 2 * NWV) {
-    const int lb = l + NWV;
-    const bool has_b = lb < L;
-    const int lbc = has_b ? lb : l;
-    float pa[8], pb[8], wa[8], wb[8];
+  if (reg_path) {
+    // word level (Dr = H): this lane's g_att columns are loop invariants ([CT][NCH] float4 out of LDS once), the row
+    // dot products are reduced on the DPP path -- per row no LDS instruction is left but the C weight broadcasts
+    float4 gq[CT][NCH];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      pa[c] = 0.f; pb[c] = 0.f;
-      wa[c] = (c < C) ? ws[l * C + c] : 0.f;
-      wb[c] = (c < C) ? ws[lbc * C + c] : 0.f;
-    }
-    const float4* ra_ = reinterpret_cast<const float4*>(right + ((size_t)row0 + l) * Dr);
-    const float4* rb_ = reinterpret_cast<const float4*>(right + ((size_t)row0 + lbc) * Dr);
-    float4* da_ = reinterpret_cast<float4*>(dright + ((size_t)row0 + l) * Dr);
-    float4* db_ = reinterpret_cast<float4*>(dright + ((size_t)row0 + lbc) * Dr);
-    for (int d4 = lane; d4 < D4; d4 += 64) {
-      const float4 rva = ra_[d4];
-      const float4 rvb = rb_[d4];
-      float4 aa = make_float4(0.f, 0.f, 0.f, 0.f), ab = aa;
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
-        if (c < C) {
-          const float4 gq = reinterpret_cast<const float4*>(ga + (size_t)c * Dr)[d4];
-          aa.x += wa[c] * gq.x; aa.y += wa[c] * gq.y; aa.z += wa[c] * gq.z; aa.w += wa[c] * gq.w;
-          ab.x += wb[c] * gq.x; ab.y += wb[c] * gq.y; ab.z += wb[c] * gq.z; ab.w += wb[c] * gq.w;
-          pa[c] += rva.x * gq.x + rva.y * gq.y + rva.z * gq.z + rva.w * gq.w;
-          pb[c] += rvb.x * gq.x + rvb.y * gq.y + rvb.z * gq.z + rvb.w * gq.w;
-        }
-      da_[d4] = aa;
-      if (has_b) db_[d4] = ab;
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float va = pa[c], vb = pb[c];
-      for (int o = 32; o > 0; o >>= 1) { va += __shfl_xor(va, o); vb += __shfl_xor(vb, o); }
-      if (lane == 0 && c < C) {
-        dw[l * C + c] = va + (g_w ? g_w[((size_t)row0 + l) * C + c] : 0.f);
-        if (has_b) dw[lb * C + c] = vb + (g_w ? g_w[((size_t)row0 + lb) * C + c] : 0.f);
+      for (int h = 0; h < NCH; ++h) {
+        gq[c][h] = reinterpret_cast<const float4*>(ga + (size_t)min(c, C - 1) * Dr)[dcl[h]];
+        if (c >= C || lane + 64 * h >= D4) gq[c][h] = zero4;          // clamped duplicates contribute nothing
       }
+    for (int l = wave; l < L; l += 2 * NWV) {
+      const int lb = l + NWV;
+      const bool has_b = lb < L;
+      float4 ca[NCH], cb[NCH];
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) { ca[h] = na[h]; cb[h] = nb[h]; }
+      if (l + 2 * NWV < L) {                     // next trip's rows in flight while this trip is consumed
+        const float4* ra_ = reinterpret_cast<const float4*>(right + ((size_t)row0 + l + 2 * NWV) * Dr);
+        const float4* rb_ = reinterpret_cast<const float4*>(right + ((size_t)row0 + min(l + 3 * NWV, L - 1)) * Dr);
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) { na[h] = ra_[dcl[h]]; nb[h] = rb_[dcl[h]]; }
+      }
+      float4 aa[NCH], ab[NCH];
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) { aa[h] = zero4; ab[h] = zero4; }
+      float pa[CT], pb[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        pa[c] = 0.f; pb[c] = 0.f;
+        if (c < C) {
+          const float wa = ws[l * C + c], wb = ws[(has_b ? lb : l) * C + c];
+#pragma unroll
+          for (int h = 0; h < NCH; ++h) {
+            const float4 q = gq[c][h];
+            aa[h].x += wa * q.x; aa[h].y += wa * q.y; aa[h].z += wa * q.z; aa[h].w += wa * q.w;
+            ab[h].x += wb * q.x; ab[h].y += wb * q.y; ab[h].z += wb * q.z; ab[h].w += wb * q.w;
+            pa[c] += ca[h].x * q.x + ca[h].y * q.y + ca[h].z * q.z + ca[h].w * q.w;
+            pb[c] += cb[h].x * q.x + cb[h].y * q.y + cb[h].z * q.z + cb[h].w * q.w;
+          }
+        }
+      }
+      float4* da_ = reinterpret_cast<float4*>(dright + ((size_t)row0 + l) * Dr);
+      float4* db_ = reinterpret_cast<float4*>(dright + ((size_t)row0 + (has_b ? lb : l)) * Dr);
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        const int d4 = lane + 64 * h;
+        if (d4 < D4) { da_[d4] = aa[h]; if (has_b) db_[d4] = ab[h]; }
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        if (c < C) {
+          const float va = wave_sum_dpp(pa[c]), vb = wave_sum_dpp(pb[c]);
+          if (lane == 0) {
+            dw[l * C + c] = va + (g_w ? g_w[((size_t)row0 + l) * C + c] : 0.f);
+            if (has_b) dw[lb * C + c] = vb + (g_w ? g_w[((size_t)row0 + lb) * C + c] : 0.f);
+          }
+        }
+    }
+  } else {
+    // wide rows (evidence level: Dr = H * heads + source width): two rows per wave in flight, columns walked in a loop
+    for (int l = wave; l < L; l += 2 * NWV) {
+      const int lb = l + NWV;
+      const bool has_b = lb < L;
+      const int lbc = has_b ? lb : l;
+      float pa[CT], pb[CT], wa[CT], wb[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        pa[c] = 0.f; pb[c] = 0.f;
+        wa[c] = (c < C) ? ws[l * C + c] : 0.f;
+        wb[c] = (c < C) ? ws[lbc * C + c] : 0.f;
+      }
+      const float4* ra_ = reinterpret_cast<const float4*>(right + ((size_t)row0 + l) * Dr);
+      const float4* rb_ = reinterpret_cast<const float4*>(right + ((size_t)row0 + lbc) * Dr);
+      float4* da_ = reinterpret_cast<float4*>(dright + ((size_t)row0 + l) * Dr);
+      float4* db_ = reinterpret_cast<float4*>(dright + ((size_t)row0 + lbc) * Dr);
+      for (int d4 = lane; d4 < D4; d4 += 64) {
+        const float4 rva = ra_[d4];
+        const float4 rvb = rb_[d4];
+        float4 aa = zero4, ab = zero4;
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+          if (c < C) {
+            const float4 gq = reinterpret_cast<const float4*>(ga + (size_t)c * Dr)[d4];
+            aa.x += wa[c] * gq.x; aa.y += wa[c] * gq.y; aa.z += wa[c] * gq.z; aa.w += wa[c] * gq.w;
+            ab.x += wb[c] * gq.x; ab.y += wb[c] * gq.y; ab.z += wb[c] * gq.z; ab.w += wb[c] * gq.w;
+            pa[c] += rva.x * gq.x + rva.y * gq.y + rva.z * gq.z + rva.w * gq.w;
+            pb[c] += rvb.x * gq.x + rvb.y * gq.y + rvb.z * gq.z + rvb.w * gq.w;
+          }
+        da_[d4] = aa;
+        if (has_b) db_[d4] = ab;
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        if (c < C) {
+          const float va = wave_sum_dpp(pa[c]), vb = wave_sum_dpp(pb[c]);
+          if (lane == 0) {
+            dw[l * C + c] = va + (g_w ? g_w[((size_t)row0 + l) * C + c] : 0.f);
+            if (has_b) dw[lb * C + c] = vb + (g_w ? g_w[((size_t)row0 + lb) * C + c] : 0.f);
+          }
+        }
     }
   }
   __syncthreads();
@@ -544,14 +634,19 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
              "att_softmax_bwd: right rows must be float4-shaped (dr=%d)", dr);
   const size_t lds = ((size_t)dr * heads + 2 * (size_t)l * heads) * 4;
   GH_REQUIRE(lds <= 160 * 1024, "att_softmax_bwd: %zu B of LDS needed", lds);
-  static bool attr = false;
-  if (!attr && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)att_softmax_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  prof_begin(s, PROF_ATT_SOFTMAX_BWD);
+  GH_REQUIRE(heads >= 1 && heads <= 8, "att_softmax_bwd: %d heads (1..8 supported)", heads);
+  const void* fn = heads <= 2 ? (const void*)att_softmax_bwd_kernel<2> : heads <= 5 ? (const void*)att_softmax_bwd_kernel<5>
+                                                                                   : (const void*)att_softmax_bwd_kernel<8>;
+  static bool attr[3] = {false, false, false};
+  const int ai = heads <= 2 ? 0 : heads <= 5 ? 1 : 2;
+  if (!attr[ai] && lds > 64 * 1024) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[ai] = true; }
+  prof_begin(s, b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_SOFTMAX_BWD);
   // few pairs (evidence level: one workgroup per claim): eight waves share the rows of a pair
-  hipLaunchKernelGGL(att_softmax_bwd_kernel, dim3(b), dim3(b < 512 ? 512 : 256), lds, s, right, weights, g_att, g_w, goff, l, dr,
-                     heads, de, dright);
+  void* args[] = {(void*)&right, (void*)&weights, (void*)&g_att, (void*)&g_w, (void*)&goff, (void*)&l, (void*)&dr, (void*)&heads,
+                  (void*)&de, (void*)&dright};
+  (void)hipLaunchKernel(fn, dim3(b), dim3(b < 512 ? 512 : 256), args, lds, s);
   const double rows = goff ? (double)m_real : (double)b * l;
-  prof_end(PROF_ATT_SOFTMAX_BWD, 4.0 * (2.0 * rows * dr + 3.0 * rows * heads + (double)b * dr * heads), s);
+  prof_end(b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_SOFTMAX_BWD, 4.0 * (2.0 * rows * dr + 3.0 * rows * heads + (double)b * dr * heads), s);
   GH_LAUNCH_CHECK();
   return 0;
 }
@@ -658,10 +753,10 @@ int launch_att_dpre(const float* de, const float* w2, const float* t, const int3
   const int RL = (256 / S4) > 0 ? (256 / S4) : 1;
   const int threads = ((S4 * RL + 63) / 64) * 64;
   const size_t lds = (size_t)RL * (1 + heads) * S4 * 16 + (size_t)l * heads * 4;
-  prof_begin(s, PROF_ATT_DPRE);
+  prof_begin(s, b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_DPRE);
   hipLaunchKernelGGL(att_dpre_kernel, dim3(b, nsl), dim3(threads), lds, s, de, w2, t, goff, l, ha, heads, RL, S4, dpre, du, dw2_part);
   const double rows = goff ? (double)m_real : (double)b * l;
-  prof_end(PROF_ATT_DPRE, 4.0 * (2.0 * rows * ha + rows * heads + (double)b * ha), s);
+  prof_end(b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_DPRE, 4.0 * (2.0 * rows * ha + rows * heads + (double)b * ha), s);
   GH_LAUNCH_CHECK();
   return 0;
 }
