@@ -473,7 +473,7 @@ def main():
                 entry = {"ms_per_step": per_step, "launches_per_step": r["launches"] / PROFILE_EXTRA_STEPS,
                          "avg_launch_ms": r["ms"] / r["launches"]}
                 if name.startswith("gemm"):
-                    pk = PEAK_BF16_MFMA_TFLOPS if (args.gemm_mode == "bf16" and name == "gemm_big") else PEAK_F32_MFMA_TFLOPS
+                    pk = PEAK_BF16_MFMA_TFLOPS if (args.gemm_mode == "bf16" and name in ("gemm_big", "gemm_big_tn")) else PEAK_F32_MFMA_TFLOPS
                     entry.update(bound="mfma", achieved_tflops=rate / 1e12, frac=rate / 1e12 / pk)
                 elif name == "few_row_streams":
                     # claim-side aggregation / gate kernels and the evidence-level attention kernels: a few MB per launch, bound

@@ -387,8 +387,9 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
                  float* __restrict__ y, int R, int H, int slab, int cap, int transpose, int accumulate) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   const int W = (R + 63) / 64;
-  float4* xs = reinterpret_cast<float4*>(dsm);                                                // [R][slab]
-  uint2* ent = reinterpret_cast<uint2*>(xs + (size_t)R * slab);                               // [cap] {j, w}
+  float4* xs = reinterpret_cast<float4*>(dsm);                                                // [R][slab] fp32 rows ...
+  const uint2* xs16 = reinterpret_cast<const uint2*>(dsm);                                    // ... or (BF) bf16 rows, 8 B per float4 column
+  uint2* ent = reinterpret_cast<uint2*>(dsm + (size_t)R * slab * (BF ? 8 : 16));              // [cap] {j, w}
   unsigned long long* rb = reinterpret_cast<unsigned long long*>(ent);                        // [R][W] refined bit rows (fallback only; cap >= R*W)
   int* st = reinterpret_cast<int*>(ent + cap);                                                // [R + 1] row starts
   float* dv = reinterpret_cast<float*>(st + R + 1);                                           // [R]
@@ -406,9 +407,6 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
   // ---- stage.  Issue order = completion order on the vector-memory counter: the few small loads of this thread's row
   // (bit words, keep words, dinv) go first, the slab's 16-byte loads after them, so the list is built from the former
   // while the latter are still in flight.  sched_barrier pins that order.
-  constexpr int SL = 12;
-  const int total = NR * ncol;
-  const unsigned mg_ncol = magic_of(ncol);
   const int trow = min(tid, R - 1);
   unsigned long long mrow[4] = {0ull, 0ull, 0ull, 0ull}, kwd[4] = {~0ull, ~0ull, ~0ull, ~0ull};
 #pragma unroll
@@ -419,24 +417,21 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
     }
   const float dvv = vals ? 0.f : dinv[(size_t)g * R + trow];
   __builtin_amdgcn_sched_barrier(0);
-  float4 tmp[BF ? SL : 1];
-  if (BF) {
-#pragma unroll
-    for (int k = 0; k < SL; ++k) {
-      const int it = min(tid + k * 256, total - 1);
-      const int i = fdiv(it, mg_ncol), c = it - i * ncol;
-      tmp[BF ? k : 0] = bf4_to_f4(reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x) + ((size_t)row0 + i) * H)[c0 + c]);
-    }
-  } else {
-    // fp32: LDS-DMA (buffer_load_dwordx4 ... lds): the LDS image is linear in it = i * ncol + c, so a wave's 64 lanes
-    // land in 1 KB of consecutive LDS; no staging registers, no ds_write
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)row0 * H), 0, 0x7fffffff, 0x00020000);
-    for (int base = 0; base < total; base += 256) {
+  {
+    // LDS-DMA (buffer_load_dwordx4 ... lds): the LDS image is linear in (row, column), so a wave's 64 lanes land in 1 KB of
+    // consecutive LDS; no staging registers, no ds_write.  fp32: one 16-byte chunk = one float4 column.  BF: the image
+    // stays bf16 (half the LDS, twice the slab), one chunk = two columns (the launcher keeps slabs even).
+    const int cpr = BF ? ncol / 2 : ncol;                 // chunks per row
+    const int chunks = NR * cpr;
+    const unsigned mg_cpr = magic_of(cpr);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const char*>(x) + (size_t)row0 * H * (BF ? 2 : 4)), 0, 0x7fffffff, 0x00020000);
+    for (int base = 0; base < chunks; base += 256) {
       const int it = base + tid;
-      if (it < total) {
-        const int i = fdiv(it, mg_ncol), c = it - i * ncol;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + base + wave * 64), 16,
-                                                 (i * H + (c0 + c) * 4) * 4, 0, 0, 0);
+      if (it < chunks) {
+        const int i = fdiv(it, mg_cpr), c = it - i * cpr;
+        const int off = BF ? (i * H + (c0 + 2 * c) * 4) * 2 : (i * H + (c0 + c) * 4) * 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + base + wave * 64), 16, off, 0, 0, 0);
       }
     }
   }
@@ -498,16 +493,7 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
       for (int w = 0; w < 4; ++w) if (w < W) rb[tid * W + w] = mrow[w];
     }
   }
-  if (BF) {
-#pragma unroll
-    for (int k = 0; k < SL; ++k) xs[min(tid + k * 256, total - 1)] = tmp[BF ? k : 0];   // LDS pitch == ncol: linear in `it`
-    for (int it = tid + SL * 256; it < total; it += 256) {
-      const int i = fdiv(it, mg_ncol), c = it - i * ncol;
-      xs[it] = bf4_to_f4(reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x) + ((size_t)row0 + i) * H)[c0 + c]);
-    }
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the slab has landed (LDS-DMA is tracked by vmcnt)
   __syncthreads();
   // ---- aggregate: thread = (row i, column group q); columns q, q + TPR, ...
   const int TPR = (ncol + CPT - 1) / CPT;
@@ -530,7 +516,10 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
         const float wb = two ? __builtin_bit_cast(float, eb.y) : 0.f;
         float4 xa[CPT], xb[CPT];
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) { xa[k] = xs[ea.x * ncol + cc[k]]; xb[k] = xs[eb.x * ncol + cc[k]]; }
+        for (int k = 0; k < CPT; ++k) {
+          if (BF) { xa[k] = bf4_to_f4(xs16[ea.x * ncol + cc[k]]); xb[k] = bf4_to_f4(xs16[eb.x * ncol + cc[k]]); }
+          else { xa[k] = xs[ea.x * ncol + cc[k]]; xb[k] = xs[eb.x * ncol + cc[k]]; }
+        }
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
           acc[k].x += wa * xa[k].x; acc[k].y += wa * xa[k].y; acc[k].z += wa * xa[k].z; acc[k].w += wa * xa[k].w;
@@ -547,7 +536,7 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
           const float wt = vg ? (transpose ? vg[(size_t)j * R + i] : vg[(size_t)i * R + j]) : di * dv[j];
 #pragma unroll
           for (int k = 0; k < CPT; ++k) {
-            const float4 xv = xs[j * ncol + cc[k]];
+            const float4 xv = BF ? bf4_to_f4(xs16[j * ncol + cc[k]]) : xs[j * ncol + cc[k]];
             acc[k].x += wt * xv.x; acc[k].y += wt * xv.y; acc[k].z += wt * xv.z; acc[k].w += wt * xv.w;
           }
         }
@@ -603,10 +592,20 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   if (variant < 0) { const char* e = getenv("GH_SPMM_VARIANT"); variant = e ? atoi(e) : 4; if (variant > 5) variant = 4; }
   const int ptag = n < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_SPMM;
   prof_begin(s, ptag);
-  if (v4 && variant >= 3 && r <= 256) {
+  if (v4 && variant >= 3 && r <= 256 && (!bf16 || hv % 2 == 0)) {
     // edge-list kernel; variant 3: one column per thread, 4 (default): two, 5: three.  LDS pitch = slab columns.
     const int cap = 11 * r;                        // edges per graph the list holds (a window-5 word graph has <= 9 R)
-    const size_t llds = (size_t)r * slab * 16 + (size_t)cap * 8 + (size_t)(r + 1) * 4 + (size_t)r * 4;
+    int lslab = slab;
+    dim3 lgrid = grid;
+    if (bf16) {                                    // bf16 LDS image: 8 B per column -> twice the columns per slab, kept even
+      int smax = (cap_kb * 1024) / (r * 8);
+      smax = smax > 64 ? 64 : (smax < 4 ? 4 : smax);
+      smax &= ~1;
+      const int ns = (hv + smax - 1) / smax;
+      lslab = (((hv + ns - 1) / ns) + 1) & ~1;
+      lgrid = dim3(n, (hv + lslab - 1) / lslab);
+    }
+    const size_t llds = (size_t)r * lslab * (bf16 ? 8 : 16) + (size_t)cap * 8 + (size_t)(r + 1) * 4 + (size_t)r * 4;
     const void* fn;
     const int lv = variant > 5 ? 5 : variant;
     if (bf16) fn = lv == 3 ? (const void*)spmm_list_kernel<true, 1> : lv == 5 ? (const void*)spmm_list_kernel<true, 3> : (const void*)spmm_list_kernel<true, 2>;
@@ -615,8 +614,8 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
     const int ai = (bf16 ? 3 : 0) + (lv - 3);
     if (!attrl[ai] && llds > 64 * 1024) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrl[ai] = true; }
     void* args[] = {(void*)&bits, (void*)&dinv, (void*)&vals, (void*)&keep, (void*)&goff, (void*)&x, (void*)&y, (void*)&r, (void*)&h,
-                    (void*)&slab, (void*)&cap, (void*)&transpose, (void*)&accumulate};
-    (void)hipLaunchKernel(fn, grid, dim3(256), args, llds, s);
+                    (void*)&lslab, (void*)&cap, (void*)&transpose, (void*)&accumulate};
+    (void)hipLaunchKernel(fn, lgrid, dim3(256), args, llds, s);
   } else if (bf16) {
     static bool attrb = false;
     if (!attrb && lds > 64 * 1024) { (void)hipFuncSetAttribute((const void*)spmm_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrb = true; }

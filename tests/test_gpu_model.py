@@ -89,6 +89,29 @@ def test_model_vs_golden(name, native):
     assert n_live == meta["n_live"]
 
 
+@pytest.mark.parametrize("native", [False, "compact"])
+def test_claim_side_stream_is_bit_identical_to_single_stream(native, monkeypatch):
+    """The forward issues the claim branch on an auxiliary stream (modules.Graph_basedSemantiStructure.forward): logits,
+    attention weights and every gradient must be bit-identical to the single-stream schedule, several times in a row
+    (a missing join would show up as stale or torn claim vectors)."""
+    from get_amd import ops
+    runs = {}
+    for side in (False, True, True, False):
+        monkeypatch.setattr(ops, "CLAIM_SIDE_STREAM", side)
+        cfg, model, inp, phi, ww, ew, loss = run_case("small", native_graphs=native)
+        loss.backward()
+        torch.cuda.synchronize()
+        res = [phi.detach().clone(), ww.detach().clone(), ew.detach().clone()] + \
+              [p.grad.clone() for _, p in sorted(model.named_parameters()) if p.grad is not None]
+        runs.setdefault(side, []).append(res)
+    ref = runs[False][0]
+    for side in (False, True):
+        for res in runs[side]:
+            assert len(res) == len(ref)
+            for a, b in zip(res, ref):
+                assert torch.equal(a, b)
+
+
 def test_model_eval_path_int32_and_predict():
     z, _ = load("g7_model_small.npz")
     cfg, model, inp, phi, ww, ew, loss = run_case("small", int32_inputs=True)
