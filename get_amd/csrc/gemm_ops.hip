@@ -819,11 +819,17 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, const in
   const int M = m_real;
   if (!left) xl = 0;
   const int ldw = xl + dr;
+  // Two-phase use (the caller may put the weight gradient of linear1 on another stream): dw1 == NULL skips its two
+  // launches; dright == NULL is the complementary "dw1 only" call on buffers (dpre, du) a first call has filled.
+  const bool weights_only = (dright == nullptr);
+  GH_REQUIRE(!weights_only || dw1, "concat_att_bwd: dright == NULL asks for the dw1-only phase, which needs dw1");
+  float* dw2_part = nullptr;
+  if (!weights_only) {
   if (int e = launch_att_softmax_bwd(right, weights, g_att, g_w, goff, m_real, b, l, dr, heads, de, dright, s)) return e;
   // dW2 = de^T t rides along with the dpre pass (per-pair partials in the workspace, one reduce)
   const size_t dw2_bytes = (size_t)b * heads * ha * sizeof(float);
   const Workspace wsp = workspace_for(s);
-  float* dw2_part = (wsp.p && dw2_bytes <= wsp.bytes && ha % 4 == 0) ? wsp.p : nullptr;
+  dw2_part = (wsp.p && dw2_bytes <= wsp.bytes && ha % 4 == 0) ? wsp.p : nullptr;
   if (int e = launch_att_dpre(de, w2, t, goff, m_real, b, l, ha, heads, dpre, du, dw2_part, s)) return e;
   if (dw2_part) {
     ReduceArgs R;
@@ -846,15 +852,17 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, const in
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }
-  if (M > 0) {
-    Batch bt(true, M, s);
-    bt.add(tn_problem(ha, dr, dw1 + xl, ldw, dpre, ha, right, dr, M));
-    bt.flush();
-    GH_CHECK_HIP(bt.err);
-  }
   if (!dw2_part && M > 0) {  // no workspace: `heads` rows are not float4-shaped, so this one takes the generic kernel
     Batch bt(true, M, s);
     bt.add(tn_problem(heads, ha, dw2, ha, de, heads, t, ha, M));
+    bt.flush();
+    GH_CHECK_HIP(bt.err);
+  }
+  }
+  if (!dw1) return 0;
+  if (M > 0) {
+    Batch bt(true, M, s);
+    bt.add(tn_problem(ha, dr, dw1 + xl, ldw, dpre, ha, right, dr, M));
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }

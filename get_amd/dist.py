@@ -117,6 +117,8 @@ class FlatTrainer:
         the first collective is still pending means a second backward pass ran before ``allreduce()`` / ``step()``
         (gradient accumulation): its early gradients would be added to an already reduced range, so this is rejected
         -- accumulate with the overlap detached, or call ``allreduce()`` after every backward."""
+        from . import ops
+        ops.side_join()        # weight gradients issued on the auxiliary stream belong to the early range
         if self._early_work is not None:
             raise RuntimeError("get_amd: a second backward pass reached the all-reduce milestone while the first early "
                                "all-reduce is still pending; gradient accumulation needs detach_overlap() (one "
@@ -136,6 +138,8 @@ class FlatTrainer:
     def allreduce(self):
         """All-reduce(sum) of the gradient bucket (RCCL over xGMI on GPUs, gloo in CPU tests): the whole bucket in one
         collective, or -- when the early part is already in flight -- a wait on it plus the late remainder."""
+        from . import ops
+        ops.side_join()
         if self.world > 1:
             if self._early_work is not None:
                 self._early_work.wait()

@@ -30,6 +30,39 @@ def side_stream(device) -> "torch.cuda.Stream":
     return s
 
 
+# Weight gradients of the few-row layers (evidence-level attention, head) leave the critical path of backward: with a
+# FlatTrainer (gradients accumulate straight into the flat bucket) they are issued on the auxiliary stream and joined
+# at the end of the backward pass (and before any all-reduce).  GET_AMD_WGRAD_STREAM=0 keeps them in line.
+WGRAD_SIDE_STREAM = os.environ.get("GET_AMD_WGRAD_STREAM", "1") != "0"
+WGRAD_FEW_ROWS = 4096
+_side_pending: set = set()
+
+
+def side_join():
+    """Make the current stream wait for everything issued on the auxiliary stream so far (no-op when nothing is)."""
+    for idx in list(_side_pending):
+        torch.cuda.current_stream(idx).wait_stream(_SIDE_STREAMS[idx])
+        _side_pending.discard(idx)
+
+
+def _side_wgrad(dev, tensors, launch):
+    """Run `launch()` (weight-gradient launches only) on the auxiliary stream after the current stream's work;
+    `tensors` are the operands it reads.  The join is queued for the end of the running backward pass."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    side = side_stream(dev)
+    main = torch.cuda.current_stream(idx)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        _lib.ensure_workspace(dev)
+        launch()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(side)
+    if idx not in _side_pending:
+        _side_pending.add(idx)
+        torch.autograd.Variable._execution_engine.queue_callback(side_join)
+
+
 _WEIGHT_EPOCH = 0
 _WT_CACHE: dict = {}
 
@@ -559,9 +592,15 @@ class _ConcatAtt(torch.autograd.Function):
         else:
             dw1 = torch.zeros((ha, xl + dr), device=dev, dtype=torch.float32)
             dw2 = torch.zeros((heads, ha), device=dev, dtype=torch.float32)
-        call("gh_concat_att_bwd", ptr(left), ptr(right), *_plan_args(plan), b, l, xl, dr, ha, heads, ptr(w1t), ptr(w2), ptr(t),
-             ptr(weights), ptr(g_att), ptr(g_w), ptr(de), ptr(dpre), ptr(du), ptr(dleft), ptr(dright), ptr(dw1),
-             ptr(dw2), stream())
+        pa = (ptr(left), ptr(right), *_plan_args(plan), b, l, xl, dr, ha, heads, ptr(w1t), ptr(w2), ptr(t), ptr(weights),
+              ptr(g_att), ptr(g_w), ptr(de), ptr(dpre), ptr(du), ptr(dleft))
+        if direct and WGRAD_SIDE_STREAM and b * l <= WGRAD_FEW_ROWS and right.is_cuda:
+            # evidence level: everything but dW1 in line, dW1 = dpre^T [left | right] on the auxiliary stream
+            call("gh_concat_att_bwd", *pa, ptr(dright), None, ptr(dw2), stream())
+            _side_wgrad(dev, (left, right, dpre, du),
+                        lambda: call("gh_concat_att_bwd", *pa, None, ptr(dw1), ptr(dw2), stream()))
+        else:
+            call("gh_concat_att_bwd", *pa, ptr(dright), ptr(dw1), ptr(dw2), stream())
         if direct:
             return dleft, dright, None, None, None, None
         return dleft, dright, None, dw1, dw2, None
@@ -604,7 +643,13 @@ class _Linear(torch.autograd.Function):
         else:
             dw = torch.zeros((n, k), device=g.device, dtype=torch.float32)
             db = torch.zeros((n,), device=g.device, dtype=torch.float32) if ctx.has_bias else None
-        call("gh_linear_bwd", ptr(x2), ptr(wt), ptr(wc), ptr(g2), m, k, n, ptr(dx), ptr(dw), ptr(db), stream())
+        if direct and WGRAD_SIDE_STREAM and m <= WGRAD_FEW_ROWS and g2.is_cuda:
+            if dx is not None:
+                call("gh_linear_bwd", ptr(x2), ptr(wt), ptr(wc), ptr(g2), m, k, n, ptr(dx), None, None, stream())
+            _side_wgrad(g2.device, (x2, g2),
+                        lambda: call("gh_linear_bwd", ptr(x2), ptr(wt), ptr(wc), ptr(g2), m, k, n, None, ptr(dw), ptr(db), stream()))
+        else:
+            call("gh_linear_bwd", ptr(x2), ptr(wt), ptr(wc), ptr(g2), m, k, n, ptr(dx), ptr(dw), ptr(db), stream())
         dxo = dx.view(ctx.xshape) if dx is not None else None
         if direct:
             return dxo, None, None

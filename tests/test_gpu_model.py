@@ -112,6 +112,36 @@ def test_claim_side_stream_is_bit_identical_to_single_stream(native, monkeypatch
                 assert torch.equal(a, b)
 
 
+def test_side_stream_weight_gradients_are_bit_identical(monkeypatch):
+    """With a FlatTrainer the weight gradients of the evidence-level attention and the head are issued on the auxiliary
+    stream and joined when backward ends (ops._side_wgrad): the flat gradient bucket must equal the in-line schedule bit
+    for bit, read right after backward() on the caller's stream, several times in a row."""
+    from get_amd import ops
+    from get_amd.dist import FlatTrainer
+    cfg, model, inp, phi, ww, ew, loss = run_case("small", native_graphs="compact")
+    trainer = FlatTrainer(model, lr=1e-4, weight_decay=1e-3)
+    ops.bump_weight_epoch()
+    model.train(False)
+    raw = make_raw_batch(cfg, MODEL_CASES["small"][1])
+    buckets = {}
+    for side in (False, True, True, False, True):
+        monkeypatch.setattr(ops, "WGRAD_SIDE_STREAM", side)
+        trainer.zero_grad()
+        cfg2, model2, inp2, phi2, ww2, ew2, loss2 = None, None, None, None, None, None, None
+        query = torch.from_numpy(inp["query"]).to(DEV)
+        document = torch.from_numpy(inp["document"]).to(DEV)
+        kargs = to_dev(reference_kargs(inp, torch, output_ranking=False))
+        out = model(query, document, **kargs)
+        torch.nn.functional.cross_entropy(out, torch.from_numpy(inp["labels"]).to(DEV)).backward()
+        buckets.setdefault(side, []).append(trainer.flat_g.clone())       # no synchronize: stream order must suffice
+    torch.cuda.synchronize()
+    ref = buckets[False][0]
+    assert float(ref.abs().max()) > 0
+    for side in (False, True):
+        for b in buckets[side]:
+            assert torch.equal(b, ref)
+
+
 def test_model_eval_path_int32_and_predict():
     z, _ = load("g7_model_small.npz")
     cfg, model, inp, phi, ww, ew, loss = run_case("small", int32_inputs=True)
