@@ -210,7 +210,9 @@ int gh_concat_att_fwd(const float* left, const float* right, const float* mask, 
                       float* u, float* t, float* e, float* weights, float* attended, gh_stream_t stream);
 /* Backward.  w1t = transpose of linear1.weight: [xl+dr][ha].  g_att [b][dr][heads], g_w [b][l][heads] or NULL.
  * Scratch: de [b*l][heads], dpre [b*l][ha], du [b][ha].
- * Out: dleft [b][xl] (NULL ok), dright [b][l][dr]; ACCUMULATED: dw1 [ha][xl+dr], dw2 [heads][ha]. */
+ * Out: dleft [b][xl] (NULL ok), dright [b][l][dr]; ACCUMULATED: dw1 [ha][xl+dr], dw2 [heads][ha].
+ * Two-phase use (e.g. the weight gradient of linear1 on another stream): dw1 == NULL leaves its launches out;
+ * dright == NULL is the complementary call that computes ONLY dw1 from the dpre / du a first call has filled. */
 int gh_concat_att_bwd(const float* left, const float* right, const int32_t* goff, int m_real, int b, int l, int xl,
                       int dr, int ha, int heads,
                       const float* w1t, const float* w2, const float* t, const float* weights,
