@@ -916,9 +916,18 @@ evd_assemble_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__
     for (int i = threadIdx.x; i < Xa; i += blockDim.x) d[i] = gp[i];
   }
   if (Ds <= 0 || !d_table) return;
-  for (int i = threadIdx.x; i < n_slots; i += blockDim.x) { const long long v = (long long)sources[i]; sids[i] = v < 0 ? 0 : (int)v; }
+  // Padding slots (slot >= the claim's evidence count) are masked out of the evidence-level softmax, so their gradient
+  // rows are exact zeros: they neither own nor join a source row (-1 never matches).  Without this every padding slot
+  // maps to source 0 and ONE workgroup walks hundreds of zero rows (177 us at the realistic evidence counts).
+  for (int i = threadIdx.x; i < n_slots; i += blockDim.x) {
+    const int bi = i / n_max;
+    const bool real = (i - bi * n_max) < min(offsets[bi + 1] - offsets[bi], n_max);
+    const long long v = (long long)sources[i];
+    sids[i] = real ? (v < 0 ? 0 : (int)v) : -1;
+  }
   __syncthreads();
   const int mine = sids[me];
+  if (mine < 0) return;
   __shared__ int earlier;
   if (threadIdx.x == 0) earlier = 0;
   __syncthreads();
