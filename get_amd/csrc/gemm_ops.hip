@@ -573,8 +573,22 @@ static int cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float
     GH_CHECK_HIP(b.err);
   }
   if (int e = launch_spmm(bits, dinv, vals, keep, goff, m_real, xp, a, n, r, h, 0, 0, s, bf)) return e;   // a = A_hat xp (:192)
-  if (m_rows > m_real)   // padding rows of the node-compact layout have no neighbours
-    GH_CHECK_HIP(hipMemsetAsync((char*)a + (size_t)m_real * h * (bf ? 2 : 4), 0, (size_t)(bf ? 2 : 4) * (size_t)(m_rows - m_real) * h, s));
+  bool partial_zero = false;
+  const long long generic_before = g_path_counts[1];
+  if (m_rows > m_real) {
+    // padding rows of the node-compact layout have no neighbours.  The fast gate GEMMs skip the aggregation segment for
+    // every row tile at or beyond seg0_rows (= m_real), so only the tile that straddles m_real ever reads such rows: zero
+    // the rows up to the next 128-row boundary (the largest row tile) plus one tile instead of all (m_rows - m_real) of
+    // them (40 MB at the bench shape).  Only when the operands are shaped for the fast kernel -- the generic kernel
+    // reads every row; the launches below are checked to have taken the fast path.
+    const uintptr_t al = (uintptr_t)a | (uintptr_t)xp | (uintptr_t)z | (uintptr_t)rr | (uintptr_t)rx | (uintptr_t)hh | (uintptr_t)out |
+                         (uintptr_t)w_z0 | (uintptr_t)w_z1 | (uintptr_t)w_r0 | (uintptr_t)w_r1 | (uintptr_t)w_h0 | (uintptr_t)w_h1 |
+                         (uintptr_t)b_z0 | (uintptr_t)b_z1 | (uintptr_t)b_r0 | (uintptr_t)b_r1 | (uintptr_t)b_h0 | (uintptr_t)b_h1;
+    partial_zero = ((al & 15) == 0) && (h % (bf ? 8 : 4) == 0) && h >= 4;
+    const int zfull = ((m_real + 127) / 128 + 1) * 128;
+    const int zend = (partial_zero && zfull < m_rows) ? zfull : m_rows;
+    GH_CHECK_HIP(hipMemsetAsync((char*)a + (size_t)m_real * h * (bf ? 2 : 4), 0, (size_t)(bf ? 2 : 4) * (size_t)(zend - m_real) * h, s));
+  }
   {  // z, r gates (:194-200): [a | xp] . [W?0 | W?1]^T as two K segments
     Batch b(false, M, s, wide);
     Problem pz = gemm_problem(M, h, EPI_SIGMOID_Z, z, h, a, h, w_z0, h, h, nullptr, bf);
@@ -606,6 +620,8 @@ static int cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float
     GH_REQUIRE(b.err != hipErrorInvalidValue || !score_w, "ggnn_cell_fwd: the fused scorer projection needs h %% 4 == 0 and h <= 320 (h=%d)", h);
     GH_CHECK_HIP(b.err);
   }
+  GH_REQUIRE(!partial_zero || g_path_counts[1] == generic_before,
+             "ggnn_cell_fwd: internal -- a gate GEMM took the generic kernel although the padding rows of `a` were only zeroed for the fast one");
   return 0;
 }
 
