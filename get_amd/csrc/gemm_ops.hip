@@ -157,7 +157,7 @@ Workspace workspace_for(hipStream_t s) {
 }
 
 struct ReduceItem { const float* ws; float* out; int I, J, ldc, ks; long long stride; };
-struct ReduceArgs { ReduceItem it[GH_MAX_PROBLEMS]; int n; };
+struct ReduceArgs { ReduceItem it[3 * GH_MAX_PROBLEMS]; int n; };     // tiles of <= 8 problems + up to two bias-gradient outputs each
 
 __global__ void __launch_bounds__(256)
 reduce_partials_kernel(const ReduceArgs R) {
@@ -419,11 +419,11 @@ struct Batch {
         }
         hipError_t e = launch_any();
         if (e != hipSuccess) err = e;
+        // one reduce launch: the bias-gradient partials ride behind the tiles (their workgroups beyond the first exit at once)
+        for (int i = 0; i < RC.n; ++i) R.it[R.n++] = RC.it[i];
+        if (max_cs > max_elems) max_elems = max_cs;
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((max_elems + 255) / 256, R.n), dim3(256), 0, s, R);
-        if (RC.n > 0) {
-          hipLaunchKernelGGL(reduce_partials_kernel, dim3((max_cs + 255) / 256, RC.n), dim3(256), 0, s, RC);
-          colsum_fused = true;
-        }
+        if (RC.n > 0) colsum_fused = true;
         e = hipGetLastError();
         if (e != hipSuccess) err = e;
         reset();
