@@ -156,7 +156,11 @@ class GGNN_with_GSL(nn.Module):
         srcs = []
         for m in (s.linearz0, s.linearz1, s.linearr0, s.linearr1, s.linearh0, s.linearh1):
             srcs += [m.linear.weight, m.linear.bias]
-        return ops.derived("gate12", tuple(srcs), lambda: torch.cat([t.detach().reshape(1) for t in srcs]))
+        # the scorer's parameters never receive a gradient (wrapper.py:219: no gradient through top-k), so a FlatTrainer
+        # leaves them out of its bucket and never rewrites them: the packed copy then only depends on tensor identity /
+        # in-place version, not on the optimiser's weight epoch (one cat launch + a dozen host ops less per step)
+        static = not any(getattr(t, "_gh_direct_grad", False) for t in srcs)
+        return ops.derived("gate12", tuple(srcs), lambda: torch.cat([t.detach().reshape(1) for t in srcs]), frozen=static)
 
     def _scorer_drop(self):
         """(p, seed) of word_scorer1's own input dropout for this call (wrapper.py:189-190)."""
