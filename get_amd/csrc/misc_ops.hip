@@ -351,7 +351,8 @@ int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m
 
 // ---------------------------------------------------------------------------- concat attention: masked softmax + weighted reduce
 // e [b][l][C] -> weights = softmax over l (two_branches_attention.py:142-146), attended[b][d][c] = sum_l right[b][l][d] w[l][c] (:147)
-__global__ void __launch_bounds__(512)
+template <int CT>     // compile-time bound on the number of heads (accumulator registers)
+__global__ void __launch_bounds__(256, 4)
 att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ mask, const float* __restrict__ right,
                        const int32_t* __restrict__ goff, int Lmax, int Dr, int C, float* __restrict__ weights,
                        float* __restrict__ attended) {
@@ -368,21 +369,31 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
   // requested BEFORE the softmax (its latency hides behind the exp / shuffle work), and every later batch before the
   // previous one is consumed -- RB rows = RB KB per wave in flight instead of the one-row-at-a-time walk that kept the
   // kernel latency-bound at 1.9 TB/s.
-  constexpr int RB = 8;
+  // A workgroup takes 128 float4 columns (two per lane): at Dr = 300 that is the WHOLE row -- the 64-column slabs
+  // left a second workgroup per pair reading 176-byte runs (11 float4) whose 128-byte lines the first one fetches too.
+  // All 960 pairs of the bench shape should be resident at once (4 workgroups per CU -> <= 128 VGPRs), and a wave should
+  // need as few memory round trips as possible for its ~16 rows: RB = 6 rows x 2 chunks in flight per trip, single
+  // buffered (the math between two trips is far shorter than a round trip, so a second buffer only costs registers).
+  constexpr int RB = CT <= 2 ? 8 : CT <= 5 ? 6 : 4, NCH = 2;   // (8 x 2 chunks + 40 accumulators spill at 128 VGPRs)
   const int D4 = Dr / 4;
-  const int d4 = blockIdx.y * 64 + lane;
-  const bool colok = d4 < D4;
-  const float4* rb = reinterpret_cast<const float4*>(right + (size_t)row0 * Dr) + (colok ? d4 : 0);
+  int dcl[NCH];
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) dcl[h] = min(blockIdx.y * (64 * NCH) + lane + 64 * h, D4 - 1);
+  const float4* rb = reinterpret_cast<const float4*>(right + (size_t)row0 * Dr);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // (unconditional loads from clamped rows: a `cond ? load : 0` select makes the compiler route the load through a flat
-  // pointer to a zero in scratch; rows beyond L are loaded twice and never consumed)
-  float4 nxt[RB];
+  // (unconditional loads from clamped rows / columns: a `cond ? load : 0` select makes the compiler route the load
+  // through a flat pointer to a zero in scratch; clamped duplicates are loaded twice and never consumed)
+  float4 rv[RB][NCH];
   if (L > 0) {
 #pragma unroll
-    for (int u = 0; u < RB; ++u) nxt[u] = rb[(size_t)min(wave + u * NWV, L - 1) * D4];
+    for (int u = 0; u < RB; ++u)
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) rv[u][h] = rb[(size_t)min(wave + u * NWV, L - 1) * D4 + dcl[h]];
   } else {
 #pragma unroll
-    for (int u = 0; u < RB; ++u) nxt[u] = zero4;
+    for (int u = 0; u < RB; ++u)
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) rv[u][h] = zero4;
   }
   for (int c = wave; c < C; c += NWV) {
     float mx = -INFINITY;
@@ -402,50 +413,58 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
   __syncthreads();
   if (blockIdx.y == 0)
     for (int i = tid; i < L * C; i += NT) weights[(size_t)row0 * C + i] = ws[i];
-  // attended[d][c] = sum_l right[l][d] w[l][c]: blockIdx.y owns a slab of 64 float4 columns, the waves take every
-  // NWV-th row (16-byte coalesced reads), partial sums meet in LDS
+  // attended[d][c] = sum_l right[l][d] w[l][c]: the waves take every NWV-th row (16-byte coalesced reads), partial sums
+  // meet in LDS, one column chunk after the other
   float* part = ws + Lmax * C;                   // [NWV][64][4][C] floats
-  float acc[4][8];
+  float acc[NCH][4][CT];
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+  for (int h = 0; h < NCH; ++h)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) acc[h][k][c] = 0.f;
   for (int l0 = wave; l0 < L; l0 += RB * NWV) {
-    float4 cur[RB];
+    if (l0 != wave) {
 #pragma unroll
-    for (int u = 0; u < RB; ++u) cur[u] = nxt[u];
-    if (l0 + RB * NWV < L) {
+      for (int u = 0; u < RB; ++u)
 #pragma unroll
-      for (int u = 0; u < RB; ++u) nxt[u] = rb[(size_t)min(l0 + (RB + u) * NWV, L - 1) * D4];
+        for (int h = 0; h < NCH; ++h) rv[u][h] = rb[(size_t)min(l0 + u * NWV, L - 1) * D4 + dcl[h]];
     }
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
       const int l = l0 + u * NWV;
-      if (l < L && colok) {
-        const float4 rv = cur[u];
+      if (l < L) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+        for (int c = 0; c < CT; ++c)
           if (c < C) {
             const float w = ws[l * C + c];
-            acc[0][c] += rv.x * w; acc[1][c] += rv.y * w; acc[2][c] += rv.z * w; acc[3][c] += rv.w * w;
+#pragma unroll
+            for (int h = 0; h < NCH; ++h) {
+              const float4 r4 = rv[u][h];
+              acc[h][0][c] += r4.x * w; acc[h][1][c] += r4.y * w; acc[h][2][c] += r4.z * w; acc[h][3][c] += r4.w * w;
+            }
           }
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+  for (int h = 0; h < NCH; ++h) {
+    if (h > 0) __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
-      if (c < C) part[((wave * 64 + lane) * 4 + k) * C + c] = acc[k][c];
-  __syncthreads();
-  for (int i = tid; i < 64 * 4 * C; i += NT) {
-    const int ln = i / (4 * C), rem = i % (4 * C);     // rem = k*C + c -> output offset within the float4 column group
-    const int dd = (blockIdx.y * 64 + ln) * 4 + rem / C;
-    if (dd < Dr) {
-      float v = 0.f;
-      for (int w = 0; w < NWV; ++w) v += part[((w * 64 + ln) * 4) * C + rem];
-      if (L == 0) v = NAN;                      // no rows at all: the reference's softmax over an all -inf column
-      attended[((size_t)b * Dr + dd) * C + rem % C] = v;
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        if (c < C) part[((wave * 64 + lane) * 4 + k) * C + c] = acc[h][k][c];
+    __syncthreads();
+    for (int i = tid; i < 64 * 4 * C; i += NT) {
+      const int ln = i / (4 * C), rem = i % (4 * C);     // rem = k*C + c -> output offset within the float4 column group
+      const int dd = (blockIdx.y * (64 * NCH) + 64 * h + ln) * 4 + rem / C;
+      if (dd < Dr) {
+        float v = 0.f;
+        for (int w = 0; w < NWV; ++w) v += part[((w * 64 + ln) * 4) * C + rem];
+        if (L == 0) v = NAN;                      // no rows at all: the reference's softmax over an all -inf column
+        attended[((size_t)b * Dr + dd) * C + rem % C] = v;
+      }
     }
   }
 }
@@ -457,8 +476,11 @@ int launch_att_softmax_fwd(const float* e, const float* mask, const float* right
   const size_t lds = ((size_t)l * heads + (nthr / 64) * 64 * 4 * heads) * 4;
   GH_REQUIRE(lds <= 64 * 1024, "att_softmax_fwd: sequence %d x heads %d too large", l, heads);
   prof_begin(s, b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_SOFTMAX_FWD);
-  hipLaunchKernelGGL(att_softmax_fwd_kernel, dim3(b, (dr / 4 + 63) / 64), dim3(nthr), lds, s, e, mask, right, goff, l, dr,
-                     heads, weights, attended);
+  GH_REQUIRE(heads >= 1 && heads <= 8, "att_softmax_fwd: %d heads (1..8 supported)", heads);
+  const dim3 grid(b, (dr / 4 + 127) / 128);
+  if (heads <= 2) hipLaunchKernelGGL(att_softmax_fwd_kernel<2>, grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended);
+  else if (heads <= 5) hipLaunchKernelGGL(att_softmax_fwd_kernel<5>, grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended);
+  else hipLaunchKernelGGL(att_softmax_fwd_kernel<8>, grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended);
   const double rows = goff ? (double)m_real : (double)b * l;
   prof_end(b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_SOFTMAX_FWD, 4.0 * (rows * dr + 2.0 * rows * heads + rows + (double)b * dr * heads), s);
   GH_LAUNCH_CHECK();
@@ -673,7 +695,10 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
   const bool act = rl < RL && cl < sw;
   // RB rows per thread and trip with all loads ahead of the math; the first trip's rows are requested before `de` is
   // staged (loads unconditional from clamped rows / columns; clamped duplicates are never consumed)
-  constexpr int RB = 4;
+#ifndef GH_DPRE_RB
+#define GH_DPRE_RB 4
+#endif
+  constexpr int RB = GH_DPRE_RB;
   const int c4c = min(c4, n4 - 1);
   const float4* tb = reinterpret_cast<const float4*>(t + (size_t)row0 * Ha) + c4c;
   float4 nxt[RB];
@@ -748,7 +773,12 @@ int launch_att_dpre(const float* de, const float* w2, const float* t, const int3
   const int n4 = ha / 4;
   // column slabs of <= 32 float4 (512 B of a row per lane group: whole 128-byte lines), ~3 slabs at ha = 300; few pairs
   // (evidence level) keep one slab per 64 columns
-  const int nsl = (n4 + 31) / 32;
+  // whole rows per workgroup up to 512 floats: a column slab makes every row a short run (400 B at three slabs) that
+  // straddles 128-byte lines shared with the neighbouring slab's workgroup -- measured 3.1 / 3.6 / 3.9 / 4.3 TB/s at
+  // 5 / 3 / 2 / 1 slabs (GH_DPRE_SLABS) once the row batches are prefetched
+  static int nsl_env = -1;
+  if (nsl_env < 0) { const char* e = getenv("GH_DPRE_SLABS"); nsl_env = e ? atoi(e) : 0; }
+  const int nsl = nsl_env > 0 ? nsl_env : (n4 + 127) / 128;
   const int S4 = (n4 + nsl - 1) / nsl;
   const int RL = (256 / S4) > 0 ? (256 / S4) : 1;
   const int threads = ((S4 * RL + 63) / 64) * 64;
