@@ -143,7 +143,12 @@ def ensure_workspace(device, nbytes: int = 256 << 20):
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
         _workspaces[key] = ws
-        call("gh_set_stream_workspace", st, ws.data_ptr(), ws.numel() * 4)
+        # the C registry is keyed by (hipGetDevice(), stream): register under `dev`, whatever the current device is
+        if dev.index != _get_device():
+            with torch.cuda.device(dev):
+                call("gh_set_stream_workspace", st, ws.data_ptr(), ws.numel() * 4)
+        else:
+            call("gh_set_stream_workspace", st, ws.data_ptr(), ws.numel() * 4)
     return ws
 
 

@@ -138,7 +138,12 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
 namespace gh {
 static std::mutex g_ws_mu;
 static Workspace g_ws_default = {nullptr, 0, nullptr, 0};
-static std::unordered_map<hipStream_t, Workspace> g_ws_stream;
+// keyed by (device, stream): the default stream has handle 0 on EVERY device, so the stream alone does not identify a
+// scratch area in a process that drives several devices
+struct WsKey { int dev; hipStream_t s; bool operator==(const WsKey& o) const { return dev == o.dev && s == o.s; } };
+struct WsKeyHash { size_t operator()(const WsKey& k) const { return std::hash<const void*>()((const void*)k.s) * 31u + (size_t)(k.dev + 1); } };
+static std::unordered_map<WsKey, Workspace, WsKeyHash> g_ws_stream;
+static int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) d = 0; return d; }
 static Workspace make_workspace(void* ptr, int64_t bytes) {
   // the last 1/16 of the buffer (16-byte aligned) serves the column-sum partials, the rest split-K tiles
   Workspace w = {nullptr, 0, nullptr, 0};
@@ -152,7 +157,7 @@ static Workspace make_workspace(void* ptr, int64_t bytes) {
 }
 Workspace workspace_for(hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  auto it = g_ws_stream.find(s);
+  auto it = g_ws_stream.find(WsKey{current_device(), s});
   return it != g_ws_stream.end() ? it->second : g_ws_default;
 }
 
@@ -912,8 +917,9 @@ extern "C" int gh_set_workspace(void* ptr, int64_t bytes) {
 
 extern "C" int gh_set_stream_workspace(gh_stream_t stream, void* ptr, int64_t bytes) {
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  if (!ptr) g_ws_stream.erase((hipStream_t)stream);
-  else g_ws_stream[(hipStream_t)stream] = make_workspace(ptr, bytes);
+  const WsKey key{current_device(), (hipStream_t)stream};      // the CURRENT device's `stream`
+  if (!ptr) g_ws_stream.erase(key);
+  else g_ws_stream[key] = make_workspace(ptr, bytes);
   return 0;
 }
 

@@ -1225,9 +1225,19 @@ extern "C" int gh_evd_assemble_bwd(const float* g, const int32_t* offsets, const
                                    int xa, int ds, float* d_avg, float* d_table, gh_stream_t stream) {
   GH_REQUIRE(b > 0 && n_max > 0 && xa > 0 && ds >= 0, "evd_assemble_bwd: bad sizes");
   const int n_slots = b * n_max;
-  GH_REQUIRE(n_slots <= 12000, "evd_assemble_bwd: %d claim x evidence slots (max 12000 per call)", n_slots);
+  // every workgroup stages the source id of every slot (4 B) + a match bit per slot in LDS: 160 KB hold 38 000 slots,
+  // i.e. 1266 claims x 30 evidence slots per call
+  GH_REQUIRE(n_slots <= 38000, "evd_assemble_bwd: %d claim x evidence slots (max 38000 per call: split the batch)", n_slots);
   hipStream_t s = (hipStream_t)stream;
   const size_t lds_bytes = (size_t)((n_slots + 1) & ~1) * 4 + (size_t)((n_slots + 63) / 64) * 8;
+  if (lds_bytes > 48 * 1024) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)evd_assemble_bwd_kernel<int64_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)evd_assemble_bwd_kernel<int32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+  }
   if (sources_i64)
     hipLaunchKernelGGL((evd_assemble_bwd_kernel<int64_t>), dim3(n_slots), dim3(256), lds_bytes, s, g, offsets,
                        (const int64_t*)sources, d_avg, d_table, n_slots, n_max, xa, ds);

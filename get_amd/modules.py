@@ -29,9 +29,10 @@ from .ops import PackedAdj
 
 def _drop_caches_on_load(module: nn.Module):
     """The forward reads cached derivatives of the weights (transposes, fused bias sums, packed scalar gates; ops.transposed
-    / ops.derived) that are validated by tensor identity and in-place version.  load_state_dict copies into `.data`
-    without bumping the version, so every module here invalidates the caches after a load.  Any OTHER raw `.data` write
-    (EMA swaps, hand-written optimisers) must call ops.bump_weight_epoch() itself."""
+    / ops.derived) that are validated by tensor identity and in-place version.  load_state_dict copies
+    into the parameters in place; every module here drops ALL cached derivatives after a load so that no stale entry can
+    survive whatever the copy path did to the version counters.  Any OTHER raw `.data` write (EMA swaps, hand-written
+    optimisers) must call ops.bump_weight_epoch() itself (it clears every derived entry, frozen ones included)."""
     module.register_load_state_dict_post_hook(lambda m, incompatible_keys: ops.bump_weight_epoch())
 
 
@@ -415,6 +416,11 @@ class Graph_basedSemantiStructure(nn.Module):
             main.wait_stream(side)
             q_repr.record_stream(main)
             query_repr.record_stream(main)
+            if query_repr.requires_grad:
+                # the claim branch's backward will run on the side stream: join it at the end of the backward pass
+                # whether or not any other side-stream work (ops._side_wgrad) happens in that pass
+                dev_ = query.device
+                query_repr.register_hook(lambda g, _d=dev_: ops.side_mark_backward(_d))
 
         # word-level attention (:173-193); the claim vector WITHOUT its source embedding (:110)
         if plan is None:

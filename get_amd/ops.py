@@ -45,6 +45,18 @@ def side_join():
         _side_pending.discard(idx)
 
 
+def side_mark_backward(device):
+    """Called from inside a backward pass when work of that pass runs (or is about to run) on the auxiliary stream -- the
+    claim branch's backward, which autograd replays on its forward stream: marks the device pending and queues the join
+    for the end of the pass.  With a FlatTrainer the branch's backward returns no gradients to autograd (they land in
+    the flat bucket directly), so the engine itself never learns about the side stream and would not join it."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx in _SIDE_STREAMS and idx not in _side_pending:
+        _side_pending.add(idx)
+        torch.autograd.Variable._execution_engine.queue_callback(side_join)
+
+
 def _side_wgrad(dev, tensors, launch):
     """Run `launch()` (weight-gradient launches only) on the auxiliary stream after the current stream's work;
     `tensors` are the operands it reads.  The join is queued for the end of the running backward pass."""
@@ -68,7 +80,19 @@ _WT_CACHE: dict = {}
 
 
 def bump_weight_epoch():
-    """Invalidate cached transposed weights (call after updating parameters through raw pointers)."""
+    """Invalidate EVERY cached derivative of the weights (transposes, bias sums, packed scalar gates, bf16 twins).  The
+    public invalidation API: call it after writing parameters through `.data` / raw pointers (EMA swaps, hand-written
+    optimisers) -- such writes do not bump `_version`, so nothing else can notice them."""
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+    _WT_CACHE.clear()
+    _DERIVED_CACHE.clear()
+
+
+def _bump_trainer_epoch():
+    """FlatTrainer.step's own invalidation: the fused optimiser rewrites exactly the parameters of its bucket, so entries
+    derived from tensors OUTSIDE the bucket (`frozen`: the never-trained GSL scorer's packed gates, the bf16 twin of a
+    frozen embedding table) stay valid."""
     global _WEIGHT_EPOCH
     _WEIGHT_EPOCH += 1
     _WT_CACHE.clear()
@@ -762,7 +786,8 @@ class _EvdAssemble(torch.autograd.Function):
         xa, ds = ctx.dims
         g = _f32(g)
         table = ctx.table
-        d_avg = torch.empty((seg.b1, xa), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        # rows no slot maps to (a claim with more than n_max evidences, reachable through the dense compatibility shim) get 0
+        d_avg = torch.zeros((seg.b1, xa), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         d_table = None
         ret_table = None
         if table is not None and table.requires_grad:
@@ -773,7 +798,7 @@ class _EvdAssemble(torch.autograd.Function):
                 ret_table = d_table
         src = ctx.sources
         call("gh_evd_assemble_bwd", ptr(g), ptr(seg.offsets), ptr(src), 1 if (src is not None and src.dtype == torch.int64) else 0,
-             seg.b, seg.n_max, xa, ds if d_table is not None else 0, ptr(d_avg), ptr(d_table), stream())
+             seg.b, seg.n_max, xa, ds, ptr(d_avg), ptr(d_table), stream())      # ds is also g's row pitch: always the real width
         return d_avg, ret_table, None, None, None
 
 
@@ -814,4 +839,4 @@ def adam_step_flat(p, g, m, v, step, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weig
     """One Adam step on flat fp32 buffers (declare_fitter.py:58-61 semantics)."""
     call("gh_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
          float(eps), float(weight_decay), int(step), float(grad_scale), stream())
-    bump_weight_epoch()
+    _bump_trainer_epoch()

@@ -234,7 +234,8 @@ int gh_set_gemm_mode(int mode);
  * (or when it is too small) the chunks add into the output with fp32 atomics.  All work that uses
  * it is ordered on the stream of the call, so one buffer serves one stream at a time. */
 int gh_set_workspace(void* ptr, int64_t bytes);
-/* The same, for work launched on `stream` only (takes precedence over the default buffer; NULL ptr unregisters). */
+/* The same, for work launched on `stream` of the CURRENT device only (takes precedence over the default buffer; NULL ptr
+ * unregisters).  The registry is keyed by (hipGetDevice(), stream): the default stream has handle 0 on every device. */
 int gh_set_stream_workspace(gh_stream_t stream, void* ptr, int64_t bytes);
 
 /* ---- plain linear y = x W^T + b (model head, graph_based_semantic_structure.py:69-72) ---- */
@@ -264,7 +265,8 @@ int gh_evd_assemble_fwd(const float* avg, const int32_t* offsets, const float* t
                         const void* document, int document_i64, int b, int n_max, int xa, int ds, int r,
                         float* right, float* mask, gh_stream_t stream);
 /* Backward: d_avg[b1][xa] (NULL ok) = unpad(g[:, :, :xa]); d_table[s][ds] += the g[:, :, xa:] rows of the slots with source s,
- * summed in slot order (deterministic).  g [b][n_max][xa+ds]. */
+ * summed in slot order (deterministic).  g [b][n_max][xa+ds] -- ds is g's row pitch as well: pass the real width even
+ * when d_table is NULL (a frozen table just skips the table part).  At most 38 000 slots (b * n_max) per call. */
 int gh_evd_assemble_bwd(const float* g, const int32_t* offsets, const void* sources, int sources_i64, int b, int n_max,
                         int xa, int ds, float* d_avg, float* d_table, gh_stream_t stream);
 /* masked mean over claim nodes (graph_based_semantic_structure.py:153): dst[b][h] = sum_l hid*mask / len */

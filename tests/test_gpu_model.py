@@ -671,3 +671,84 @@ def test_native_batch_counts_nodes_like_convert_text():
             for row, n in zip(raw["evd_tokens"], raw["evd_len"])]
     assert nb.m_real == sum(want) and want[0] == 1 and want[1] == 1
     assert nb.b1 == 51 and nb.compact in (True, False)
+
+
+def test_claim_branch_backward_on_the_side_stream_is_joined_without_side_wgrad(monkeypatch):
+    """with a FlatTrainer the claim cell's backward writes straight into the flat bucket and returns nothing to
+    autograd, so the engine never joins the auxiliary stream it ran on; the only join used to come from ops._side_wgrad.
+    With GET_AMD_WGRAD_STREAM off nothing ordered those writes against the caller's stream.  Made deterministic here: the
+    side stream is kept busy for ~100 ms before backward(), so the claim backward is still pending when backward()
+    returns -- the bucket read on the caller's stream right after must nevertheless be complete."""
+    from get_amd import ops
+    from get_amd.dist import FlatTrainer
+    cfg, model, inp, phi, ww, ew, loss = run_case("small", native_graphs="compact")
+    trainer = FlatTrainer(model, lr=1e-4, weight_decay=1e-3)
+    ops.bump_weight_epoch()
+    model.train(False)
+    monkeypatch.setattr(ops, "WGRAD_SIDE_STREAM", False)
+    query = torch.from_numpy(inp["query"]).to(DEV)
+    document = torch.from_numpy(inp["document"]).to(DEV)
+    labels = torch.from_numpy(inp["labels"]).to(DEV)
+    big = torch.randn(6144, 6144, device=DEV)
+    buckets = []
+    for busy in (False, True, True):
+        trainer.zero_grad()
+        kargs = to_dev(reference_kargs(inp, torch, output_ranking=False))
+        out = model(query, document, **kargs)
+        lossv = torch.nn.functional.cross_entropy(out, labels)
+        if busy:
+            torch.cuda.synchronize()
+            with torch.cuda.stream(ops.side_stream(DEV)):
+                for _ in range(40):
+                    big = (big @ big).clamp_(-1, 1)
+        lossv.backward()
+        buckets.append(trainer.flat_g.clone())          # caller's stream, no synchronize
+    torch.cuda.synchronize()
+    assert float(buckets[0].abs().max()) > 0
+    for b in buckets[1:]:
+        assert torch.equal(b, buckets[0])
+
+
+@pytest.mark.parametrize("trainer_bucket", [False, True])
+def test_frozen_article_source_table_keeps_every_other_gradient(trainer_bucket):
+    """evd_assemble_bwd takes the table width as the row pitch of its incoming gradient; with a frozen
+    article_source_embs (no table gradient wanted) the pitch used to collapse to the avg width and every slot after the
+    first read the wrong row.  Freezing the table must leave every other gradient exactly as it was."""
+    from get_amd import ops
+    from get_amd.dist import FlatTrainer
+    grads = {}
+    for frozen in (False, True):
+        cfg, model, inp, phi, ww, ew, loss = run_case("small", native_graphs="compact")
+        model.article_source_embs.weight.requires_grad_(not frozen)
+        if trainer_bucket:
+            FlatTrainer(model)
+            ops.bump_weight_epoch()
+        query = torch.from_numpy(inp["query"]).to(DEV)
+        document = torch.from_numpy(inp["document"]).to(DEV)
+        kargs = to_dev(reference_kargs(inp, torch, output_ranking=False))
+        out = model(query, document, **kargs)
+        torch.nn.functional.cross_entropy(out, torch.from_numpy(inp["labels"]).to(DEV)).backward()
+        torch.cuda.synchronize()
+        grads[frozen] = {k: p.grad.clone() for k, p in model.named_parameters()
+                         if p.grad is not None and p.requires_grad and float(p.grad.abs().max()) > 0}
+    assert "article_source_embs.weight" in grads[False] and "article_source_embs.weight" not in grads[True]
+    for k, g in grads[True].items():
+        assert torch.equal(g, grads[False][k]), k
+    assert len(grads[True]) == len(grads[False]) - 1
+
+
+def test_bump_weight_epoch_drops_frozen_derived_entries():
+    """a raw `.data` write followed by ops.bump_weight_epoch() must also refresh entries derived from tensors
+    the trainer never touches (the scorer's packed gates): the keep-sets have to follow the new scorer weights."""
+    from get_amd import ops
+    cfg, model, inp, phi, ww, ew, loss = run_case("small", native_graphs="compact")
+    s0 = model.ggnn_with_gsl.last_score.clone()
+    with torch.no_grad():
+        model.ggnn_with_gsl.word_scorer1.linearz0.linear.bias.data += 3.0        # raw write: no version bump
+    ops.bump_weight_epoch()
+    query = torch.from_numpy(inp["query"]).to(DEV)
+    document = torch.from_numpy(inp["document"]).to(DEV)
+    kargs = to_dev(reference_kargs(inp, torch, output_ranking=False))
+    with torch.no_grad():
+        model(query, document, **kargs)
+    assert not torch.equal(model.ggnn_with_gsl.last_score, s0), "the scorer still ran on its stale packed gates"
