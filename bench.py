@@ -4,6 +4,7 @@ on synthetic Snopes-shaped batches (BASELINE.json configs[1]: B=32 claims x 30 e
 D=H=300, 5 word heads / 2 evidence heads, window 3, gsl_rate 0.6, fp32).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...          # RANK unset: re-executes itself under torch.distributed.run, one rank per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -57,17 +58,22 @@ def flops_per_pair(cfg: SynthConfig, nnz_per_graph: float, real_nodes: float = N
 
 
 def build_workload(batch=32, n_evd=30, seed=20240229, device="cuda:0", cfg: SynthConfig = None, lr=1e-4, compact=None,
-                   n_batches=1, evd_dist="fixed"):
+                   n_batches=1, evd_dist="fixed", model_seed=None, claim_shard=None):
     """Model (random init, reference init scheme), `n_batches` distinct seeded synthetic batches resident on `device`
     (seed, seed + 1000, ...; the step loop rotates through them so that no per-batch cost hides behind one reused
     batch), and `oracle_slice(k)`: CPU-oracle results of the first k claims of batch 0.
-    evd_dist: "fixed" (cfg.n_evd per claim; <= 0 = U[1,30]) or "snopes" (empirical histogram, mean 6.9)."""
+    evd_dist: "fixed" (cfg.n_evd per claim; <= 0 = U[1,30]) or "snopes" (empirical histogram, mean 6.9).
+    model_seed: seed of the embeddings and the parameter init (default: `seed`); data-parallel ranks pass the SAME
+    model_seed and different data seeds, so that replicas are identical by construction.
+    claim_shard(counts) -> claim indices: this rank's shard of a GLOBAL batch of cfg.batch claims (strong scaling: every
+    rank generates the same global batch from `seed` and keeps its shard, dist.shard_claims)."""
     from get_amd import modules
     from get_amd.batch import NativeBatch
     from get_amd.synth import snopes_evidence_counts
     cfg = cfg or SynthConfig(batch=batch, n_evd=n_evd)
-    emb, art, clm = make_embeddings(cfg, seed)
-    torch.manual_seed(seed)
+    model_seed = seed if model_seed is None else model_seed
+    emb, art, clm = make_embeddings(cfg, model_seed)
+    torch.manual_seed(model_seed)
     model = modules.Graph_basedSemantiStructure(cfg.model_params(emb, art, clm)).to(device)
     raws, batches = [], []
     for i in range(max(1, n_batches)):
@@ -76,11 +82,15 @@ def build_workload(batch=32, n_evd=30, seed=20240229, device="cuda:0", cfg: Synt
             counts = snopes_evidence_counts(np.random.default_rng(seed + 1000 * i + 17), cfg.batch)
             c = SynthConfig(**{**cfg.__dict__, "evd_counts": [int(x) for x in counts]})
         raw = make_raw_batch(c, seed + 1000 * i)
+        if claim_shard is not None:
+            raw = subset_raw(raw, claim_shard(raw["evd_counts"]))
         raws.append(raw)
         batches.append(NativeBatch(raw["claim_tokens"], raw["claim_len"], raw["evd_tokens"], raw["evd_len"], raw["evd_counts"],
                                    raw["doc_sources"], raw["query_sources"], raw["labels"], window=cfg.window,
                                    n_max=cfg.fixed_num_evidences, device=device, compact=compact))
     raw, b0 = raws[0], batches[0]
+    if claim_shard is not None:
+        cfg = SynthConfig(**{**cfg.__dict__, "batch": b0.b, "evd_counts": None})
     query, document, kargs = b0.inputs()
     nnz = float(torch.count_nonzero(kargs["docs_adj"].to_dense()).item()) / max(b0.b1, 1)
 
@@ -104,10 +114,94 @@ def build_workload(batch=32, n_evd=30, seed=20240229, device="cuda:0", cfg: Synt
             out["keep"] = res[3]["keep"]
         return out
 
-    return dict(cfg=cfg, model=model, raw=raw, batches=batches, oracle_slice=oracle_slice, nnz_per_graph=nnz,
+    return dict(cfg=cfg, model=model, raw=raw, raws=raws, batches=batches, oracle_slice=oracle_slice, nnz_per_graph=nnz,
                 query=query, document=document, kargs=kargs, labels=b0.labels, make_inputs=b0.inputs,
                 compact=b0.compact, b1=sum(b.b1 for b in batches) / len(batches), b1_each=[b.b1 for b in batches],
                 m_real=sum(b.m_real for b in batches) / len(batches))
+
+
+def subset_raw(raw: dict, claims) -> dict:
+    """The claims `claims` (ascending indices) of a raw batch, evidences kept claim-major."""
+    cl = np.asarray(list(claims), dtype=np.int64)
+    counts = raw["evd_counts"]
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    rows = np.concatenate([np.arange(offs[c], offs[c + 1]) for c in cl]) if len(cl) else np.zeros((0,), np.int64)
+    return dict(claim_tokens=raw["claim_tokens"][cl], claim_len=raw["claim_len"][cl], evd_tokens=raw["evd_tokens"][rows],
+                evd_len=raw["evd_len"][rows], evd_counts=counts[cl], doc_sources=raw["doc_sources"][cl],
+                query_sources=raw["query_sources"][cl], labels=raw["labels"][cl])
+
+
+class ReferenceApiBatch:
+    """What the UNCHANGED fitter holds on the device before its de-padding loop (char_man_fitter_query_repr1.py:92-107,
+    196-223): padded (B,n,R) node ids, dense float64 (B,n,R,R) evidence adjacency and (B,L,L) claim adjacency
+    (handlers/mz_sampler.py:146-160), counts, sources.  inputs() runs the compatibility shim
+    (batch.kargs_from_reference_tensors: one mask gather instead of the per-claim loop); the model then packs the dense
+    adjacency on the device (PackedAdj.from_dense) and runs the reference's padded layout."""
+
+    def __init__(self, nb):
+        from get_amd import ops
+        b, n, r = nb.b, nb.n_max, nb.evd_tokens.shape[1]
+        qa, q_ids, q_n = ops.graph_build(nb.claim_tokens, nb.claim_len, nb.window)
+        da, d_ids, d_n = ops.graph_build(nb.evd_tokens, nb.evd_len, nb.window)
+        dev = nb.device
+        self.query = q_ids.long()
+        self.query_lens = q_n.long()
+        self.query_adj = qa.to_dense().double()
+        self.doc_ids = torch.zeros((b * n, r), device=dev, dtype=torch.int64)
+        self.doc_ids.index_copy_(0, nb._slot, d_ids.long())
+        self.doc_ids = self.doc_ids.view(b, n, r)
+        adj = torch.zeros((b * n, r, r), device=dev, dtype=torch.float64)
+        adj.index_copy_(0, nb._slot, da.to_dense().double())
+        self.docs_adj = adj.view(b, n, r, r)
+        self.counts, self.doc_sources, self.query_sources, self.labels = nb.counts, nb.doc_sources, nb.query_sources, nb.labels
+        self.b, self.b1, self.n_max = b, nb.b1, n
+        self.bytes_handed_over = sum(t.numel() * t.element_size() for t in
+                                     (self.query, self.query_adj, self.doc_ids, self.docs_adj, self.counts, self.doc_sources))
+
+    def inputs(self):
+        from get_amd.batch import kargs_from_reference_tensors
+        kargs = kargs_from_reference_tensors(self.query_lens, self.doc_ids, self.docs_adj, self.query_adj, self.counts,
+                                             self.doc_sources, self.query_sources, n_max=self.n_max)
+        return self.query, self.doc_ids, kargs
+
+
+class StreamedBatches:
+    """A fresh NativeBatch per step from HOST arrays: H2D of the token ids / counts / sources (one packed pinned buffer),
+    the device graph build that counts the nodes and the 4-byte m_real read-back (get_amd/batch.py), built ONE batch
+    ahead on a side stream while the previous step's launches run (take() ... issue the step ... prefetch())."""
+
+    def __init__(self, raws, cfg, device, compact):
+        self.raws, self.cfg, self.device, self.compact = raws, cfg, torch.device(device), compact
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.i = 0
+        self.ready = None
+        self._prepare()
+
+    def _prepare(self):
+        from get_amd.batch import NativeBatch
+        raw = self.raws[self.i % len(self.raws)]
+        self.i += 1
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            nb = NativeBatch(raw["claim_tokens"], raw["claim_len"], raw["evd_tokens"], raw["evd_len"], raw["evd_counts"],
+                             raw["doc_sources"], raw["query_sources"], raw["labels"], window=self.cfg.window,
+                             n_max=self.cfg.fixed_num_evidences, device=self.device, compact=self.compact, pinned=True)
+        self.ready = (nb, self.stream.record_event())
+
+    def take(self):
+        """The batch prepared during the previous step (the current stream waits for its copies / graph build)."""
+        nb, ev = self.ready
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(ev)
+        for t in nb.device_tensors():          # allocated on the side stream, consumed on the caller's
+            t.record_stream(main)
+        self.ready = None
+        return nb
+
+    def prefetch(self):
+        """Call AFTER the step's launches are issued: the host then blocks on the next batch's 4-byte read-back while the
+        device is busy with the step."""
+        self._prepare()
 
 
 def box_reference(device):
@@ -222,17 +316,27 @@ def cpu_baseline_probe(wl, budget_s=8.0, claims=2):
                       f"in {dt:.1f} s, best torch pool size of a 8..128 probe"}
 
 
-def measure(args, wl, trainer, world, device, dist, steps, warmup, profile=True):
-    """W warm-up + K timed steps (barrier + synchronize on both sides) of the rotating resident batches; returns
-    (seconds, last loss, dominant-kernel profile row or None)."""
-    from get_amd import _lib
+MIN_TIMED_SECONDS = 2.0        # the K-step block is repeated until the timed region is at least this long
+MAX_TIMED_BLOCKS = 64
+
+
+def make_step(args, wl, trainer, source="resident"):
+    """One training step over the next batch.  source: "resident" (rotating resident NativeBatches -- the headline),
+    "reference" (ReferenceApiBatch: dense float64 hand-over, padded layout) or "streamed" (StreamedBatches: a fresh
+    NativeBatch per step, H2D + read-back included).  Returns (step_fn, pairs_fn) -- pairs_fn() = pairs of the steps
+    issued since its last call."""
     model = wl["model"]
-    batches = wl["batches"]
-    state = {"i": 0}
+    state = {"i": 0, "pairs": 0}
+    batches = wl["ref_batches"] if source == "reference" else wl["batches"]
+    streamed = wl.get("streamed") if source == "streamed" else None
 
     def step():
-        b = batches[state["i"] % len(batches)]
+        if streamed is not None:
+            b = streamed.take()
+        else:
+            b = batches[state["i"] % len(batches)]
         state["i"] += 1
+        state["pairs"] += b.b1
         if args.forward_only:
             with torch.no_grad():
                 query, document, kargs = b.inputs()
@@ -243,36 +347,71 @@ def measure(args, wl, trainer, world, device, dist, steps, warmup, profile=True)
         loss = torch.nn.functional.cross_entropy(phi, b.labels)
         loss.backward()
         trainer.step()
+        if streamed is not None:
+            streamed.prefetch()
         return loss
+
+    def pairs():
+        p, state["pairs"] = state["pairs"], 0
+        return p
+
+    return step, pairs
+
+
+def measure(args, wl, trainer, world, device, dist, steps, warmup, profile=True, source="resident",
+            min_seconds=MIN_TIMED_SECONDS):
+    """W warm-up steps, then blocks of EXACTLY K timed steps, each block bracketed by barrier + synchronize on both sides
+    and reduced with MAX over the ranks; the block is repeated until the timed region covers `min_seconds` (the number
+    of repeats is fixed from the first block's duration, identically on every rank).  Returns a dict: the per-block
+    seconds, the pairs this rank processed per block, the last loss, the dominant-kernel profile row and the step fn."""
+    from get_amd import _lib
+    step, pairs_fn = make_step(args, wl, trainer, source)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def rank_max(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     for _ in range(warmup):
         step()
+    pairs_fn()
     prof_dom = None
-    # live roofline of the dominant kernel: HIP events around each of its launches in the FIRST `prof_steps` of the timed
-    # steps (an event pair between two kernels costs ~10 us of dispatch overlap: on every launch of every timed step that
-    # was 1.7 % of the reported throughput; on a quarter of the steps it is 0.4 %)
+    # live roofline of the dominant kernel: HIP events around each of its launches in the FIRST `prof_steps` timed steps
+    # of the first block (an event pair between two kernels costs ~10 us of dispatch overlap: 0.4 % of those steps)
     prof_steps = min(steps, max(1, PROFILE_TIMED_STEPS)) if profile else 0
     if profile:
         _lib.profile_enable(True, only=[DOMINANT])
         _lib.profile_collect()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        if profile and i == prof_steps:
-            _lib.profile_enable(False)       # host-side switch, no device work
-        loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if profile:
-        prof_dom = _lib.profile_collect()[DOMINANT]
-        prof_dom["steps"] = prof_steps
-        _lib.profile_enable(False)
-    return dt, loss, prof_dom, step
+    blocks, block_pairs = [], []
+    n_blocks = 1
+    loss = None
+    b = 0
+    while b < n_blocks:
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if profile and b == 0 and i == prof_steps:
+                _lib.profile_enable(False)       # host-side switch, no device work
+            loss = step()
+        barrier()
+        dt = rank_max(time.perf_counter() - t0)
+        blocks.append(dt)
+        block_pairs.append(pairs_fn())
+        if b == 0:
+            if profile:
+                prof_dom = _lib.profile_collect()[DOMINANT]
+                prof_dom["steps"] = prof_steps
+                _lib.profile_enable(False)
+            n_blocks = int(min(MAX_TIMED_BLOCKS, max(1, np.ceil(min_seconds / max(dt, 1e-6)))))
+        b += 1
+    return {"blocks_s": blocks, "block_pairs": block_pairs, "loss": loss, "prof_dom": prof_dom, "step": step}
 
 
 def phase_split(wl, trainer, steps=5):
@@ -336,6 +475,46 @@ DOMINANT = "gemm_big"
 PROFILE_TIMED_STEPS = 5           # timed steps whose dominant-kernel launches carry HIP events
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def spawn_ranks(n_gpus: int) -> int:
+    """`python bench.py --gpus N` with RANK unset: run this very command line under torch.distributed.run, one rank per
+    GPU of this node (RCCL needs one device per rank: fewer visible GPUs than ranks is an error, not a silent 1-rank run)."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        sys.stderr.write(f"bench.py: --gpus {n_gpus} needs {n_gpus} visible GPUs, this node shows {have}; RCCL runs one rank per "
+                         f"device, so the {n_gpus}-rank measurement cannot be taken here (no line printed).\n")
+        return 3
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def summarize_blocks(m, steps, world_pairs_per_block):
+    """Median block -> value / ms_per_step; spread over the blocks."""
+    secs = np.asarray(m["blocks_s"], dtype=np.float64)
+    rates = np.asarray(world_pairs_per_block, dtype=np.float64) / secs
+    med = float(np.median(rates))
+    k = int(np.argmin(np.abs(rates - med)))
+    return {"value": med, "ms_per_step": 1e3 * float(secs[k]) / steps,
+            "timed": {"blocks": int(len(secs)), "steps_per_block": int(steps), "seconds_total": float(secs.sum()),
+                      "pairs_per_s_min": float(rates.min()), "pairs_per_s_median": med, "pairs_per_s_max": float(rates.max()),
+                      "spread_rel": float((rates.max() - rates.min()) / med) if med > 0 else None,
+                      "note": f"the {steps}-step block (barrier + synchronize on both sides, MAX over ranks) is repeated "
+                              f"until >= {MIN_TIMED_SECONDS:g} s are timed; value = median block"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -343,7 +522,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="claims per GPU (weak scaling: fixed per-GPU work)")
     ap.add_argument("--global-batch", type=int, default=0,
-                    help="fixed GLOBAL claim count, split evenly over the ranks (SURVEY 8(e): 256 -> 256/N per GPU; strong scaling)")
+                    help="fixed GLOBAL claim count, split evenly over the ranks (SURVEY 8(e): 256 -> 256/N per GPU; strong "
+                         "scaling); ragged evidence counts are balanced by sort-then-stripe (dist.shard_claims)")
     ap.add_argument("--n-evd", type=int, default=30, help="evidences per claim (<=0: ragged U[1,30])")
     ap.add_argument("--evd-dist", choices=["fixed", "snopes"], default="fixed",
                     help="snopes: evidence counts from the empirical Snopes histogram (mean 6.9, the realistic series)")
@@ -360,22 +540,54 @@ def main():
                     help="auxiliary serving measurement: evaluation-mode forward only (not the headline metric)")
     ap.add_argument("--padded", action="store_true",
                     help="run every layer on all R padded node rows (the reference's layout) instead of the node-compact one")
+    ap.add_argument("--reference-api", action="store_true",
+                    help="ALSO time the path an unchanged fitter drives: dense float64 (B,n,R,R) adjacency handed over per step "
+                         "through batch.kargs_from_reference_tensors, packed on the device, padded layout (printed beside the headline)")
+    ap.add_argument("--streamed", action="store_true",
+                    help="ALSO time a fresh NativeBatch per step (H2D of the ids + m_real read-back, one batch ahead on a side stream)")
+    ap.add_argument("--no-side-modes", action="store_true", help="skip the --reference-api / --streamed legs the headline run adds by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-series", action="store_true", help="skip the realistic evidence-count series")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (default: the probe's fastest pool size)")
+    ap.add_argument("--measure-build", action="store_true",
+                    help="kernel A/B tooling only: load lib/libget_hip_measure.so (make -C get_amd/csrc measure), honour the GH_* "
+                         "switches, and stamp the line as NOT a product measurement")
     args = ap.parse_args()
+
+    # measurement switches of the library (GH_*) change what the kernels compute or how they are scheduled: a bench line
+    # taken with one set is not a measurement of the product.  (The shipped .so ignores them -- they only exist in the
+    # -DGH_MEASURE tool build -- but a GET_AMD_LIB override could point at such a build.)
+    leaked = sorted(k for k in os.environ if k.startswith("GH_"))
+    if args.measure_build:
+        os.environ["GET_AMD_LIB"] = os.path.join(ROOT, "get_amd", "lib", "libget_hip_measure.so")
+        from get_amd import _lib as _l
+        _l.LIB_PATH = os.environ["GET_AMD_LIB"]
+    elif leaked or os.environ.get("GET_AMD_LIB"):
+        sys.stderr.write(f"bench.py: refusing to run with measurement switches in the environment: {leaked + (['GET_AMD_LIB'] if os.environ.get('GET_AMD_LIB') else [])}\n")
+        sys.exit(4)
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}; refusing to print a line whose "
+                         "n_gpus is not the number of ranks that ran\n")
+        sys.exit(5)
+    backend = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # GET_AMD_BENCH_BACKEND=gloo: rehearsal of the N>1 code path on a box with fewer GPUs than ranks (ranks share
         # devices, the all-reduce goes through the host).  The real run is one rank per GPU over RCCL ("nccl").
         backend = os.environ.get("GET_AMD_BENCH_BACKEND", "nccl")
+        if backend == "nccl" and torch.cuda.device_count() < world:
+            sys.stderr.write(f"bench.py: {world} RCCL ranks need {world} GPUs, {torch.cuda.device_count()} visible\n")
+            sys.exit(3)
         local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
@@ -384,7 +596,6 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
-    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     device = f"cuda:{local_rank if world > 1 else 0}"
 
     from get_amd import _lib
@@ -392,26 +603,31 @@ def main():
     _lib.load()
     _lib.set_gemm_mode(args.gemm_mode)
 
+    SEED = 20240229
     per_rank = args.batch
+    shard = None
     if args.global_batch > 0:
-        per_rank = len(shard_claims(args.global_batch, rank, world))
-    cfg_in = SynthConfig(batch=per_rank, n_evd=args.n_evd, len_right=args.len_right, hidden=args.hidden, emb_dim=args.hidden,
-                         word_heads=args.word_heads, window=args.window, gsl_rate=args.gsl_rate)
-    wl = build_workload(seed=20240229 + rank, device=device, cfg=cfg_in, compact=False if args.padded else None,
-                        n_batches=args.batches, evd_dist=args.evd_dist)
+        # strong scaling: ONE global batch (same seed on every rank), claims dealt by sort-then-stripe on their evidence counts
+        per_rank = args.global_batch // world
+        shard = (lambda counts: shard_claims(args.global_batch, rank, world, counts))
+    cfg_in = SynthConfig(batch=args.global_batch if shard else per_rank, n_evd=args.n_evd, len_right=args.len_right,
+                         hidden=args.hidden, emb_dim=args.hidden, word_heads=args.word_heads, window=args.window,
+                         gsl_rate=args.gsl_rate)
+    # replicas are identical by construction (model_seed is rank-independent); the data seed differs per rank (weak scaling)
+    wl = build_workload(seed=SEED + (0 if shard else rank), device=device, cfg=cfg_in, compact=False if args.padded else None,
+                        n_batches=args.batches, evd_dist=args.evd_dist, model_seed=SEED, claim_shard=shard)
     model, cfg = wl["model"], wl["cfg"]
-    if world > 1:      # identical replicas: broadcast rank 0's parameters
-        for p in model.parameters():
-            dist.broadcast(p.data, src=0)
     trainer = FlatTrainer(model, lr=1e-4, weight_decay=1e-3)
     from get_amd import ops
     ops.bump_weight_epoch()            # parameters were (re)written through .data: drop cached transposes
     if world > 1:
-        trainer.attach_overlap()     # 76 % of the gradient all-reduce runs underneath the first cell's backward
+        trainer.broadcast_parameters(0)      # two collectives (flat bucket + everything outside it), not one per tensor
+        trainer.attach_overlap()             # 76 % of the gradient all-reduce runs underneath the first cell's backward
     model.train(not (args.eval_mode or args.forward_only))
 
-    dt, loss, prof_dom, step = measure(args, wl, trainer, world, device, dist, args.steps, args.warmup,
-                                       profile=not args.no_profile)
+    m = measure(args, wl, trainer, world, device, dist, args.steps, args.warmup, profile=not args.no_profile)
+    loss, prof_dom, step = m["loss"], m["prof_dom"], m["step"]
+    comm_bytes_step = trainer.comm_bytes / max(1, (args.warmup + args.steps * len(m["blocks_s"])))
     prof = None
     PROFILE_EXTRA_STEPS = 5
     if not args.no_profile:
@@ -423,21 +639,20 @@ def main():
         prof = _lib.profile_collect()
         _lib.profile_enable(False)
     split = None if args.forward_only else phase_split(wl, trainer)      # collective inside: every rank runs it
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-    pairs_done = sum(wl["b1_each"][i % len(wl["b1_each"])] for i in range(args.warmup, args.warmup + args.steps))
-    cnt = torch.tensor([float(pairs_done), float(cfg.batch * args.steps)], device=device, dtype=torch.float64)
+    # whole-job pairs per block: sum over the ranks (the per-block seconds are already MAX over ranks)
+    bp = torch.tensor(m["block_pairs"] + [float(cfg.batch * args.steps)], device=device, dtype=torch.float64)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
-    total_pairs, total_claims = float(cnt[0].item()), float(cnt[1].item())
+        dist.all_reduce(bp, op=dist.ReduceOp.SUM)
+    world_pairs = [float(x) for x in bp[:-1].tolist()]
+    total_claims_block = float(bp[-1].item())
 
-    if rank == 0:
-        ms_per_step = 1e3 * dt / args.steps
-        value = total_pairs / dt
-        headline = (args.len_right, args.hidden, args.word_heads, args.window, args.gsl_rate, args.n_evd, args.evd_dist) == \
+    headline_run = (args.len_right, args.hidden, args.word_heads, args.window, args.gsl_rate, args.n_evd, args.evd_dist) == \
                    (100, 300, 5, 3, 0.6, 30, "fixed") and per_rank == 32 and args.gemm_mode == "fp32" and not args.padded \
                    and not args.eval_mode and not args.forward_only
+    if rank == 0:
+        summ = summarize_blocks(m, args.steps, world_pairs)
+        value, ms_per_step = summ["value"], summ["ms_per_step"]
+        headline = headline_run
         real_nodes = wl["m_real"] / max(wl["b1"], 1)
         fl = flops_per_pair(cfg, wl["nnz_per_graph"], real_nodes if wl["compact"] else None)
         fl_run = fl.get("executed", fl["fwd_bwd"])
@@ -450,7 +665,14 @@ def main():
             "higher_is_better": True, "scaling": "strong" if args.global_batch > 0 else "weak", "vs_baseline": None,
             "dtype": "f32" if args.gemm_mode == "fp32" else "bf16 operands / f32 accumulate in the big GEMMs, f32 elsewhere",
             "data": "synthetic",
-            "claims_per_s": total_claims / dt,
+            "claims_per_s": total_claims_block * value / max(float(np.median(world_pairs)), 1.0),
+            "timed": summ["timed"],
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "collective": {"backend": backend, "allreduce_bytes_per_step_per_rank": comm_bytes_step,
+                           "allreduce_ms_per_step": (split or {}).get("allreduce_ms"),
+                           "calls_per_step": trainer.comm_calls / max(1, (args.warmup + args.steps * len(m["blocks_s"]))),
+                           "note": "one flat fp32 gradient bucket; the early-final range (head, attentions, second cell) is "
+                                   "reduced asynchronously underneath the first cell's backward, the rest after backward"},
             "config": {"workload": ("BASELINE configs[1]: Snopes-shaped synthetic batch, " if headline
                                     else "non-headline shape (see flags): synthetic batch, ") +
                                    f"B={cfg.batch} claims x {evd_txt} evidences per GPU "
@@ -466,6 +688,8 @@ def main():
                                  else "padded: every layer on all R node rows (reference layout)",
                        "parallelism": f"dp{world}", "pairs_per_gpu": wl["b1"],
                        "global_batch_claims": cfg.batch * world if args.global_batch <= 0 else args.global_batch,
+                       "sharding": ("sort-then-stripe by evidence count (dist.shard_claims)" if shard else
+                                    "one independent batch per rank (weak scaling)"),
                        "loss": float(loss.item())},
             "path_tflops": {"flops_per_pair_executed": fl_run, "flops_per_pair_padded_form": fl["fwd_bwd"],
                             "achieved_tflops_per_gpu": fl_run * value / world / 1e12,
@@ -501,18 +725,21 @@ def main():
                  "avg_launch_ms": prof_dom["ms"] / prof_dom["launches"], "launches_per_step": prof_dom["launches"] / prof_dom["steps"]}
             # HBM bytes per launch from the committed rocprofv3 PMC passes -- only for the invocation they were measured
             # on (the headline shape); any other shape reports null rather than a number that belongs to another run
-            traffic = None
+            traffic, traffic_src = None, None
             if headline and world == 1:
                 try:
-                    pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[dom]
+                    pmj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                    pm = pmj[dom]
                     traffic = (pm["fetch_kib"] * pm["fetch_correction"] + pm["write_kib"]) * 1024.0
+                    traffic_src = pmj.get("_source")
                 except Exception:
                     traffic = None
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["achieved_tflops"],
                                "peak": dom_peak, "unit": "TFLOP/s", "frac": d["frac"], "traffic": traffic,
+                               "traffic_source": traffic_src,
                                "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_per_step"],
                                "alg_flops_per_launch": prof_dom["work"] / prof_dom["launches"],
-                               "measured": f"HIP events around every {dom} launch of the first {prof_dom['steps']} of the {args.steps} timed steps"}
+                               "measured": f"HIP events around every {dom} launch of the first {prof_dom['steps']} timed steps"}
             if dom_note:
                 out["roofline"]["note"] = dom_note
             out["kernels_note"] = (f"per-kernel table from {PROFILE_EXTRA_STEPS} extra untimed steps with every library "
@@ -522,21 +749,57 @@ def main():
             out["step_split_ms"] = split
         if not args.no_profile and world == 1:
             out["box_reference"] = box_reference(device)
+    default_side = (world == 1 and headline_run and not args.no_side_modes and not args.no_series)
+    do_ref = world == 1 and not args.forward_only and (args.reference_api or default_side)
+    do_stream = world == 1 and not args.forward_only and (args.streamed or default_side)
+    if (do_ref or do_stream) and rank == 0:
+        # VERDICT r2 item 8 -- the two regimes no headline line covers, printed beside it (single GPU):
+        #   reference_api: what an UNCHANGED fitter hands over (dense f64 adjacency, resident on the device when the timed
+        #                  region starts; the PCIe-inclusive figure adds bytes / 63 GB/s per step, stated)
+        #   streamed     : a new batch per step from host arrays (H2D of ids + the m_real read-back), one batch ahead
+        extra = {}
+        if do_ref:
+            wl["ref_batches"] = [ReferenceApiBatch(b) for b in wl["batches"][:2]]
+            mr = measure(args, wl, trainer, 1, device, dist, max(4, args.steps // 2), 3, profile=False, source="reference",
+                         min_seconds=1.0)
+            sr = summarize_blocks(mr, max(4, args.steps // 2), mr["block_pairs"])
+            hb = wl["ref_batches"][0].bytes_handed_over
+            extra["reference_api"] = {"pairs_per_s": sr["value"], "ms_per_step": sr["ms_per_step"],
+                                      "bytes_handed_over_per_step": hb,
+                                      "pairs_per_s_if_shipped_over_pcie_63GBps": wl["ref_batches"][0].b1 / (sr["ms_per_step"] * 1e-3 + hb / 63e9),
+                                      "what": "dense float64 (B,n,R,R) adjacency + padded ids resident in HBM -> kargs_from_reference_tensors "
+                                              "(one mask gather) -> PackedAdj.from_dense on the device -> padded layout; same model, "
+                                              "same optimiser step (mz_sampler.py:146-160, char_man_fitter_query_repr1.py:92-107,204-250)"}
+            del wl["ref_batches"]
+            torch.cuda.empty_cache()
+        if do_stream:
+            raws8 = wl["raws"] + [make_raw_batch(cfg, SEED + 1000 * (len(wl["raws"]) + i)) for i in range(4)]
+            wl["streamed"] = StreamedBatches(raws8, cfg, device, wl["compact"])
+            ms_ = measure(args, wl, trainer, 1, device, dist, args.steps, 3, profile=False, source="streamed", min_seconds=1.0)
+            ss = summarize_blocks(ms_, args.steps, ms_["block_pairs"])
+            extra["streamed"] = {"pairs_per_s": ss["value"], "ms_per_step": ss["ms_per_step"],
+                                 "what": "a NEW NativeBatch per step from host numpy arrays: one pinned staging buffer -> one H2D copy, "
+                                         "device graph build for the node count, 4-byte m_real read-back; prepared one batch ahead "
+                                         "on a side stream while the previous step runs (8 distinct host batches rotated)"}
+            del wl["streamed"]
+        out["other_regimes"] = extra
+    if rank == 0:
         if world == 1 and not args.no_series and not args.forward_only and args.evd_dist == "fixed" and headline:
             # SURVEY 8(d) "realistic series": evidence counts from the empirical Snopes histogram (mean 6.9 per claim);
             # at B = 32 that is ~220 pairs per step, at B = 139 about the headline's 960
             series = []
             for bsz in (32, 139):
                 c2 = SynthConfig(**{**cfg.__dict__, "batch": bsz})
-                w2 = build_workload(seed=20240229, device=device, cfg=c2, n_batches=args.batches, evd_dist="snopes")
+                w2 = build_workload(seed=SEED, device=device, cfg=c2, n_batches=args.batches, evd_dist="snopes")
                 w2["model"].train(True)
                 t2 = FlatTrainer(w2["model"], lr=1e-4, weight_decay=1e-3)
                 ops.bump_weight_epoch()
-                S_W, S_K = 8, 30        # (3 + 10 steps were too few for a fresh model: allocator / workspace warm-up leaked in)
-                dt2, _, _, _ = measure(args, w2, t2, 1, device, dist, S_K, S_W, profile=False)
-                done = sum(w2["b1_each"][i % len(w2["b1_each"])] for i in range(S_W, S_W + S_K))
-                series.append({"claims": bsz, "pairs_per_step": w2["b1"], "pairs_per_s": done / dt2,
-                               "claims_per_s": bsz * S_K / dt2, "ms_per_step": 1e3 * dt2 / S_K})
+                S_W, S_K = 8, 32        # (3 + 10 steps were too few for a fresh model: allocator / workspace warm-up leaked in)
+                m2 = measure(args, w2, t2, 1, device, dist, S_K, S_W, profile=False, min_seconds=1.0)
+                s2 = summarize_blocks(m2, S_K, m2["block_pairs"])
+                series.append({"claims": bsz, "pairs_per_step": w2["b1"], "pairs_per_s": s2["value"],
+                               "claims_per_s": s2["value"] * bsz / w2["b1"], "ms_per_step": s2["ms_per_step"],
+                               "blocks": s2["timed"]["blocks"], "spread_rel": s2["timed"]["spread_rel"]})
                 del w2, t2
             ops.bump_weight_epoch()
             out["realistic_series"] = {"evidence_counts": "empirical Snopes histogram (get_amd.synth.SNOPES_EVD_HIST, mean 6.9, max 26)",
@@ -548,6 +811,9 @@ def main():
             cb["speedup_gpu_over_cpu"] = value / cb["value"]
             out["cpu_baseline"] = cb
             out["cpu_baseline_probe"] = probe
+        if args.measure_build:
+            out["metric"] = "MEASUREMENT BUILD (not a product number): " + out["metric"]
+            out["measurement_switches"] = {k: os.environ[k] for k in leaked}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

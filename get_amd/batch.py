@@ -28,23 +28,50 @@ class NativeBatch:
     """
 
     def __init__(self, claim_tokens, claim_len, evd_tokens, evd_len, evd_counts, doc_sources, query_sources, labels,
-                 window: int, n_max: int = 30, device="cuda:0", compact: bool = None):
+                 window: int, n_max: int = 30, device="cuda:0", compact: bool = None, pinned: bool = False):
         dev = torch.device(device)
-        t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a).to(dev)
         counts_host = np.asarray(evd_counts.cpu() if torch.is_tensor(evd_counts) else evd_counts, dtype=np.int64)
         self.window, self.n_max, self.device = int(window), int(n_max), dev
-        self.claim_tokens, self.claim_len = t(claim_tokens).int(), t(claim_len).int()
-        self.evd_tokens, self.evd_len = t(evd_tokens).int(), t(evd_len).int()
-        self.counts = t(counts_host)
         self._counts_host = counts_host
-        self.doc_sources, self.query_sources, self.labels = t(doc_sources), t(query_sources), t(labels)
         self.b, self.b1 = int(counts_host.shape[0]), int(counts_host.sum())
-        assert self.evd_tokens.shape[0] == self.b1, "evd_tokens must hold sum(evd_counts) rows"
         assert counts_host.max(initial=0) <= self.n_max
         # slot of every pair inside the (B, n_max, R) padded evidence tensor -- host arithmetic, done once
         offs = np.concatenate([[0], np.cumsum(counts_host)])[:-1]
         p2c = np.repeat(np.arange(self.b), counts_host)
-        self._slot = t((p2c * self.n_max + (np.arange(self.b1) - offs[p2c])).astype(np.int64))
+        slot = (p2c * self.n_max + (np.arange(self.b1) - offs[p2c])).astype(np.int64)
+        host = [np.ascontiguousarray(counts_host), slot, doc_sources, query_sources, labels,
+                (claim_tokens, np.int32), (claim_len, np.int32), (evd_tokens, np.int32), (evd_len, np.int32)]
+        if pinned and not any(torch.is_tensor(x[0] if isinstance(x, tuple) else x) for x in host):
+            # streaming loaders: every host array goes into ONE pinned staging buffer (8-byte items first, 16-byte
+            # aligned pieces) and crosses PCIe as one asynchronous copy; the tensors below are views of its device twin
+            arrs = []
+            for x in host:
+                a, dt = x if isinstance(x, tuple) else (x, np.int64)
+                arrs.append(np.ascontiguousarray(np.asarray(a), dtype=dt))
+            offs_b, total = [], 0
+            for a in arrs:
+                offs_b.append(total)
+                total += (a.nbytes + 15) // 16 * 16
+            stage = torch.empty(max(total, 16), dtype=torch.uint8, pin_memory=True)
+            sn = stage.numpy()
+            for a, o in zip(arrs, offs_b):
+                sn[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+            devbuf = stage.to(dev, non_blocking=True)
+            self._stage = stage            # keep the pinned buffer alive until the copy has been consumed
+            views = []
+            for a, o in zip(arrs, offs_b):
+                tdt = torch.int64 if a.dtype == np.int64 else torch.int32
+                views.append(devbuf[o:o + a.nbytes].view(tdt).view(a.shape))
+            (self.counts, self._slot, self.doc_sources, self.query_sources, self.labels, self.claim_tokens, self.claim_len,
+             self.evd_tokens, self.evd_len) = views
+        else:
+            t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a).to(dev)
+            self.claim_tokens, self.claim_len = t(claim_tokens).int(), t(claim_len).int()
+            self.evd_tokens, self.evd_len = t(evd_tokens).int(), t(evd_len).int()
+            self.counts = t(counts_host)
+            self.doc_sources, self.query_sources, self.labels = t(doc_sources), t(query_sources), t(labels)
+            self._slot = t(slot)
+        assert self.evd_tokens.shape[0] == self.b1, "evd_tokens must hold sum(evd_counts) rows"
         # node-compact layout (ops.RaggedPlan): the host has to know the total number of real evidence nodes, i.e.
         # the unique tokens per evidence -- what convert_text returns as `length_` (interactions.py:351) at load time
         if compact is None:
@@ -77,6 +104,11 @@ class NativeBatch:
         }
         return q_ids, document.view(self.b, self.n_max, r), kargs
 
+
+    def device_tensors(self):
+        """Every device tensor this batch owns (stream hand-over: `t.record_stream(consumer_stream)`)."""
+        return [t for t in (self.counts, self._slot, self.doc_sources, self.query_sources, self.labels, self.claim_tokens,
+                            self.claim_len, self.evd_tokens, self.evd_len) if torch.is_tensor(t) and t.is_cuda]
 
     def subset(self, lo: int, hi: int) -> "NativeBatch":
         """Claims [lo, hi) of this batch as a batch of their own (device-side slices; evaluation in chunks)."""

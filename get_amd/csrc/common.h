@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace gh {
@@ -29,6 +30,24 @@ void set_error(const char* fmt, ...);
 #define GH_LAUNCH_CHECK() GH_CHECK_HIP(hipGetLastError())
 
 inline int words_for(int r) { return (r + 63) / 64; }
+
+// Measurement switches (environment variables GH_*: kernel-variant A/B runs, timing-only modes that skip the K loop or
+// the epilogue) exist ONLY in the tool build (`make measure` -> -DGH_MEASURE, lib/libget_hip_measure.so).  The shipped
+// library never reads the environment: a stray GH_DBG cannot turn results silently wrong.
+inline int measure_env(const char* name, int dflt) {
+#ifdef GH_MEASURE
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
+}
+#ifdef GH_MEASURE
+#define GH_DBG_BITS(L) ((L).dbg)
+#else
+#define GH_DBG_BITS(L) 0
+#endif
 
 // Optional per-kernel timing with HIP events on the launch stream (bench.py's live roofline numbers).
 // Tags index the rows gh_profile_collect() returns; `work` is the launch's algorithmic flops (GEMMs)

@@ -21,6 +21,7 @@
 //     epilogue accesses (16 rows x 64 B per instruction) ran the same streams at 3.8 TB/s, whole rows at 6.7 TB/s;
 //     row reductions (attention head scores, the GSL scorer's projection) re-read the finished rows from LDS.
 #pragma once
+#include "common.h"
 #include "gemm.hip.h"
 
 namespace gh {
@@ -88,11 +89,13 @@ gemm_nt_kernel(const Launch L_byval) {
   const int m0 = m_tile * BM;
   if (m0 >= M) return;
 
-  // measurement switches: static wave priority per workgroup class, so that co-resident workgroups drift out of phase
-  if (L.dbg & 4) {
+  // measurement switches (tool build only, common.h): static wave priority per workgroup class, so that co-resident
+  // workgroups drift out of phase
+  const int dbg_bits = GH_DBG_BITS(L);
+  if (dbg_bits & 4) {
     const int cls = ((bid >> 3) >> 5) % 3;
     if (cls == 0) __builtin_amdgcn_s_setprio(2); else if (cls == 1) __builtin_amdgcn_s_setprio(1);
-  } else if (L.dbg & 8) {
+  } else if (dbg_bits & 8) {
     const int cls = (bid >> 3) % 3;
     if (cls == 0) __builtin_amdgcn_s_setprio(2); else if (cls == 1) __builtin_amdgcn_s_setprio(1);
   }
@@ -117,7 +120,7 @@ gemm_nt_kernel(const Launch L_byval) {
   // the node-compact layout): start at the first tile of segment 1
   const int toff = (nseg > 1 && P.seg0_rows > 0 && m0 >= P.seg0_rows && !split) ? nt0 : 0;
   const int T_all = nt0 + (nseg > 1 ? (K1 + BK - 1) / BK : 0) - toff;
-  int tbeg = 0, tend = (L.dbg & 2) ? 1 : T_all;
+  int tbeg = 0, tend = (dbg_bits & 2) ? 1 : T_all;
   if (split) {
     const int ct = L.kchunk / BK;
     tbeg = ks * ct;
@@ -349,7 +352,7 @@ gemm_nt_kernel(const Launch L_byval) {
   // is float4 (row i / C4, column chunk i % C4) with C4 = EP_PITCH/4 a compile-time divisor, so a wave instruction
   // touches one contiguous run of a row in every epilogue stream.  Row reductions (attention head scores, the GSL
   // scorer's projection) read the finished rows back from LDS, one wave per row, in a fixed order (deterministic).
-  if (L.dbg & 1) {
+  if (dbg_bits & 1) {
     if (acc[0][0][0] == 12345.678f && acc[MI - 1][NI - 1][3] == 1.f) P.C[0] = 0.f;
     return;
   }

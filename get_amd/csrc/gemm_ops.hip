@@ -325,19 +325,19 @@ struct Batch {
     const Workspace w = workspace_for(s_);
     g_ws = w.p; g_ws_bytes = w.bytes;
     static int force_small = -1;
-    if (force_small < 0) { const char* e = getenv("GH_NT_FORCE_SMALL"); force_small = e ? atoi(e) : 0; }
+    if (force_small < 0) force_small = measure_env("GH_NT_FORCE_SMALL", 0);
     big = tn_ || (rows_hint >= 8192 && !force_small);      // 64x320 tile (2x2 waves) for the activation-sized GEMMs, 32x320 (1x4) for few-row ones
     bm = big ? 64 : 32;
     bn = 320;
     static int no_wide = -1;
-    if (no_wide < 0) { const char* e = getenv("GH_BF16_TILE"); no_wide = (e && atoi(e) == 320) ? 1 : 0; }
+    if (no_wide < 0) no_wide = measure_env("GH_BF16_TILE", 0) == 320 ? 1 : 0;
     if (wide_bf16 && big && !tn_ && !no_wide) { wide = true; bm = 128; bn = 256; }
     reset();
   }
   void reset() {
     L.nprob = 0; L.m_tiles = 0; L.ksplit = 1; L.kchunk = 0; k_total = 0;
     static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("GH_DBG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) dbg = measure_env("GH_DBG", 0);
     L.dbg = dbg;
     for (int i = 0; i < GH_MAX_PROBLEMS; ++i) cs_out[i] = cs_out2[i] = nullptr;
   }
@@ -378,7 +378,7 @@ struct Batch {
     if (tn) {
       const int n_inner = L.m_tiles * L.nprob;
       static int target = -1;
-      if (target < 0) { const char* e = getenv("GH_TN_SPLIT_TARGET"); target = e ? atoi(e) : 2304; }
+      if (target < 0) target = measure_env("GH_TN_SPLIT_TARGET", 2304);
       int ks = (target + n_inner - 1) / n_inner;   // three resident rounds of 256 CUs x 3 workgroups (measured on the bench step: 1152 -> 2.06 ms,
                                                    // 1536 -> 1.95, 2304 -> 1.86, 3072 -> 1.84 but more partials to reduce; one round 20 % slower)
       const int ks_max = (k_total / 256 > 1) ? k_total / 256 : 1;
@@ -447,7 +447,7 @@ struct Batch {
       // tiles that ends in a thinly filled last round (e.g. 976 workgroups = 1.27 rounds, the node-compact single-problem
       // launches) runs faster on 32-row tiles (1937 workgroups = 2.52 rounds): measured 83 vs 78 TF at K = 300.
       static int mode = -1;
-      if (mode < 0) { const char* e = getenv("GH_NT_TILE_RULE"); mode = e ? atoi(e) : 1; }
+      if (mode < 0) mode = measure_env("GH_NT_TILE_RULE", 1);
       const double r = (double)L.m_tiles * L.nprob / 768.0;
       const double frac = r - (double)(long long)r;
       if (mode == 1 && g_gemm_mode == 0 && r < 3.0 && frac > 0.02 && frac < 0.45) {

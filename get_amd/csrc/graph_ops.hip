@@ -571,7 +571,7 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   // slab: <= 32 float4 (or 128 scalars) per row, as even as possible
   // (sized so that a workgroup's slab stays under ~32 KB of LDS: four to five workgroups per CU, also at R = 200)
   static int cap_kb = -1;
-  if (cap_kb < 0) { const char* e = getenv("GH_SPMM_SLAB_KB"); cap_kb = e ? atoi(e) : 32; }   // measured per step: 48 KB -> 0.314 ms, 32 -> 0.288, 24 -> 0.294, 16 -> 0.344 (R = 100); R = 200: 0.60 -> 0.43
+  if (cap_kb < 0) cap_kb = measure_env("GH_SPMM_SLAB_KB", 32);   // measured per step: 48 KB -> 0.314 ms, 32 -> 0.288, 24 -> 0.294, 16 -> 0.344 (R = 100); R = 200: 0.60 -> 0.43
   const int lds_cap = (cap_kb * 1024) / (r * (v4 ? 16 : 4));
   const int slab_max = v4 ? (lds_cap < 32 ? (lds_cap < 4 ? 4 : lds_cap) : 32) : (lds_cap < 128 ? (lds_cap < 16 ? 16 : lds_cap) : 128);
   const int nslab = (hv + slab_max - 1) / slab_max;
@@ -589,7 +589,7 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   // 1 / 2: LDS-free gather variants (thread-per-float4 / wave-per-row).  Measured equal or slower on MI355X: with
   // ~8K waves in flight their sliding-window working set (~49 MB) thrashes the 32 MB of L2 (hit rate 32 %).
   static int variant = -1;
-  if (variant < 0) { const char* e = getenv("GH_SPMM_VARIANT"); variant = e ? atoi(e) : 4; if (variant > 5) variant = 4; }
+  if (variant < 0) { variant = measure_env("GH_SPMM_VARIANT", 4); if (variant > 5) variant = 4; }
   const int ptag = n < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_SPMM;
   prof_begin(s, ptag);
   if (v4 && variant >= 3 && r <= 256 && (!bf16 || hv % 2 == 0)) {

@@ -777,7 +777,7 @@ int launch_att_dpre(const float* de, const float* w2, const float* t, const int3
   // straddles 128-byte lines shared with the neighbouring slab's workgroup -- measured 3.1 / 3.6 / 3.9 / 4.3 TB/s at
   // 5 / 3 / 2 / 1 slabs (GH_DPRE_SLABS) once the row batches are prefetched
   static int nsl_env = -1;
-  if (nsl_env < 0) { const char* e = getenv("GH_DPRE_SLABS"); nsl_env = e ? atoi(e) : 0; }
+  if (nsl_env < 0) nsl_env = measure_env("GH_DPRE_SLABS", 0);
   const int nsl = nsl_env > 0 ? nsl_env : (n4 + 127) / 128;
   const int S4 = (n4 + nsl - 1) / nsl;
   const int RL = (256 / S4) > 0 ? (256 / S4) : 1;

@@ -9,10 +9,22 @@ and of the optimiser, matching torch.optim.Adam's skipping of ``grad is None`` (
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
+
+
+def pin_rccl_for_parity(env=None):
+    """Fix RCCL's algorithm / protocol choice BEFORE init_process_group: the summation order of an
+    all-reduce is a function of the algorithm (ring vs tree) and protocol RCCL picks per message size and topology; with
+    both pinned, two runs of the same world size reduce in the same order, so multi-GPU parity runs compare like with
+    like.  Values already present in the environment win."""
+    env = os.environ if env is None else env
+    env.setdefault("NCCL_ALGO", "Ring")
+    env.setdefault("NCCL_PROTO", "Simple")
+    return {k: env[k] for k in ("NCCL_ALGO", "NCCL_PROTO")}
 
 DEAD_PREFIXES = ("bilstm.", "query_bilstm.", "trans.", "ggnn_with_gsl.word_scorer1.")
 # Parameters whose gradients are final only at the very end of the backward pass (the first evidence cell, the claim
@@ -29,12 +41,30 @@ def live_parameters(model: torch.nn.Module):
             if p.requires_grad and not n.startswith(DEAD_PREFIXES)]
 
 
-def shard_claims(n_claims: int, rank: int, world: int) -> range:
-    """Contiguous, equal slices of the (already shuffled) claim list; equal claim counts keep the
-    mean-reduced loss of the union equal to the average of the per-rank losses."""
+def shard_claims(n_claims: int, rank: int, world: int, evd_counts=None):
+    """Claim indices of `rank`'s shard of a global batch.  Every rank gets the same NUMBER of claims (equal claim counts
+    keep the mean-reduced loss of the union equal to the average of the per-rank losses).
+
+    evd_counts None: contiguous slices of the (already shuffled) claim list.
+    evd_counts (n_claims,): sort-then-stripe -- the work of a claim is its evidence count (pairs, the
+    per-claim slices of char_man_fitter_query_repr1.py:207-217), which is ragged on real data (Snopes: mean 6.9, max 26),
+    so contiguous slices leave the ranks with unequal B1 and the step waits for the heaviest.  Claims are sorted by
+    evidence count (descending, stable) and dealt to the ranks in boustrophedon order (0..W-1, W-1..0, ...): each round
+    of 2W claims gives every rank one claim from the heavy and one from the light half of the round."""
     assert n_claims % world == 0, "global batch must divide by the number of ranks"
     per = n_claims // world
-    return range(rank * per, (rank + 1) * per)
+    if evd_counts is None:
+        return range(rank * per, (rank + 1) * per)
+    import numpy as np
+    c = np.asarray(evd_counts, dtype=np.int64).reshape(-1)
+    assert c.shape[0] == n_claims, "one evidence count per claim"
+    order = np.argsort(-c, kind="stable")
+    pos = np.arange(n_claims)
+    rnd, k = pos // world, pos % world
+    owner = np.where(rnd % 2 == 0, k, world - 1 - k)
+    mine = order[owner == rank]
+    assert mine.shape[0] == per
+    return [int(i) for i in np.sort(mine)]          # ascending: keeps the claim-major order of the batch tensors
 
 
 class FlatTrainer:
@@ -42,8 +72,14 @@ class FlatTrainer:
     live parameter are views into them, so autograd accumulates straight into the all-reduce bucket."""
 
     def __init__(self, model: torch.nn.Module, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8,
-                 process_group=None, late_prefixes: Sequence[str] = LATE_PREFIXES, check_overlap: bool = False):
+                 process_group=None, late_prefixes: Sequence[str] = LATE_PREFIXES, check_overlap: bool = False,
+                 always_reduce: bool = False):
         self.model = model
+        # always_reduce: issue the collectives even in a 1-rank group (a world_size-1 RCCL group on a single-GPU box then
+        # exercises communicator set-up, the device all-reduce and the asynchronous early range; tests/test_gpu_dist.py)
+        self._always_reduce = bool(always_reduce)
+        self.comm_bytes = 0          # bytes handed to all-reduce since construction (bench.py reports them per step)
+        self.comm_calls = 0
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.group = process_group
         live = live_parameters(model)
@@ -104,6 +140,37 @@ class FlatTrainer:
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
+    def _reducing(self) -> bool:
+        return self.world > 1 or (self._always_reduce and dist.is_available() and dist.is_initialized())
+
+    def _all_reduce(self, t: torch.Tensor, async_op: bool = False):
+        self.comm_bytes += t.numel() * t.element_size()
+        self.comm_calls += 1
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def broadcast_parameters(self, src: int = 0):
+        """Make every replica identical to rank `src` with TWO collectives: the flat bucket of the live parameters, and
+        one packed buffer of everything outside it that the forward reads (the never-trained GSL scorer, frozen
+        embedding tables, the dead-but-present LSTM / trans parameters a checkpoint carries).  The per-tensor loop this
+        replaces issued ~90 broadcasts."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        from . import ops
+        dist.broadcast(self.flat_p, src=src, group=self.group)
+        live = {id(p) for p in self.params}
+        rest = [p for p in self.model.parameters() if id(p) not in live]
+        rest += [b for b in self.model.buffers() if b.is_floating_point()]
+        if rest:
+            pack = torch.cat([t.detach().reshape(-1).float() for t in rest])
+            dist.broadcast(pack, src=src, group=self.group)
+            off = 0
+            with torch.no_grad():
+                for t in rest:
+                    n = t.numel()
+                    t.copy_(pack[off:off + n].view_as(t))
+                    off += n
+        ops.bump_weight_epoch()          # parameters were rewritten in place: drop every cached derivative
+
     def zero_grad(self):
         assert self._early_work is None, "zero_grad() while an all-reduce is in flight (call step() / allreduce() first)"
         self.flat_g.zero_()
@@ -123,12 +190,11 @@ class FlatTrainer:
             raise RuntimeError("get_amd: a second backward pass reached the all-reduce milestone while the first early "
                                "all-reduce is still pending; gradient accumulation needs detach_overlap() (one "
                                "all-reduce per step) or an allreduce() after every backward")
-        if self.world > 1 and 0 < self.n_early < self.numel and self._overlap_ok:
+        if self._reducing() and 0 < self.n_early < self.numel and self._overlap_ok:
             if self._check_overlap:
                 self._early_snapshot = self.flat_g[:self.n_early].clone()
             try:
-                self._early_work = dist.all_reduce(self.flat_g[:self.n_early], op=dist.ReduceOp.SUM, group=self.group,
-                                                   async_op=True)
+                self._early_work = self._all_reduce(self.flat_g[:self.n_early], async_op=True)
             except Exception as e:      # a backend without async collectives: keep training with the single all-reduce
                 self._overlap_ok = False
                 self._early_work = None
@@ -140,7 +206,7 @@ class FlatTrainer:
         collective, or -- when the early part is already in flight -- a wait on it plus the late remainder."""
         from . import ops
         ops.side_join()
-        if self.world > 1:
+        if self._reducing():
             if self._early_work is not None:
                 self._early_work.wait()
                 self._early_work = None
@@ -154,9 +220,9 @@ class FlatTrainer:
                     if bad != 0.0:
                         raise RuntimeError(f"get_amd: an early-bucket gradient changed after its all-reduce started (max "
                                            f"diff {bad:.3e}); a parameter is missing from late_prefixes")
-                dist.all_reduce(self.flat_g[self.n_early:], op=dist.ReduceOp.SUM, group=self.group)
+                self._all_reduce(self.flat_g[self.n_early:])
             else:
-                dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+                self._all_reduce(self.flat_g)
 
     def attach_overlap(self, module=None):
         """Overlap the early part of the all-reduce with the tail of the backward pass: the module that owns the

@@ -102,3 +102,38 @@ print('ok')
 """ % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/MasterFC"), reason="reference tree only exists in the build container")
+def test_master_get_itself_imports_against_the_shim_and_builds_the_hip_backed_model():
+    """the reference's driver, MasterFC/master_get.py, imported UNMODIFIED (its own `from Models...
+    import graph_based_semantic_structure` at :5, the fitter, matchzoo, handlers) after get_amd.install(): the model class
+    it would construct at :145 is the HIP-backed drop-in, and constructing it with the params dict of :118-144 works."""
+    code = r"""
+import sys, os
+sys.path.insert(0, %r)
+from oracle import _refshim
+_refshim.install()
+import get_amd
+M = get_amd.install()
+sys.path.insert(0, '/root/reference/MasterFC')
+os.chdir('/root/reference/MasterFC')
+import master_get                                                        # the driver module itself, top to bottom
+assert master_get.graph_based_semantic_structure.Graph_basedSemantiStructure is M.Graph_basedSemantiStructure
+import numpy as np
+# the params dict master_get.fit_models builds at :118-144 (sizes shrunk)
+params = dict(embedding=np.random.rand(50, 16).astype('float32'), embedding_freeze=True, num_classes=2,
+              fixed_length_left=30, fixed_length_right=100, use_claim_source=0, claim_source_embeddings=np.zeros((4, 8), 'float32'),
+              use_article_source=1, article_source_embeddings=np.zeros((6, 8), 'float32'), cuda=0,
+              num_att_heads_for_words=5, num_att_heads_for_evds=2, dropout_gnn=0.2, dropout_left=0.2, dropout_right=0.2,
+              hidden_size=16, output_size=2, gsl_rate=0.6)
+net = master_get.graph_based_semantic_structure.Graph_basedSemantiStructure(params)
+assert type(net.ggnn_with_gsl).__module__ == 'get_amd.modules'
+assert params['embedding_input_dim'] == 50 and params['embedding_output_dim'] == 16
+# the fitter class the driver instantiates at :148 accepts the drop-in model
+fit = master_get.char_man_fitter_query_repr1.CharManFitterQueryRepr1
+assert callable(fit)
+print('ok')
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-3000:]

@@ -217,3 +217,84 @@ def test_trainable_word_embedding_sits_in_the_late_range():
         if n == "embedding.weight":
             assert off >= tr.n_early, "trainable embedding table landed in the early all-reduce range"
         off += (p.numel() + 63) // 64 * 64
+
+
+def test_sort_then_stripe_balances_snopes_shaped_batches():
+    """SURVEY 8(e) / VERDICT r2: on the empirical Snopes evidence histogram (mean 6.9, max 26) the striped shards must
+    carry nearly equal pair counts (max/min B1 per rank <= 1.1), keep equal claim counts and partition the batch."""
+    from get_amd.synth import snopes_evidence_counts
+    worst_striped, worst_contig = 1.0, 1.0
+    for seed in range(20):
+        counts = snopes_evidence_counts(np.random.default_rng(seed), 256)
+        for world in (2, 4, 8):
+            shards = [shard_claims(256, r, world, counts) for r in range(world)]
+            assert sorted(i for s in shards for i in s) == list(range(256))
+            assert all(len(s) == 256 // world for s in shards)
+            assert all(list(s) == sorted(s) for s in shards)
+            b1 = [int(counts[list(s)].sum()) for s in shards]
+            worst_striped = max(worst_striped, max(b1) / min(b1))
+            b1c = [int(counts[list(shard_claims(256, r, world))].sum()) for r in range(world)]
+            worst_contig = max(worst_contig, max(b1c) / min(b1c))
+    assert worst_striped <= 1.1, worst_striped
+    assert worst_contig > worst_striped          # (contiguous slices reach ~1.5 at 8 ranks)
+    # B = 32 claims per rank at 8 ranks, the configs[3] split
+    assert shard_claims(16, 1, 2, np.arange(16)) == [1, 2, 5, 6, 9, 10, 13, 14]
+
+
+def _worker_broadcast(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                      # replicas start DIFFERENT
+    model = Toy()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(torch.randn_like(p))
+    tr = FlatTrainer(model)
+    calls = []
+    orig = dist.broadcast
+    dist.broadcast = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        tr.broadcast_parameters(src=0)
+    finally:
+        dist.broadcast = orig
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        out.put((len(calls), all(torch.equal(g, gathered[0]) for g in gathered),
+                 model.live.weight.data_ptr() == tr.flat_p.data_ptr()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_parameters_is_two_collectives_and_covers_dead_and_frozen_tensors():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_broadcast, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    ncalls, same, still_view = q.get(timeout=5)
+    assert ncalls == 2 and same and still_view
+
+
+def test_single_rank_group_reduces_only_when_asked():
+    """always_reduce: a world_size-1 group still issues the collectives (the RCCL smoke test on a 1-GPU box relies on it)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        for flag, calls in ((False, 0), (True, 2)):
+            model = Toy2()
+            tr = FlatTrainer(model, late_prefixes=("late.",), always_reduce=flag)
+            tr.attach_overlap(model)
+            x, y = torch.randn(4, 6), torch.randint(0, 3, (4,))
+            tr.zero_grad()
+            torch.nn.functional.cross_entropy(model(x), y).backward()
+            tr.allreduce()
+            assert tr.comm_calls == calls
+            assert tr.comm_bytes == (tr.numel * 4 if flag else 0)
+    finally:
+        dist.destroy_process_group()

@@ -119,3 +119,65 @@ def test_two_ranks_real_model_match_the_union_batch(compact):
     # fp32 summation order differs between a 4-claim shard and the 8-claim union (split-K chunking of the weight-gradient
     # GEMMs, row-tile boundaries): the worst parameter sits at ~1e-5 of its own gradient scale (1e-5 rel)
     assert worst <= 3e-5, f"averaged 2-rank gradient differs from the union-batch gradient by {worst:.2e} (relative)"
+
+
+def _worker_rccl_single(port, q, use_group):
+    """One rank on cuda:0.  use_group: a world_size-1 RCCL ("nccl") group with always_reduce -- librccl is loaded, a
+    communicator is created on the device, the early range goes out as an asynchronous device all-reduce from inside
+    backward and the late range as a blocking one, all on RCCL's own stream with the event hand-offs torch.distributed
+    inserts.  Without the group the same two steps run with no collective at all."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from get_amd.dist import FlatTrainer, pin_rccl_for_parity
+    torch.cuda.set_device(0)
+    pinned = pin_rccl_for_parity()
+    if use_group:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        cfg, seed = _cfg(), 5
+        model, nb = _make(cfg, seed, "cuda:0", None, True)
+        tr = FlatTrainer(model, check_overlap=use_group, always_reduce=use_group)
+        if use_group:
+            tr.broadcast_parameters(0)
+        tr.attach_overlap()
+        early_seen = 0
+        for step in range(3):
+            tr.zero_grad()
+            q_, d_, k_ = nb.inputs()
+            loss = torch.nn.functional.cross_entropy(model(q_, d_, **k_), nb.labels)
+            loss.backward()
+            early_seen += int(tr._early_work is not None)
+            tr.step()
+        torch.cuda.synchronize()
+        backend = dist.get_backend() if use_group else "none"
+        q.put((use_group, tr.flat_p.cpu().numpy(), tr.comm_calls, tr.comm_bytes, early_seen, backend, tr.numel, pinned))
+        if use_group:
+            dist.barrier()
+    finally:
+        if use_group:
+            dist.destroy_process_group()
+
+
+def test_rccl_world_size_one_runs_the_overlapped_allreduce_on_the_device():
+    """RCCL itself had never executed.  A 1-GPU box can still load RCCL, build a communicator and push
+    the flat bucket through ncclAllReduce (sum over one rank = identity): three FlatTrainer steps with attach_overlap()
+    under a world_size-1 "nccl" group must leave the parameters BIT-identical to the same steps without any group."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    res = {}
+    for use_group in (True, False):
+        q = ctx.Queue()
+        p = ctx.Process(target=_worker_rccl_single, args=(_free_port(), q, use_group))
+        p.start()
+        got = q.get(timeout=600)
+        p.join(300)
+        assert p.exitcode == 0
+        res[use_group] = got
+    _, p_rccl, calls, nbytes, early_seen, backend, numel, pinned = res[True]
+    _, p_plain, calls0, nbytes0, early0, _, _, _ = res[False]
+    assert backend == "nccl"
+    assert pinned == {"NCCL_ALGO": "Ring", "NCCL_PROTO": "Simple"}
+    assert early_seen == 3, "the milestone hook did not start the asynchronous early all-reduce"
+    assert calls == 6 and nbytes == 3 * numel * 4           # early + late range per step = the whole bucket once
+    assert calls0 == 0 and early0 == 0
+    assert np.array_equal(p_rccl, p_plain), "three steps through RCCL differ from three steps without a collective"

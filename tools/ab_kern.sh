@@ -4,8 +4,8 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r2
 for e in "$@"; do
-  if [ "$e" = "-" ]; then e="GH_NONE=1"; fi
-  env $e python bench.py --steps 20 --warmup 6 --no-cpu-baseline --no-series 2> gpurun_out/r2/ab_err.log | python -c "
+  if [ "$e" = "-" ]; then e="GET_AMD_AB_NONE=1"; fi
+  env $e python bench.py --measure-build --steps 20 --warmup 6 --no-cpu-baseline --no-series 2> gpurun_out/r2/ab_err.log | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('== $e', 'pairs/s %.0f  ms/step %.4f  parity %s mism %s' % (d['value'], d['ms_per_step'], d.get('parity', {}).get('max_abs_logit_diff_vs_cpu_oracle'), d.get('parity', {}).get('graphs_with_real_node_keep_set_mismatch')))
