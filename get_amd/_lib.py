@@ -19,7 +19,7 @@ _I = ctypes.c_int
 _F = ctypes.c_float
 _L = ctypes.c_int64
 _U = ctypes.c_uint32
-ABI_VERSION = 4          # GH_ABI_VERSION of include/get_hip.h
+ABI_VERSION = 5          # GH_ABI_VERSION of include/get_hip.h
 
 # name -> argtypes (mirrors include/get_hip.h; tests/test_abi.py checks the two agree)
 SIGNATURES = {
@@ -58,6 +58,13 @@ SIGNATURES = {
     "gh_profile_collect": [_P, _I],
     "gh_gemm_path_counters": [_P, _I],
     "gh_set_gemm_mode": [_I],
+    # composite entry points (get_amd/fused.py holds the ctypes mirrors of the descriptor structs)
+    "gh_get_plan_buffers": [_P, _P, _P],
+    "gh_get_forward": [_P, _P, _P, _P, _P],
+    "gh_get_backward": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
+    "gh_cross_entropy": [_P, _P, _I, _I, _P, _P, _P],
+    "gh_get_prepare": [_P, _P, _I, _I, _P, _P, _I, _I, _I] + [_P] * 8 + [_I] + [_P] * 5 + [_P, _P, _P],
+    "gh_get_struct_sizes": [_P],
 }
 
 PROFILE_ROWS = ["gemm_big", "gemm_big_tn", "gemm_small", "gemm_small_tn", "spmm", "scorer_gsl",
@@ -129,6 +136,12 @@ def load():
 
 
 _workspaces = {}
+
+
+def has_workspace(device, raw_stream) -> bool:
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else _get_device()
+    return (idx, raw_stream) in _workspaces
 
 
 def ensure_workspace(device, nbytes: int = 256 << 20):

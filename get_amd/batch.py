@@ -72,6 +72,7 @@ class NativeBatch:
             self.doc_sources, self.query_sources, self.labels = t(doc_sources), t(query_sources), t(labels)
             self._slot = t(slot)
         assert self.evd_tokens.shape[0] == self.b1, "evd_tokens must hold sum(evd_counts) rows"
+        self.counts._gh_fit = True        # every count <= n_max (asserted above): the backward needs no zero fill of unmapped rows
         # node-compact layout (ops.RaggedPlan): the host has to know the total number of real evidence nodes, i.e.
         # the unique tokens per evidence -- what convert_text returns as `length_` (interactions.py:351) at load time
         if compact is None:
@@ -85,30 +86,56 @@ class NativeBatch:
             self.m_real = int(d_n.sum().item())
         else:
             self.m_real = 0
+        self._graphs = None           # per-step graph buffers, allocated by the first inputs()
 
     def inputs(self):
         """Per-step device work: token ids -> (query node ids, padded document ids, kargs) for
-        ``Graph_basedSemantiStructure.forward`` (interactions.py:334-351 runs as two kernel launches)."""
-        qa, q_ids, q_n = ops.graph_build(self.claim_tokens, self.claim_len, self.window)
-        da, d_ids, d_n = ops.graph_build(self.evd_tokens, self.evd_len, self.window)
-        if self.compact:
-            da = da.with_plan(ops.RaggedPlan(d_n, d_ids, self.m_real))
-        r = self.evd_tokens.shape[1]
-        document = torch.zeros((self.b * self.n_max, r), device=self.device, dtype=torch.int32)
-        document.index_copy_(0, self._slot, d_ids)
-        kargs = {
-            K.Query_lens: q_n, K.Doc_lens: None, K.DocLensIndices: None,
-            K.DocContentNoPaddingEvidence: d_ids, K.EvidenceCountPerQuery: self.counts,
-            K.FIXED_NUM_EVIDENCES: self.n_max, K.Query_Adj: qa, K.Evd_Docs_Adj: da,
-            K.DocSources: self.doc_sources, K.QuerySources: self.query_sources,
-        }
-        return q_ids, document.view(self.b, self.n_max, r), kargs
-
+        ``Graph_basedSemantiStructure.forward``.  interactions.py:334-351 for both sides, the node-compact plan and the
+        padded ``document`` tensor of basic_fc_model.py:94-121 run as ONE library call (gh_get_prepare: two graph-build
+        launches, the plan's scan + fill, one scatter) into buffers this batch owns: they are allocated on the first
+        call and rewritten in place on every later one, so a step allocates nothing here."""
+        from ._lib import call, ptr, stream
+        c = self._graphs
+        if c is None:
+            dev = self.device
+            b, b1 = self.b, self.b1
+            l, r = self.claim_tokens.shape[1], self.evd_tokens.shape[1]
+            wq, wd = (l + 63) // 64, (r + 63) // 64
+            i32 = lambda *sh: torch.empty(sh, device=dev, dtype=torch.int32)
+            c = {"q_ids": i32(b, l), "q_n": i32(b), "q_bits": torch.empty((b, l, wq), device=dev, dtype=torch.int64),
+                 "q_dinv": torch.empty((b, l), device=dev, dtype=torch.float32),
+                 "d_ids": i32(b1, r), "d_n": i32(b1), "d_bits": torch.empty((b1, r, wd), device=dev, dtype=torch.int64),
+                 "d_dinv": torch.empty((b1, r), device=dev, dtype=torch.float32),
+                 "document": torch.zeros((b * self.n_max, r), device=dev, dtype=torch.int32)}      # unused slots stay zero
+            qa = ops.PackedAdj(c["q_bits"], c["q_dinv"], None, None, b, l)
+            da = ops.PackedAdj(c["d_bits"], c["d_dinv"], None, None, b1, r)
+            plan = None
+            if self.compact and b1 > 0:
+                plan = ops.RaggedPlan.empty(b1, r, self.m_real, dev)
+                da = da.with_plan(plan)
+            c["plan"] = plan
+            c["kargs"] = {
+                K.Query_lens: c["q_n"], K.Doc_lens: None, K.DocLensIndices: None,
+                K.DocContentNoPaddingEvidence: c["d_ids"], K.EvidenceCountPerQuery: self.counts,
+                K.FIXED_NUM_EVIDENCES: self.n_max, K.Query_Adj: qa, K.Evd_Docs_Adj: da,
+                K.DocSources: self.doc_sources, K.QuerySources: self.query_sources,
+            }
+            c["doc_view"] = c["document"].view(b, self.n_max, r)
+            plan_ptrs = (ptr(plan.goff), ptr(plan.rowg), ptr(plan.src), ptr(plan.cids), ptr(plan.maskf)) if plan is not None \
+                else (None,) * 5
+            c["args"] = (ptr(self.claim_tokens), ptr(self.claim_len), b, l, ptr(self.evd_tokens), ptr(self.evd_len), b1, r, self.window,
+                         ptr(c["q_ids"]), ptr(c["q_n"]), ptr(c["q_bits"]), ptr(c["q_dinv"]),
+                         ptr(c["d_ids"]), ptr(c["d_n"]), ptr(c["d_bits"]), ptr(c["d_dinv"]),
+                         self.m_real if plan is not None else -1, *plan_ptrs, ptr(self._slot), ptr(c["document"]))
+            self._graphs = c
+        call("gh_get_prepare", *c["args"], stream())
+        return c["q_ids"], c["doc_view"], c["kargs"]
 
     def device_tensors(self):
         """Every device tensor this batch owns (stream hand-over: `t.record_stream(consumer_stream)`)."""
         return [t for t in (self.counts, self._slot, self.doc_sources, self.query_sources, self.labels, self.claim_tokens,
-                            self.claim_len, self.evd_tokens, self.evd_len) if torch.is_tensor(t) and t.is_cuda]
+                            self.claim_len, self.evd_tokens, self.evd_len) if torch.is_tensor(t) and t.is_cuda] + \
+               ([v for v in self._graphs.values() if torch.is_tensor(v) and v.is_cuda] if self._graphs else [])
 
     def subset(self, lo: int, hi: int) -> "NativeBatch":
         """Claims [lo, hi) of this batch as a batch of their own (device-side slices; evaluation in chunks)."""

@@ -92,4 +92,31 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
 int launch_att_dpre(const float* de, const float* w2, const float* t, const int32_t* goff, int m_real, int b, int l,
                     int ha, int heads, float* dpre, float* du, float* dw2_part, hipStream_t s);
 
+// fused building blocks shared by the per-module entry points (gemm_ops.hip) and the composite model entry points
+// (model_ops.hip); argument meaning as the gh_* functions of the same name in include/get_hip.h
+int cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                  const int32_t* goff, int m_real, int m_rows, const float* x, const int32_t* ids, int n, int r, int din, int h,
+                  const float* w_p, const float* w_z0, const float* w_z1, const float* w_r0, const float* w_r1, const float* w_h0,
+                  const float* w_h1, const float* b_z0, const float* b_z1, const float* b_r0, const float* b_r1, const float* b_h0,
+                  const float* b_h1, float* xp, float* a, float* z, float* rr, float* rx, float* hh, float* out, float drop_p,
+                  uint32_t drop_seed, const float* score_w, float* score_x, float score_drop_p, uint32_t score_drop_seed,
+                  void* stream);
+int cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const int32_t* goff,
+                  int m_real, const float* x, const int32_t* ids, int n, int r, int din, int h, const float* wt_p,
+                  const float* wt_z0, const float* wt_z1, const float* wt_r0, const float* wt_r1, const float* wt_h0,
+                  const float* wt_h1, const float* xp, const float* a, const float* z, const float* rr, const float* rx,
+                  const float* hh, const float* g, float* dhp, float* dzp, float* drp, float* dxp, float* da, float* dx,
+                  float* dw_p, float* dw_z0, float* dw_z1, float* dw_r0, float* dw_r1, float* dw_h0, float* dw_h1, float* db_z,
+                  float* db_r, float* db_h, float* db_z1, float* db_r1, float* db_h1, float drop_p, uint32_t drop_seed, void* stream);
+int att_fwd_impl(const float* left, int nl, const int32_t* rowu, const float* right, const float* mask, const int32_t* goff,
+                 const int32_t* rowg, int m_real, int b, int l, int xl, int dr, int ha, int heads, const float* w1, const float* w2,
+                 float* u, float* t, float* e, float* weights, float* attended, hipStream_t s);
+int att_bwd_impl(const float* left, const float* right, const int32_t* goff, int m_real, int b, int l, int xl, int dr, int ha,
+                 int heads, const float* w1t, const float* w2, const float* t, const float* weights, const float* g_att,
+                 const float* g_w, float* de, float* dpre, float* du, float* dleft, float* dright, float* dw1, float* dw2,
+                 const int32_t* claim_offsets, int nl, float* du_c, int dleft_accumulate, hipStream_t s);
+int linear2_fwd(const float* x0, int k0, const float* x1, int k1, const float* w, const float* bias, float* y, int m, int n, hipStream_t s);
+int linear2_bwd(const float* x0, int k0, const float* x1, int k1, const float* wt, const float* g, int m, int n, float* dx0,
+                int dx0_accumulate, float* dx1, float* dw, float* db, hipStream_t s);
+
 }  // namespace gh

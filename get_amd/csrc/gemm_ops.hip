@@ -545,7 +545,7 @@ using namespace gh;
 
 // bf: bf16 storage pipeline -- x (or the table behind ids), the weights and xp/a/z/rr/rx/hh/out hold bf16 (pointers typed
 // float* all the same); out32 then receives the fp32 copy of the cell output.  Biases, score_w and score_x stay fp32.
-static int cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
                                 const int32_t* goff, int m_real, int m_rows,
                                 const float* x, const int32_t* ids, int n, int r, int din, int h,
                                 const float* w_p, const float* w_z0, const float* w_z1, const float* w_r0,
@@ -666,7 +666,7 @@ extern "C" int gh_ggnn_cell_fwd_bf16(const uint64_t* bits, const float* dinv, co
 
 // bf: bf16 storage pipeline -- x / table, wt_*, the saved xp..hh and the scratch dhp..da hold bf16; g, dx and every weight /
 // bias gradient stay fp32.
-static int cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
                                 const int32_t* goff, int m_real,
                                 const float* x, const int32_t* ids, int n, int r, int din, int h,
                                 const float* wt_p, const float* wt_z0, const float* wt_z1, const float* wt_r0,
@@ -785,35 +785,38 @@ extern "C" int gh_ggnn_cell_bwd_bf16(const uint64_t* bits, const float* dinv, co
                        db_h1, drop_p, drop_seed, stream);
 }
 
-extern "C" int gh_concat_att_fwd(const float* left, const float* right, const float* mask, const int32_t* goff,
-                                 const int32_t* rowg, int m_real, int b, int l, int xl,
-                                 int dr, int ha, int heads, const float* w1, const float* w2,
-                                 float* u, float* t, float* e, float* weights, float* attended,
-                                 gh_stream_t stream) {
-  hipStream_t s = (hipStream_t)stream;
+// Concat attention, generalised for the composite model entry points (model_ops.hip):
+//   nl / rowu: `left` has nl rows and output row m takes the left projection u[rowu[m]] (the word level's left input is the
+//              CLAIM vector: one u row per claim instead of one per pair; rowu = NULL keeps nl == b and the per-pair map);
+//   att_out / att_ld: where `attended` goes (row pitch att_ld >= dr * heads: straight into a wider concatenation buffer).
+int gh::att_fwd_impl(const float* left, int nl, const int32_t* rowu, const float* right, const float* mask, const int32_t* goff,
+                 const int32_t* rowg, int m_real, int b, int l, int xl, int dr, int ha, int heads, const float* w1, const float* w2,
+                 float* u, float* t, float* e, float* weights, float* attended, hipStream_t s) {
   GH_REQUIRE(heads >= 1 && heads <= 8, "concat_att: heads=%d not in [1,8]", heads);
   GH_REQUIRE(b > 0 && l > 0 && dr > 0 && ha > 0, "concat_att_fwd: bad sizes");
   GH_REQUIRE((goff == nullptr) == (rowg == nullptr), "concat_att_fwd: goff and rowg come together");
   if (!goff) m_real = b * l;
   GH_REQUIRE(m_real >= 0 && m_real <= b * l, "concat_att_fwd: node-compact rows %d do not fit b*l=%d", m_real, b * l);
+  if (!rowu) nl = b;
   const int M = m_real;
   const bool one_block = ha <= Batch(false, M, s).bn;      // column block of the tile configuration this launch will use
   GH_REQUIRE(one_block || (ha % 4 == 0 && al16(t) && al16(u) && al16(w2)),
              "concat_att_fwd: attention hidden %d wider than one column block needs float4-shaped rows", ha);
   const int xl_in = (left && xl > 0) ? xl : 0;      // column offset of the right branch inside linear1.weight
-  if (left && xl > 0) {  // u = W1[:, :xl] . left -- once per pair, not per token (two_branches_attention.py:137-140)
-    Batch bt(false, b, s);
-    bt.add(gemm_problem(b, ha, EPI_STORE, u, ha, left, xl, w1, xl + dr, xl));
+  if (left && xl > 0) {  // u = W1[:, :xl] . left -- once per pair / claim, not per token (two_branches_attention.py:137-140)
+    Batch bt(false, nl, s);
+    bt.add(gemm_problem(nl, ha, EPI_STORE, u, ha, left, xl, w1, xl + dr, xl));
     bt.flush();
     GH_CHECK_HIP(bt.err);
   } else {
-    GH_CHECK_HIP(hipMemsetAsync(u, 0, sizeof(float) * (size_t)b * ha, s));
+    GH_CHECK_HIP(hipMemsetAsync(u, 0, sizeof(float) * (size_t)nl * ha, s));
     xl = 0;
   }
+  const int32_t* urow = rowu ? rowu : rowg;
   if (M > 0) {  // t = tanh(W1[:, xl:] . right_t + u) ; e = W2 t  (:140-141)
     Batch bt(false, M, s);
     Problem p = gemm_problem(M, ha, EPI_ATT, t, ha, right, dr, w1 + xl_in, xl_in + dr, dr);
-    p.u = u; p.ldu = ha; p.R = l; p.w2 = w2; p.heads = heads; p.e = e; p.rowg = rowg;
+    p.u = u; p.ldu = ha; p.R = l; p.w2 = w2; p.heads = heads; p.e = e; p.rowg = urow;
     if (!one_block) p.epi = EPI_STORE;     // wide hidden layer (h = 768): the head scores need whole rows, so the
     bt.add(p);                             // tanh + W2 reduction runs as a row-per-wave pass over the stored product
     bt.flush();
@@ -821,7 +824,7 @@ extern "C" int gh_concat_att_fwd(const float* left, const float* right, const fl
     if (!one_block) {
       FinishArgs F;
       F.n = 1;
-      F.it[0] = FinishItem{t, 0, 1, M, ha, EPI_ATT, 0, ha, t, nullptr, nullptr, nullptr, nullptr, nullptr, u, w2, e, ha, l, heads, rowg};
+      F.it[0] = FinishItem{t, 0, 1, M, ha, EPI_ATT, 0, ha, t, nullptr, nullptr, nullptr, nullptr, nullptr, u, w2, e, ha, l, heads, urow};
       hipLaunchKernelGGL(nt_finish_kernel, dim3((M + 3) / 4, 1), dim3(256), 0, s, F);
       GH_LAUNCH_CHECK();
     }
@@ -829,16 +832,31 @@ extern "C" int gh_concat_att_fwd(const float* left, const float* right, const fl
   return launch_att_softmax_fwd(e, mask, right, goff, m_real, b, l, dr, heads, weights, attended, s);   // (:142-147)
 }
 
-extern "C" int gh_concat_att_bwd(const float* left, const float* right, const int32_t* goff, int m_real, int b, int l,
-                                 int xl, int dr, int ha, int heads, const float* w1t, const float* w2, const float* t, const float* weights,
-                                 const float* g_att, const float* g_w, float* de, float* dpre, float* du,
-                                 float* dleft, float* dright, float* dw1, float* dw2, gh_stream_t stream) {
-  hipStream_t s = (hipStream_t)stream;
+extern "C" int gh_concat_att_fwd(const float* left, const float* right, const float* mask, const int32_t* goff,
+                                 const int32_t* rowg, int m_real, int b, int l, int xl,
+                                 int dr, int ha, int heads, const float* w1, const float* w2,
+                                 float* u, float* t, float* e, float* weights, float* attended,
+                                 gh_stream_t stream) {
+  return att_fwd_impl(left, b, nullptr, right, mask, goff, rowg, m_real, b, l, xl, dr, ha, heads, w1, w2, u, t, e, weights, attended,
+                      (hipStream_t)stream);
+}
+
+// Backward.  claim_offsets / nl / du_c (all or none): the left input has nl rows, one per CLAIM, and pair p belongs to the
+// claim c with claim_offsets[c] <= p < claim_offsets[c+1]: the per-pair du is summed per claim into du_c [nl][ha] first and
+// dleft / the left part of dw1 are computed from (du_c, left) over nl rows.  dleft_accumulate: dleft += .
+int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff, int m_real, int b, int l,
+                 int xl, int dr, int ha, int heads, const float* w1t, const float* w2, const float* t, const float* weights,
+                 const float* g_att, const float* g_w, float* de, float* dpre, float* du,
+                 float* dleft, float* dright, float* dw1, float* dw2,
+                 const int32_t* claim_offsets, int nl, float* du_c, int dleft_accumulate, hipStream_t s) {
   GH_REQUIRE(heads >= 1 && heads <= 8, "concat_att: heads=%d not in [1,8]", heads);
   if (!goff) m_real = b * l;
   GH_REQUIRE(m_real >= 0 && m_real <= b * l, "concat_att_bwd: node-compact rows %d do not fit b*l=%d", m_real, b * l);
+  GH_REQUIRE((claim_offsets == nullptr) == (du_c == nullptr), "concat_att_bwd: claim_offsets and du_c come together");
   const int M = m_real;
   if (!left) xl = 0;
+  if (!claim_offsets) nl = b;
+  const float* dul = claim_offsets ? du_c : du;      // the left branch's pre-activation gradient, one row per left row
   const int ldw = xl + dr;
   // Two-phase use (the caller may put the weight gradient of linear1 on another stream): dw1 == NULL skips its two
   // launches; dright == NULL is the complementary "dw1 only" call on buffers (dpre, du) a first call has filled.
@@ -859,6 +877,8 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, const in
     hipLaunchKernelGGL(reduce_partials_wave_kernel, dim3((heads * (ha / 4) + 3) / 4, 1), dim3(256), 0, s, R);
     GH_LAUNCH_CHECK();
   }
+  if (claim_offsets && xl > 0)
+    if (int e = gh_seg_sum(du, claim_offsets, du_c, nl, ha, (gh_stream_t)s)) return e;
   if (M > 0) {  // dright += dpre W1[:, xl:]
     Batch bt(false, M, s);
     Problem p = gemm_problem(M, dr, EPI_STORE, dright, dr, dpre, ha, w1t + (size_t)xl * ha, ha, ha);
@@ -868,8 +888,10 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, const in
     GH_CHECK_HIP(bt.err);
   }
   if (xl > 0 && dleft) {  // dleft = du W1[:, :xl]
-    Batch bt(false, b, s);
-    bt.add(gemm_problem(b, xl, EPI_STORE, dleft, xl, du, ha, w1t, ha, ha));
+    Batch bt(false, nl, s);
+    Problem p = gemm_problem(nl, xl, EPI_STORE, dleft, xl, dul, ha, w1t, ha, ha);
+    p.accumulate = dleft_accumulate ? 1 : 0;
+    bt.add(p);
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }
@@ -888,11 +910,53 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, const in
     GH_CHECK_HIP(bt.err);
   }
   if (xl > 0) {
-    Batch bt(true, b, s);
-    bt.add(tn_problem(ha, xl, dw1, ldw, du, ha, left, xl, b));
+    Batch bt(true, nl, s);
+    bt.add(tn_problem(ha, xl, dw1, ldw, dul, ha, left, xl, nl));
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }
+  return 0;
+}
+
+extern "C" int gh_concat_att_bwd(const float* left, const float* right, const int32_t* goff, int m_real, int b, int l,
+                                 int xl, int dr, int ha, int heads, const float* w1t, const float* w2, const float* t, const float* weights,
+                                 const float* g_att, const float* g_w, float* de, float* dpre, float* du,
+                                 float* dleft, float* dright, float* dw1, float* dw2, gh_stream_t stream) {
+  return att_bwd_impl(left, right, goff, m_real, b, l, xl, dr, ha, heads, w1t, w2, t, weights, g_att, g_w, de, dpre, du, dleft, dright,
+                      dw1, dw2, nullptr, b, nullptr, 0, (hipStream_t)stream);
+}
+
+// y[m][n] = [x0 | x1] . W^T + bias with W [n][k0 + k1] as stored: the head's first layer on the concatenation
+// [claim vector | attended evidences] (graph_based_semantic_structure.py:251-267) without materialising the concatenation.
+int gh::linear2_fwd(const float* x0, int k0, const float* x1, int k1, const float* w, const float* bias, float* y, int m, int n, hipStream_t s) {
+  Batch b(false, m, s);
+  Problem p = gemm_problem(m, n, EPI_STORE, y, n, x0, k0, w, k0 + k1, k0);
+  if (k1 > 0) add_seg(p, x1, k1, w + k0, k0 + k1, k1);
+  p.bias = bias;
+  b.add(p);
+  b.flush();
+  GH_CHECK_HIP(b.err);
+  return 0;
+}
+// dx0 [m][k0] (+)= g Wt[:k0] ; dx1 [m][k1] = g Wt[k0:] (wt = W^T [k0+k1][n]) ; dw [n][k0+k1] += g^T [x0 | x1] ; db += colsum(g).
+// dx_only / dw_only split the call in two phases (weight gradients on another stream).
+int gh::linear2_bwd(const float* x0, int k0, const float* x1, int k1, const float* wt, const float* g, int m, int n,
+                float* dx0, int dx0_accumulate, float* dx1, float* dw, float* db, hipStream_t s) {
+  if (dx0 || dx1) {
+    Batch b(false, m, s);
+    if (dx0) { Problem p = gemm_problem(m, k0, EPI_STORE, dx0, k0, g, n, wt, n, n); p.accumulate = dx0_accumulate ? 1 : 0; b.add(p); }
+    if (dx1 && k1 > 0) b.add(gemm_problem(m, k1, EPI_STORE, dx1, k1, g, n, wt + (size_t)k0 * n, n, n));
+    b.flush();
+    GH_CHECK_HIP(b.err);
+  }
+  if (dw) {
+    Batch b(true, m, s);
+    b.add(tn_problem(n, k0, dw, k0 + k1, g, n, x0, k0, m));
+    if (k1 > 0) b.add(tn_problem(n, k1, dw + k0, k0 + k1, g, n, x1, k1, m));
+    b.flush();
+    GH_CHECK_HIP(b.err);
+  }
+  if (db) return launch_colsum(g, db, m, n, s);
   return 0;
 }
 

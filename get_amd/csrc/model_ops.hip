@@ -1,0 +1,418 @@
+// Composite entry points: the whole GET forward / backward as ONE library call each (include/get_hip.h "a7"), the fused
+// cross-entropy and the one-call batch preparation.  Host-side chaining of the fused building blocks of gemm_ops.hip /
+// graph_ops.hip / misc_ops.hip on two streams, plus the few small kernels that replace the at::native glue the
+// module-by-module path needed (lens casts, `* has`, torch.cat, index_copy_, the CE kernels).
+//
+// Why: issuing a training step module by module costs ~120 Python -> ctypes -> autograd round trips (~2.2 ms of host
+// time); at realistic evidence counts (~220 pairs per step, ~1.3 ms of device time) the step was bound by that.
+#include "../../include/get_hip.h"
+#include "common.h"
+#include <mutex>
+#include <unordered_map>
+
+namespace gh {
+
+// ---------------------------------------------------------------------------------------------- buffer plan
+struct Dims {
+  int B, B1, L, R, n, D, H, hw, he, C, cs, as, Xl, Xa, Dre, E, W;
+  bool compact;
+  int Mr, Mt, M1, Mq;
+};
+struct CellBuf { int64_t xp, a, z, rr, rx, hh, out; };
+struct FwdBuf {
+  int64_t offsets, pair2claim, has, lens_eff, rowc, maskf_p;
+  CellBuf q, c1, c2;
+  int64_t q_repr, score_x, score, keep;
+  int64_t uw, tw, ew, ww, avg, new_left;
+  int64_t right_e, mask_e, ue, te, ee, we, att_e, y0, phi;
+  int64_t total;
+};
+struct BwdBuf {
+  int64_t d_y0, d_new_left, d_att_e, de_e, dpre_e, du_e, dright_e, d_avg;
+  int64_t de_w, dpre_w, du_w, du_c, d_q, g2, d_qhid, qs[5], sc[5], dx2;
+  int64_t total;
+};
+struct Bump {
+  int64_t off = 0;
+  int64_t take(int64_t nfloats) { const int64_t o = off; off += (nfloats + 63) & ~(int64_t)63; return o; }     // 256-byte slots
+};
+
+static int make_dims(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d) {
+  GH_REQUIRE(Mo && Ba, "get: NULL model / batch descriptor");
+  d.B = Ba->b; d.B1 = Ba->b1; d.L = Ba->l; d.R = Ba->r; d.n = Ba->n_max;
+  d.D = Mo->d; d.H = Mo->h; d.hw = Mo->word_heads; d.he = Mo->evd_heads; d.C = Mo->n_classes;
+  d.cs = Mo->claim_src_dim; d.as = Mo->article_src_dim;
+  GH_REQUIRE(d.B > 0 && d.B1 > 0 && d.L > 0 && d.R > 0 && d.n > 0, "get: bad batch sizes b=%d b1=%d l=%d r=%d n_max=%d", d.B, d.B1, d.L, d.R, d.n);
+  GH_REQUIRE(d.R <= 256 && d.L <= 256, "get: padded graph sizes above 256 nodes are not supported (l=%d r=%d)", d.L, d.R);
+  GH_REQUIRE(d.D % 4 == 0 && d.H % 4 == 0 && d.D >= 4 && d.D <= d.H && d.H <= 320,
+             "get: the composite path needs float4-shaped widths with d <= h <= 320 (d=%d h=%d); use the per-module entry points", d.D, d.H);
+  GH_REQUIRE(d.hw >= 1 && d.hw <= 8 && d.he >= 1 && d.he <= 8, "get: heads %d / %d not in [1,8]", d.hw, d.he);
+  GH_REQUIRE(d.C >= 1 && d.cs >= 0 && d.as >= 0 && d.cs % 4 == 0 && d.as % 4 == 0, "get: bad class / source widths (%d, %d, %d)", d.C, d.cs, d.as);
+  d.Xl = d.H + d.cs; d.Xa = d.H * d.hw; d.Dre = d.Xa + d.as; d.E = d.Xl + d.Dre * d.he; d.W = words_for(d.R);
+  d.compact = Ba->m_real >= 0;
+  d.Mt = d.B1 * d.R;
+  if (d.compact) {
+    GH_REQUIRE(Ba->goff && Ba->rowg && Ba->cids && Ba->maskf, "get: the node-compact layout needs goff, rowg, cids and maskf");
+    GH_REQUIRE(Ba->m_real > 0 && Ba->m_real <= d.Mt, "get: m_real=%d does not fit b1*r=%d", Ba->m_real, d.Mt);
+    d.Mr = Ba->m_real;
+    d.M1 = Ba->collapsed ? (d.Mr + 1 < d.Mt ? d.Mr + 1 : d.Mt) : d.Mt;
+    GH_REQUIRE(!(Ba->collapsed && Ba->drop_gnn > 0.f), "get: collapsed padding rows are an evaluation-mode layout (no dropout)");
+  } else {
+    d.Mr = d.Mt; d.M1 = d.Mt;
+  }
+  d.Mq = d.B * d.L;
+  return 0;
+}
+
+static void cell_buf(Bump& b, CellBuf& c, int64_t rows, int H) {
+  c.xp = b.take(rows * H); c.a = b.take(rows * H); c.z = b.take(rows * H); c.rr = b.take(rows * H);
+  c.rx = b.take(rows * H); c.hh = b.take(rows * H); c.out = b.take(rows * H);
+}
+
+static int layout(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d, FwdBuf& f, BwdBuf& w) {
+  if (int e = make_dims(Mo, Ba, d)) return e;
+  Bump b;
+  f.offsets = b.take(d.B + 1); f.pair2claim = b.take(d.B1); f.has = b.take(d.B); f.lens_eff = b.take(d.B);
+  f.rowc = b.take(d.Mr);
+  f.maskf_p = d.compact ? -1 : b.take(d.Mt);
+  // observables first (small), then the activations
+  f.phi = b.take((int64_t)d.B * d.C);
+  f.ww = b.take((int64_t)d.Mr * d.hw);
+  f.we = b.take((int64_t)d.B * d.n * d.he);
+  f.score = b.take((int64_t)d.B1 * d.R);
+  f.keep = b.take((int64_t)d.B1 * d.W * 2);
+  cell_buf(b, f.q, d.Mq, d.H);
+  f.q_repr = b.take((int64_t)d.B * d.H);
+  cell_buf(b, f.c1, d.M1, d.H);
+  f.score_x = b.take(d.M1);
+  cell_buf(b, f.c2, d.Mr, d.H);
+  f.uw = b.take((int64_t)d.B * d.H); f.tw = b.take((int64_t)d.Mr * d.H); f.ew = b.take((int64_t)d.Mr * d.hw);
+  f.avg = b.take((int64_t)d.B1 * d.Xa);
+  f.new_left = d.cs > 0 ? b.take((int64_t)d.B * d.Xl) : f.q_repr;
+  f.right_e = b.take((int64_t)d.B * d.n * d.Dre); f.mask_e = b.take((int64_t)d.B * d.n);
+  f.ue = b.take((int64_t)d.B * d.H); f.te = b.take((int64_t)d.B * d.n * d.H); f.ee = b.take((int64_t)d.B * d.n * d.he);
+  f.att_e = b.take((int64_t)d.B * d.Dre * d.he);
+  f.y0 = b.take((int64_t)d.B * d.H);
+  f.total = b.off;
+  Bump c;
+  w.d_y0 = c.take((int64_t)d.B * d.H); w.d_new_left = c.take((int64_t)d.B * d.Xl); w.d_att_e = c.take((int64_t)d.B * d.Dre * d.he);
+  w.de_e = c.take((int64_t)d.B * d.n * d.he); w.dpre_e = c.take((int64_t)d.B * d.n * d.H); w.du_e = c.take((int64_t)d.B * d.H);
+  w.dright_e = c.take((int64_t)d.B * d.n * d.Dre);
+  w.d_avg = c.take((int64_t)d.B1 * d.Xa);
+  w.de_w = c.take((int64_t)d.Mr * d.hw); w.dpre_w = c.take((int64_t)d.Mr * d.H); w.du_w = c.take((int64_t)d.B1 * d.H);
+  w.du_c = c.take((int64_t)d.B * d.H);
+  w.d_q = d.cs > 0 ? c.take((int64_t)d.B * d.H) : w.d_new_left;
+  w.g2 = c.take((int64_t)d.Mr * d.H);
+  w.d_qhid = c.take((int64_t)d.Mq * d.H);
+  for (int i = 0; i < 5; ++i) w.qs[i] = c.take((int64_t)d.Mq * d.H);
+  for (int i = 0; i < 5; ++i) w.sc[i] = c.take((int64_t)d.Mr * d.H);
+  w.dx2 = c.take((int64_t)d.Mr * d.H);
+  w.total = c.off;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- stream fork / join events
+struct DevEvents { hipEvent_t ev[6]; };
+static std::mutex g_ev_mu;
+static std::unordered_map<int, DevEvents> g_events;
+static int get_events(DevEvents& out) {
+  int dev = 0;
+  GH_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_ev_mu);
+  auto it = g_events.find(dev);
+  if (it == g_events.end()) {
+    DevEvents e;
+    for (int i = 0; i < 6; ++i) GH_CHECK_HIP(hipEventCreateWithFlags(&e.ev[i], hipEventDisableTiming));
+    it = g_events.emplace(dev, e).first;
+  }
+  out = it->second;
+  return 0;
+}
+// `to` waits for everything issued on `from` so far
+static int stream_after(hipStream_t to, hipStream_t from, hipEvent_t ev) {
+  if (to == from) return 0;
+  GH_CHECK_HIP(hipEventRecord(ev, from));
+  GH_CHECK_HIP(hipStreamWaitEvent(to, ev, 0));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- small glue kernels
+// rowc[row] = claim of feature row `row` (row -> pair through rowg, or row / R in the padded layout; pair -> claim);
+// maskf_p[row] = (id >= 1) for the padded layout; lens_eff[b] = len[b] / has[b] (+inf for a claim without evidences), so
+// that gh_masked_mean_*'s 1 / lens scale also carries the `* has` of graph_based_semantic_structure.py:213 / pad_right.
+__global__ void __launch_bounds__(256)
+rows_prep_kernel(const int32_t* __restrict__ pair2claim, const int32_t* __restrict__ rowg, int R, int Mr,
+                 int32_t* __restrict__ rowc, const int32_t* __restrict__ d_ids, float* __restrict__ maskf_p,
+                 const void* __restrict__ q_lens, int kind, const float* __restrict__ has, float* __restrict__ lens_eff, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < Mr) {
+    const int pair = rowg ? rowg[i] : i / R;
+    rowc[i] = pair2claim[pair];
+    if (maskf_p) maskf_p[i] = d_ids[i] >= 1 ? 1.f : 0.f;
+  }
+  if (i < B) {
+    float len;
+    if (kind == 0) len = reinterpret_cast<const float*>(q_lens)[i];
+    else if (kind == 1) len = (float)reinterpret_cast<const int32_t*>(q_lens)[i];
+    else len = (float)reinterpret_cast<const int64_t*>(q_lens)[i];
+    lens_eff[i] = has[i] > 0.f ? len : INFINITY;
+  }
+}
+
+// new_left[b] = [claim_src_table[src[b]] * has[b] | q_repr[b]]   (q_repr already carries has; graph_based_semantic_structure.py:113-116)
+template <typename TS>
+__global__ void __launch_bounds__(256)
+left_assemble_fwd_kernel(const float* __restrict__ table, const TS* __restrict__ src, const float* __restrict__ q_repr,
+                         const float* __restrict__ has, float* __restrict__ new_left, int cs, int H) {
+  const int b = blockIdx.x;
+  const float hb = has[b];
+  const float* tp = table + (size_t)(long long)src[b] * cs;
+  float* o = new_left + (size_t)b * (cs + H);
+  for (int i = threadIdx.x; i < cs; i += blockDim.x) o[i] = tp[i] * hb;
+  for (int i = threadIdx.x; i < H; i += blockDim.x) o[cs + i] = q_repr[(size_t)b * H + i];
+}
+// d_q[b] = d_new_left[b][cs:] ; d_table[src[b]] += d_new_left[b][:cs] * has[b], claims walked in order by ONE workgroup
+// (duplicate sources inside a batch add deterministically, no atomics)
+template <typename TS>
+__global__ void __launch_bounds__(256)
+left_assemble_bwd_kernel(const float* __restrict__ d_new_left, const TS* __restrict__ src, const float* __restrict__ has,
+                         float* __restrict__ d_q, float* __restrict__ d_table, int B, int cs, int H) {
+  for (int i = threadIdx.x; i < B * H; i += blockDim.x) {
+    const int b = i / H, c = i - b * H;
+    d_q[i] = d_new_left[(size_t)b * (cs + H) + cs + c];
+  }
+  if (!d_table) return;
+  for (int c = threadIdx.x; c < cs; c += blockDim.x)
+    for (int b = 0; b < B; ++b)
+      d_table[(size_t)(long long)src[b] * cs + c] += d_new_left[(size_t)b * (cs + H) + c] * has[b];
+}
+
+// losses.py:29-32: mean CE and its gradient in one pass.  One workgroup; claims strided over the threads; the loss is
+// reduced in a fixed order.
+__global__ void __launch_bounds__(256)
+cross_entropy_kernel(const float* __restrict__ phi, const int64_t* __restrict__ labels, int B, int C, float* __restrict__ loss,
+                     float* __restrict__ dphi) {
+  __shared__ float part[256];
+  float acc = 0.f;
+  const float invb = 1.f / (float)B;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float* p = phi + (size_t)b * C;
+    float mx = p[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(p[c] - mx);
+    const float lse = mx + logf(se);
+    const int y = (int)labels[b];
+    acc += lse - p[y];
+    for (int c = 0; c < C; ++c) dphi[(size_t)b * C + c] = (expf(p[c] - lse) - (c == y ? 1.f : 0.f)) * invb;
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = part[0] * invb;
+}
+
+// document[slot[g]][:] = d_ids[g][:]   (padded layout; the node-compact plan's fill kernel does it on the way)
+__global__ void __launch_bounds__(256)
+document_scatter_kernel(const int32_t* __restrict__ d_ids, const int64_t* __restrict__ slot, int32_t* __restrict__ document, int R) {
+  const int g = blockIdx.x;
+  const size_t dst = (size_t)slot[g] * R;
+  for (int j = threadIdx.x; j < R; j += blockDim.x) document[dst + j] = d_ids[(size_t)g * R + j];
+}
+
+}  // namespace gh
+
+using namespace gh;
+
+extern "C" int gh_get_plan_buffers(const gh_get_model* Mo, const gh_get_batch* Ba, gh_get_plan* P) {
+  GH_REQUIRE(P, "get_plan_buffers: NULL plan");
+  Dims d; FwdBuf f; BwdBuf w;
+  if (int e = layout(Mo, Ba, d, f, w)) return e;
+  P->fwd_floats = f.total; P->bwd_floats = w.total;
+  P->phi = f.phi; P->word_w = f.ww; P->evd_w = f.we; P->score = f.score; P->keep = f.keep;
+  return 0;
+}
+
+extern "C" int gh_get_struct_sizes(int64_t* out) {
+  GH_REQUIRE(out, "get_struct_sizes: NULL");
+  out[0] = sizeof(gh_get_model); out[1] = sizeof(gh_get_batch); out[2] = sizeof(gh_get_plan); out[3] = sizeof(gh_cell_params);
+  return 0;
+}
+
+#define GH_TRY(expr) do { if (int _rc = (expr)) return _rc; } while (0)
+
+static inline const int32_t* I32(const float* A, int64_t off) { return reinterpret_cast<const int32_t*>(A + off); }
+static inline int32_t* I32(float* A, int64_t off) { return reinterpret_cast<int32_t*>(A + off); }
+
+static int cell_fwd(const gh_cell_params& c, const CellBuf& cb, float* A, const uint64_t* bits, const float* dinv, const float* vals,
+                    const uint64_t* keep, const int32_t* goff, int m_real, int m_rows, const float* x, const int32_t* ids, int n, int r,
+                    int din, int h, float drop_p, uint32_t seed, const float* score_w, float* score_x, float sdrop, uint32_t sseed,
+                    hipStream_t s) {
+  return cell_fwd_impl(0, nullptr, bits, dinv, vals, keep, goff, m_real, m_rows, x, ids, n, r, din, h, c.w_p, c.w_z0, c.w_z1, c.w_r0,
+                       c.w_r1, c.w_h0, c.w_h1, c.b_z0, c.b_z1, c.b_r0, c.b_r1, c.b_h0, c.b_h1, A + cb.xp, A + cb.a, A + cb.z,
+                       A + cb.rr, A + cb.rx, A + cb.hh, A + cb.out, drop_p, seed, score_w, score_x, sdrop, sseed, (void*)s);
+}
+static int cell_bwd(const gh_cell_params& c, const CellBuf& cb, const float* A, const uint64_t* bits, const float* dinv,
+                    const float* vals, const uint64_t* keep, const int32_t* goff, int m_real, const float* x, const int32_t* ids, int n,
+                    int r, int din, int h, const float* g, float* W, const int64_t* sc, float* dx, float drop_p, uint32_t seed,
+                    hipStream_t s) {
+  GH_REQUIRE(c.wt_p && c.dw_p && c.db_z0 && c.db_z1, "get_backward: a cell's transposes / gradient outputs are missing");
+  return cell_bwd_impl(0, bits, dinv, vals, keep, goff, m_real, x, ids, n, r, din, h, c.wt_p, c.wt_z0, c.wt_z1, c.wt_r0, c.wt_r1,
+                       c.wt_h0, c.wt_h1, A + cb.xp, A + cb.a, A + cb.z, A + cb.rr, A + cb.rx, A + cb.hh, g, W + sc[0], W + sc[1],
+                       W + sc[2], W + sc[3], W + sc[4], dx, c.dw_p, c.dw_z0, c.dw_z1, c.dw_r0, c.dw_r1, c.dw_h0, c.dw_h1, c.db_z0,
+                       c.db_r0, c.db_h0, c.db_z1, c.db_r1, c.db_h1, drop_p, seed, (void*)s);
+}
+
+extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, float* A, gh_stream_t stream, gh_stream_t side_stream) {
+  Dims d; FwdBuf f; BwdBuf w;
+  GH_TRY(layout(Mo, Ba, d, f, w));
+  GH_REQUIRE(A && (reinterpret_cast<uintptr_t>(A) & 255) == 0, "get_forward: the arena must be 256-byte aligned");
+  GH_REQUIRE(Mo->embedding && Mo->scorer_w && Mo->scorer_gate && Mo->out0_w && Mo->out1_w, "get_forward: missing model tensors");
+  GH_REQUIRE((d.cs == 0) == (Mo->claim_src_table == nullptr) && (d.as == 0) == (Mo->article_src_table == nullptr),
+             "get_forward: source tables and their widths must come together");
+  GH_REQUIRE(Ba->drop_claim >= 0.f && Ba->drop_claim < 1.f && Ba->drop_gnn >= 0.f && Ba->drop_gnn < 1.f, "get_forward: dropout p not in [0,1)");
+  hipStream_t s = (hipStream_t)stream, ss = side_stream ? (hipStream_t)side_stream : s;
+  DevEvents ev;
+  GH_TRY(get_events(ev));
+  const int H = d.H;
+  // ---- claim -> pair map, row -> claim map, masks
+  GH_TRY(gh_seg_offsets(Ba->counts, d.B, I32(A, f.offsets), I32(A, f.pair2claim), d.B1, A + f.has, (void*)s));
+  {
+    const int nthr = d.Mr > d.B ? d.Mr : d.B;
+    hipLaunchKernelGGL(rows_prep_kernel, dim3((nthr + 255) / 256), dim3(256), 0, s, I32(A, f.pair2claim), d.compact ? Ba->rowg : nullptr, d.R,
+                       d.Mr, I32(A, f.rowc), Ba->d_ids, d.compact ? nullptr : A + f.maskf_p, Ba->q_lens, Ba->q_lens_kind, A + f.has,
+                       A + f.lens_eff, d.B);
+    GH_LAUNCH_CHECK();
+  }
+  // ---- claim branch on the side stream (graph_based_semantic_structure.py:144-155): cell -> masked mean (x has)
+  GH_TRY(stream_after(ss, s, ev.ev[0]));
+  GH_TRY(cell_fwd(Mo->claim, f.q, A, Ba->q_bits, Ba->q_dinv, Ba->q_vals, nullptr, nullptr, 0, 0, Mo->embedding, Ba->q_ids, d.B, d.L, d.D, H,
+                  Ba->drop_claim, Ba->seed_claim, nullptr, nullptr, 0.f, 0, ss));
+  GH_TRY(gh_masked_mean_fwd(A + f.q.out, Ba->q_ids, A + f.lens_eff, A + f.q_repr, d.B, d.L, H, (void*)ss));
+  if (d.cs > 0) {
+    if (Ba->query_sources_i64)
+      hipLaunchKernelGGL(left_assemble_fwd_kernel<int64_t>, dim3(d.B), dim3(256), 0, ss, Mo->claim_src_table, (const int64_t*)Ba->query_sources,
+                         A + f.q_repr, A + f.has, A + f.new_left, d.cs, H);
+    else
+      hipLaunchKernelGGL(left_assemble_fwd_kernel<int32_t>, dim3(d.B), dim3(256), 0, ss, Mo->claim_src_table, (const int32_t*)Ba->query_sources,
+                         A + f.q_repr, A + f.has, A + f.new_left, d.cs, H);
+    GH_LAUNCH_CHECK();
+  }
+  // ---- evidence branch (:107; wrapper.py:165-172): cell -> scorer + top-k -> cell on the refined graph
+  const int32_t* goff = d.compact ? Ba->goff : nullptr;
+  const int32_t* ids1 = d.compact ? Ba->cids : Ba->d_ids;
+  GH_TRY(cell_fwd(Mo->cell1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, d.M1, Mo->embedding, ids1, d.B1, d.R, d.D, H,
+                  Ba->drop_gnn, Ba->seed_cell1, Mo->scorer_w, A + f.score_x, Ba->drop_gnn, Ba->seed_scorer, s));
+  uint64_t* keep = reinterpret_cast<uint64_t*>(A + f.keep);
+  GH_TRY(gh_scorer_gsl(Ba->d_bits, Ba->d_dinv, Ba->d_vals, goff, (d.compact && Ba->collapsed) ? 1 : 0, nullptr, A + f.score_x, Mo->scorer_w,
+                       Mo->scorer_gate, d.B1, d.R, H, Ba->k_keep, A + f.score, keep, 0.f, 0, (void*)s));
+  GH_TRY(cell_fwd(Mo->cell2, f.c2, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, keep, goff, d.Mr, d.Mr, A + f.c1.out, nullptr, d.B1, d.R, H, H,
+                  Ba->drop_gnn, Ba->seed_cell2, nullptr, nullptr, 0.f, 0, s));
+  GH_TRY(stream_after(s, ss, ev.ev[1]));
+  // ---- word-level attention (:173-193): the left input is the claim vector -> ONE u row per claim
+  GH_TRY(att_fwd_impl(A + f.q_repr, d.B, I32(A, f.rowc), A + f.c2.out, d.compact ? Ba->maskf : A + f.maskf_p, goff,
+                      d.compact ? Ba->rowg : nullptr, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1, Mo->att_word.w2, A + f.uw, A + f.tw,
+                      A + f.ew, A + f.ww, A + f.avg, s));
+  // ---- evidence-level assembly + attention (:157-171, :195-221)
+  GH_TRY(gh_evd_assemble_fwd(A + f.avg, I32(A, f.offsets), Mo->article_src_table, d.as > 0 ? Ba->doc_sources : nullptr, Ba->doc_sources_i64,
+                             Ba->document, Ba->document_i64, d.B, d.n, d.Xa, d.as, d.R, A + f.right_e, A + f.mask_e, (void*)s));
+  GH_TRY(att_fwd_impl(A + f.new_left, d.B, nullptr, A + f.right_e, A + f.mask_e, nullptr, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he,
+                      Mo->att_evd.w1, Mo->att_evd.w2, A + f.ue, A + f.te, A + f.ee, A + f.we, A + f.att_e, s));
+  // ---- head (:251-267, :69-74): Linear([claim | attended evidences]) -> Linear, no activation
+  GH_TRY(linear2_fwd(A + f.new_left, d.Xl, A + f.att_e, d.Dre * d.he, Mo->out0_w, Mo->out0_b, A + f.y0, d.B, H, s));
+  GH_TRY(gh_linear_fwd(A + f.y0, Mo->out1_w, Mo->out1_b, A + f.phi, d.B, H, d.C, (void*)s));
+  return 0;
+}
+
+extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, const float* A, float* Wb, const float* g_phi,
+                               const float* g_word_w, const float* g_evd_w, int phase, gh_stream_t stream, gh_stream_t side_stream) {
+  Dims d; FwdBuf f; BwdBuf w;
+  GH_TRY(layout(Mo, Ba, d, f, w));
+  GH_REQUIRE(phase >= 0 && phase <= 2, "get_backward: phase %d not in {0,1,2}", phase);
+  GH_REQUIRE(A && Wb && g_phi, "get_backward: NULL arena / gradient");
+  GH_REQUIRE(Mo->out0_wt && Mo->out1_wt && Mo->att_word.w1t && Mo->att_evd.w1t && Mo->d_out0_w && Mo->d_out0_b && Mo->d_out1_w &&
+             Mo->d_out1_b && Mo->att_word.dw1 && Mo->att_word.dw2 && Mo->att_evd.dw1 && Mo->att_evd.dw2,
+             "get_backward: transposes / gradient outputs of the attention layers or the head are missing");
+  hipStream_t s = (hipStream_t)stream, ss = side_stream ? (hipStream_t)side_stream : s;
+  DevEvents ev;
+  GH_TRY(get_events(ev));
+  const int H = d.H;
+  const int32_t* goff = d.compact ? Ba->goff : nullptr;
+  const int32_t* ids1 = d.compact ? Ba->cids : Ba->d_ids;
+  const uint64_t* keep = reinterpret_cast<const uint64_t*>(A + f.keep);
+  if (phase != 2) {
+    // ---- head
+    GH_TRY(gh_linear_bwd(A + f.y0, Mo->out1_wt, Mo->out1_w, g_phi, d.B, H, d.C, Wb + w.d_y0, Mo->d_out1_w, Mo->d_out1_b, (void*)s));
+    GH_TRY(linear2_bwd(A + f.new_left, d.Xl, A + f.att_e, d.Dre * d.he, Mo->out0_wt, Wb + w.d_y0, d.B, H, Wb + w.d_new_left, 0,
+                       Wb + w.d_att_e, nullptr, nullptr, s));
+    GH_TRY(stream_after(ss, s, ev.ev[2]));          // few-row weight gradients leave the critical path
+    GH_TRY(linear2_bwd(A + f.new_left, d.Xl, A + f.att_e, d.Dre * d.he, Mo->out0_wt, Wb + w.d_y0, d.B, H, nullptr, 0, nullptr,
+                       Mo->d_out0_w, Mo->d_out0_b, ss));
+    // ---- evidence-level attention; its left gradient adds to the head's
+    GH_TRY(att_bwd_impl(A + f.new_left, A + f.right_e, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he, Mo->att_evd.w1t, Mo->att_evd.w2, A + f.te,
+                        A + f.we, Wb + w.d_att_e, g_evd_w, Wb + w.de_e, Wb + w.dpre_e, Wb + w.du_e, Wb + w.d_new_left, Wb + w.dright_e,
+                        nullptr, Mo->att_evd.dw2, nullptr, d.B, nullptr, 1, s));
+    GH_TRY(stream_after(ss, s, ev.ev[3]));
+    GH_TRY(att_bwd_impl(A + f.new_left, A + f.right_e, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he, Mo->att_evd.w1t, Mo->att_evd.w2, A + f.te,
+                        A + f.we, Wb + w.d_att_e, g_evd_w, Wb + w.de_e, Wb + w.dpre_e, Wb + w.du_e, nullptr, nullptr, Mo->att_evd.dw1,
+                        Mo->att_evd.dw2, nullptr, d.B, nullptr, 0, ss));
+    // ---- evidence-level assembly: d_avg (rows of claims with more than n_max evidences stay zero), article-source table
+    if (!Ba->counts_fit) GH_CHECK_HIP(hipMemsetAsync(Wb + w.d_avg, 0, sizeof(float) * (size_t)d.B1 * d.Xa, s));
+    GH_TRY(gh_evd_assemble_bwd(Wb + w.dright_e, I32(A, f.offsets), d.as > 0 ? Ba->doc_sources : nullptr, Ba->doc_sources_i64, d.B, d.n, d.Xa,
+                               d.as, Wb + w.d_avg, d.as > 0 ? Mo->d_article_src_table : nullptr, (void*)s));
+    if (d.cs > 0) {
+      if (Ba->query_sources_i64)
+        hipLaunchKernelGGL(left_assemble_bwd_kernel<int64_t>, dim3(1), dim3(256), 0, s, Wb + w.d_new_left, (const int64_t*)Ba->query_sources,
+                           A + f.has, Wb + w.d_q, Mo->d_claim_src_table, d.B, d.cs, H);
+      else
+        hipLaunchKernelGGL(left_assemble_bwd_kernel<int32_t>, dim3(1), dim3(256), 0, s, Wb + w.d_new_left, (const int32_t*)Ba->query_sources,
+                           A + f.has, Wb + w.d_q, Mo->d_claim_src_table, d.B, d.cs, H);
+      GH_LAUNCH_CHECK();
+    }
+    // ---- word-level attention: per-pair du summed per claim; d(claim vector) accumulates on top of the head / evidence part
+    GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
+                        A + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, Wb + w.g2, Mo->att_word.dw1,
+                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, s));
+    // ---- claim branch backward on the side stream, underneath the evidence cells
+    GH_TRY(stream_after(ss, s, ev.ev[4]));
+    GH_TRY(gh_masked_mean_bwd(Wb + w.d_q, Ba->q_ids, A + f.lens_eff, Wb + w.d_qhid, d.B, d.L, H, (void*)ss));
+    GH_TRY(cell_bwd(Mo->claim, f.q, A, Ba->q_bits, Ba->q_dinv, Ba->q_vals, nullptr, nullptr, 0, Mo->embedding, Ba->q_ids, d.B, d.L, d.D, H,
+                    Wb + w.d_qhid, Wb, w.qs, nullptr, Ba->drop_claim, Ba->seed_claim, ss));
+    // ---- second evidence cell
+    GH_TRY(cell_bwd(Mo->cell2, f.c2, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, keep, goff, d.Mr, A + f.c1.out, nullptr, d.B1, d.R, H, H,
+                    Wb + w.g2, Wb, w.sc, Wb + w.dx2, Ba->drop_gnn, Ba->seed_cell2, s));
+  }
+  if (phase != 1) {
+    GH_TRY(cell_bwd(Mo->cell1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, Mo->embedding, ids1, d.B1, d.R, d.D, H,
+                    Wb + w.dx2, Wb, w.sc, nullptr, Ba->drop_gnn, Ba->seed_cell1, s));
+    GH_TRY(stream_after(s, ss, ev.ev[5]));
+  }
+  return 0;
+}
+
+extern "C" int gh_cross_entropy(const float* phi, const int64_t* labels, int b, int c, float* loss, float* dphi, gh_stream_t stream) {
+  GH_REQUIRE(b > 0 && c > 0 && phi && labels && loss && dphi, "cross_entropy: bad arguments");
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, phi, labels, b, c, loss, dphi);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gh_get_prepare(const int32_t* claim_tokens, const int32_t* claim_len, int b, int l,
+                              const int32_t* evd_tokens, const int32_t* evd_len, int b1, int r, int window,
+                              int32_t* q_ids, int32_t* q_n, uint64_t* q_bits, float* q_dinv,
+                              int32_t* d_ids, int32_t* d_n, uint64_t* d_bits, float* d_dinv,
+                              int m_real, int32_t* goff, int32_t* rowg, int32_t* src, int32_t* cids, float* maskf,
+                              const int64_t* slot, int32_t* document, gh_stream_t stream) {
+  GH_TRY(gh_graph_build(claim_tokens, claim_len, b, l, window, q_ids, q_n, q_bits, q_dinv, stream));
+  GH_TRY(gh_graph_build(evd_tokens, evd_len, b1, r, window, d_ids, d_n, d_bits, d_dinv, stream));
+  if (m_real >= 0 && b1 > 0)
+    GH_TRY(gh_ragged_plan(d_n, d_ids, b1, r, goff, rowg, src, cids, maskf, stream));
+  if (slot && document && b1 > 0) {
+    hipLaunchKernelGGL(document_scatter_kernel, dim3(b1), dim3(256), 0, (hipStream_t)stream, d_ids, slot, document, r);
+    GH_LAUNCH_CHECK();
+  }
+  return 0;
+}

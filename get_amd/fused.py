@@ -1,0 +1,415 @@
+"""The whole GET forward / backward as ONE library call each (include/get_hip.h: gh_get_forward / gh_get_backward).
+
+``Graph_basedSemantiStructure.forward`` routes through :func:`forward` whenever the model/batch qualify (fp32 mode,
+frozen word table, float4-shaped widths with d <= h <= 320 -- every shape BASELINE.json's fp32 configs name); anything
+else keeps the module-by-module path of get_amd/modules.py + get_amd/ops.py, which stays the API for callers that use
+the reference's modules one by one.  Same kernels underneath; what disappears is ~120 Python -> ctypes -> autograd round
+trips per training step (~2.2 ms of host time, the bound of the realistic-evidence-count regime) and the at::native
+glue between them.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+from . import _lib, ops
+from .keywords import KeyWordSettings as K
+from .ops import PackedAdj
+
+ENABLED = os.environ.get("GET_AMD_FUSED", "1") != "0"
+
+_P, _I, _F, _U, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint32, ctypes.c_int64
+
+_CELL_W = ["w_p", "w_z0", "w_z1", "w_r0", "w_r1", "w_h0", "w_h1"]
+_CELL_B = ["b_z0", "b_z1", "b_r0", "b_r1", "b_h0", "b_h1"]
+
+
+class CellParams(ctypes.Structure):
+    _fields_ = ([(n, _P) for n in _CELL_W] + [(n, _P) for n in _CELL_B] + [("wt" + n[1:], _P) for n in _CELL_W] +
+                [("d" + n, _P) for n in _CELL_W] + [("d" + n, _P) for n in _CELL_B])
+
+
+class AttParams(ctypes.Structure):
+    _fields_ = [("w1", _P), ("w2", _P), ("w1t", _P), ("dw1", _P), ("dw2", _P)]
+
+
+class GetModel(ctypes.Structure):
+    _fields_ = [("d", _I), ("h", _I), ("word_heads", _I), ("evd_heads", _I), ("n_classes", _I),
+                ("claim_src_dim", _I), ("article_src_dim", _I),
+                ("embedding", _P),
+                ("claim", CellParams), ("cell1", CellParams), ("cell2", CellParams),
+                ("scorer_w", _P), ("scorer_gate", _P),
+                ("att_word", AttParams), ("att_evd", AttParams),
+                ("claim_src_table", _P), ("article_src_table", _P),
+                ("d_claim_src_table", _P), ("d_article_src_table", _P),
+                ("out0_w", _P), ("out0_b", _P), ("out0_wt", _P),
+                ("out1_w", _P), ("out1_b", _P), ("out1_wt", _P),
+                ("d_out0_w", _P), ("d_out0_b", _P), ("d_out1_w", _P), ("d_out1_b", _P)]
+
+
+class GetBatch(ctypes.Structure):
+    _fields_ = [("b", _I), ("b1", _I), ("l", _I), ("r", _I), ("n_max", _I),
+                ("m_real", _I), ("collapsed", _I), ("k_keep", _I),
+                ("q_ids", _P), ("q_lens", _P), ("q_lens_kind", _I),
+                ("q_bits", _P), ("q_dinv", _P), ("q_vals", _P),
+                ("d_ids", _P), ("d_bits", _P), ("d_dinv", _P), ("d_vals", _P),
+                ("goff", _P), ("rowg", _P), ("cids", _P), ("maskf", _P),
+                ("counts", _P), ("counts_fit", _I),
+                ("doc_sources", _P), ("doc_sources_i64", _I),
+                ("query_sources", _P), ("query_sources_i64", _I),
+                ("document", _P), ("document_i64", _I),
+                ("drop_claim", _F), ("drop_gnn", _F),
+                ("seed_claim", _U), ("seed_cell1", _U), ("seed_scorer", _U), ("seed_cell2", _U)]
+
+
+class GetPlan(ctypes.Structure):
+    _fields_ = [("fwd_floats", _L), ("bwd_floats", _L), ("phi", _L), ("word_w", _L), ("evd_w", _L), ("score", _L), ("keep", _L)]
+
+
+def _cell_tensors(cell):
+    """(weights[7], biases[6]) of a modules.GGNN in the C struct's order."""
+    g = lambda m: m.linear
+    ws = [cell.proj.linear.weight, g(cell.linearz0).weight, g(cell.linearz1).weight, g(cell.linearr0).weight,
+          g(cell.linearr1).weight, g(cell.linearh0).weight, g(cell.linearh1).weight]
+    bs = [g(cell.linearz0).bias, g(cell.linearz1).bias, g(cell.linearr0).bias, g(cell.linearr1).bias,
+          g(cell.linearh0).bias, g(cell.linearh1).bias]
+    return ws, bs
+
+
+class Binding:
+    """Everything of one model the composite calls need, in the C struct's order: the parameter tensors (weights as stored),
+    their cached transposes, and where the gradients go.  Rebuilt only when a pointer moved (checked per call with one
+    tuple comparison of the data pointers)."""
+
+    def __init__(self, model):
+        self.model = model
+        gw = model.ggnn_with_gsl
+        self.cells = [model.ggnn4claim_1, gw.feat_prop1, gw.feat_prop2]
+        self.params = []          # live parameters in a fixed order (gradient outputs follow the same order)
+        self.mats = []            # those that need a transpose in the backward
+        for c in self.cells:
+            ws, bs = _cell_tensors(c)
+            self.params += ws + bs
+            self.mats += ws
+        aw, ae = model.self_att_word, model.self_att_evd
+        self.params += [aw.linear1.weight, aw.linear2.weight, ae.linear1.weight, ae.linear2.weight]
+        self.mats += [aw.linear1.weight, ae.linear1.weight]
+        self.params += [model.out[0].weight, model.out[0].bias, model.out[1].weight, model.out[1].bias]
+        self.mats += [model.out[0].weight, model.out[1].weight]
+        self.tables = []
+        if model.use_claim_source:
+            self.tables.append(model.claim_source_embs.weight)
+        if model.use_article_source:
+            self.tables.append(model.article_source_embs.weight)
+        self.struct = {False: None, True: None}      # cached GetModel per need_grads
+        self._sig = {False: None, True: None}
+        self._mat_ids = [id(m) for m in self.mats]
+        self._checked = False
+
+    def eligible(self) -> bool:
+        m = self.model
+        d = m.embedding.weight.shape[1]
+        h = m.hidden_size
+        cs = m.claim_emb_size if m.use_claim_source else 0
+        as_ = m.article_emb_size if m.use_article_source else 0
+        return (not m.embedding.weight.requires_grad and d % 4 == 0 and h % 4 == 0 and 4 <= d <= h <= 320 and
+                1 <= m.num_att_heads_for_words <= 8 and 1 <= m.num_att_heads_for_evds <= 8 and cs % 4 == 0 and as_ % 4 == 0 and
+                m.ggnn4claim_1.proj.linear.weight.shape == (h, d) and m.out[1].weight.shape[1] == h and
+                all(p.dtype == torch.float32 and p.is_contiguous() for p in self.params))
+
+    def get(self, need_grads: bool):
+        """-> (GetModel struct, direct, grad_buffer or None, views or None).  direct: the kernels accumulate straight into the
+        parameters' .grad (FlatTrainer bucket); otherwise a zeroed flat buffer receives them and `views` maps id(parameter)
+        to its slice (returned to autograd)."""
+        if not self._checked:          # the ctypes mirrors must have the C structs' sizes
+            sz = (ctypes.c_int64 * 4)()
+            _lib.call("gh_get_struct_sizes", ctypes.cast(sz, ctypes.c_void_p))
+            mine = (ctypes.sizeof(GetModel), ctypes.sizeof(GetBatch), ctypes.sizeof(GetPlan), ctypes.sizeof(CellParams))
+            if tuple(sz) != mine:
+                raise RuntimeError(f"get_amd: struct layout mismatch between fused.py {mine} and libget_hip.so {tuple(sz)}")
+            self._checked = True
+        m = self.model
+        direct = need_grads and all(ops._direct(p) for p in self.params) and all((not t.requires_grad) or ops._direct(t) for t in self.tables)
+        wts = [ops.transposed(w) for w in self.mats] if need_grads else None
+        gscorer = m.ggnn_with_gsl._gate12()
+        sig = (tuple(p.data_ptr() for p in self.params), tuple(t.data_ptr() for t in self.tables),
+               tuple(t.data_ptr() for t in wts) if wts else None,
+               tuple(p.grad.data_ptr() for p in self.params) if direct else None,
+               tuple((t.grad.data_ptr() if t.requires_grad else 0) for t in self.tables) if direct else None,
+               m.embedding.weight.data_ptr(), gscorer.data_ptr(), m.ggnn_with_gsl.word_scorer1.proj.linear.weight.data_ptr())
+        gbuf = views = None
+        if need_grads and not direct:
+            sizes = [(p.numel() + 63) // 64 * 64 for p in self.params] + [(t.numel() + 63) // 64 * 64 for t in self.tables]
+            gbuf = torch.zeros(sum(sizes), device=self.params[0].device, dtype=torch.float32)
+            views, off = {}, 0
+            for t, sz in zip(self.params + self.tables, sizes):
+                views[id(t)] = gbuf[off:off + t.numel()].view_as(t)
+                off += sz
+        if self.struct[need_grads] is not None and sig == self._sig[need_grads] and gbuf is None:
+            return self.struct[need_grads], direct, None, None
+        S = GetModel()
+        S.d, S.h = m.embedding.weight.shape[1], m.hidden_size
+        S.word_heads, S.evd_heads, S.n_classes = m.num_att_heads_for_words, m.num_att_heads_for_evds, m.out[1].weight.shape[0]
+        S.claim_src_dim = m.claim_emb_size if m.use_claim_source else 0
+        S.article_src_dim = m.article_emb_size if m.use_article_source else 0
+        S.embedding = m.embedding.weight.data_ptr()
+        gptr = None
+        if need_grads:
+            gl = [p.grad for p in self.params] if direct else [views[id(p)] for p in self.params]
+            gptr = [g.data_ptr() for g in gl]
+        wt_of = {i: t.data_ptr() for i, t in zip(self._mat_ids, wts)} if wts else {}
+        k = 0
+        for cs_, cell in zip((S.claim, S.cell1, S.cell2), self.cells):
+            ws, bs = _cell_tensors(cell)
+            for name, t in zip(_CELL_W, ws):
+                setattr(cs_, name, t.data_ptr())
+                if need_grads:
+                    setattr(cs_, "wt" + name[1:], wt_of[id(t)])
+                    setattr(cs_, "d" + name, gptr[k])
+                k += 1
+            for name, t in zip(_CELL_B, bs):
+                setattr(cs_, name, t.data_ptr())
+                if need_grads:
+                    setattr(cs_, "d" + name, gptr[k])
+                k += 1
+        S.scorer_w = m.ggnn_with_gsl.word_scorer1.proj.linear.weight.data_ptr()
+        S.scorer_gate = gscorer.data_ptr()
+        self._keep_alive = (gscorer, wts)
+        for a_, att in zip((S.att_word, S.att_evd), (m.self_att_word, m.self_att_evd)):
+            a_.w1, a_.w2 = att.linear1.weight.data_ptr(), att.linear2.weight.data_ptr()
+            if need_grads:
+                a_.w1t = wt_of[id(att.linear1.weight)]
+                a_.dw1, a_.dw2 = gptr[k], gptr[k + 1]
+            k += 2
+        S.out0_w, S.out0_b = m.out[0].weight.data_ptr(), m.out[0].bias.data_ptr()
+        S.out1_w, S.out1_b = m.out[1].weight.data_ptr(), m.out[1].bias.data_ptr()
+        if need_grads:
+            S.out0_wt, S.out1_wt = wt_of[id(m.out[0].weight)], wt_of[id(m.out[1].weight)]
+            S.d_out0_w, S.d_out0_b, S.d_out1_w, S.d_out1_b = gptr[k], gptr[k + 1], gptr[k + 2], gptr[k + 3]
+        k += 4
+        for use, fld, tab in ((m.use_claim_source, "claim_src_table", getattr(m, "claim_source_embs", None)),
+                              (m.use_article_source, "article_src_table", getattr(m, "article_source_embs", None))):
+            if not use:
+                continue
+            w = tab.weight
+            setattr(S, fld, w.data_ptr())
+            if need_grads and w.requires_grad:
+                setattr(S, "d_" + fld, w.grad.data_ptr() if direct else views[id(w)].data_ptr())
+        if gbuf is None:
+            self.struct[need_grads], self._sig[need_grads] = S, sig
+        return S, direct, gbuf, views
+
+
+def _binding(model) -> Binding:
+    b = model.__dict__.get("_gh_binding")
+    if b is None:
+        b = Binding(model)
+        model.__dict__["_gh_binding"] = b
+    return b
+
+
+def _i32(t):
+    return t if t.dtype == torch.int32 and t.is_contiguous() else t.to(torch.int32).contiguous()
+
+
+class _Prepared:
+    """One forward's batch descriptor plus the tensors it points into (kept alive until the backward has run)."""
+    __slots__ = ("struct", "keep", "b", "b1", "r", "plan", "n_max", "hw", "he", "rows", "w", "c")
+
+
+def _prepare(model, query, document, kargs, q_adj: PackedAdj, d_adj: PackedAdj, plan, doc):
+    m = model
+    B, L = query.shape
+    n_max = int(kargs[K.FIXED_NUM_EVIDENCES])
+    b1, R = doc.shape
+    S = GetBatch()
+    S.b, S.b1, S.l, S.r, S.n_max = B, b1, L, R, n_max
+    training = m.training
+    S.collapsed = 0
+    if plan is not None:
+        S.m_real = plan.m_real
+        S.collapsed = 0 if training else 1
+        S.goff, S.rowg, S.cids, S.maskf = plan.goff.data_ptr(), plan.rowg.data_ptr(), plan.cids.data_ptr(), plan.maskf.data_ptr()
+        rows = plan.m_real
+    else:
+        S.m_real = -1
+        rows = b1 * R
+    S.k_keep = int(m.ggnn_with_gsl.gsl1.rate * R)
+    q_ids = _i32(query)
+    d_ids = _i32(doc)
+    q_lens = kargs[K.Query_lens]
+    if q_lens.dtype not in (torch.float32, torch.int32, torch.int64):
+        q_lens = q_lens.float()
+    q_lens = q_lens.contiguous()
+    counts = kargs[K.EvidenceCountPerQuery]
+    fit = bool(getattr(counts, "_gh_fit", False))
+    if counts.dtype != torch.int64 or not counts.is_contiguous():
+        counts = counts.to(torch.int64).contiguous()
+    S.q_ids, S.q_lens = q_ids.data_ptr(), q_lens.data_ptr()
+    S.q_lens_kind = {torch.float32: 0, torch.int32: 1, torch.int64: 2}[q_lens.dtype]
+    S.q_bits = q_adj.bits.data_ptr()
+    S.q_dinv = q_adj.dinv.data_ptr() if q_adj.dinv is not None else None
+    S.q_vals = q_adj.vals.data_ptr() if q_adj.vals is not None else None
+    S.d_ids = d_ids.data_ptr()
+    S.d_bits = d_adj.bits.data_ptr()
+    S.d_dinv = d_adj.dinv.data_ptr() if d_adj.dinv is not None else None
+    S.d_vals = d_adj.vals.data_ptr() if d_adj.vals is not None else None
+    S.counts, S.counts_fit = counts.data_ptr(), 1 if fit else 0
+    keep = [q_ids, d_ids, q_lens, counts, q_adj, d_adj, plan]
+    if m.use_article_source:
+        src = kargs[K.DocSources]
+        if src.dtype not in (torch.int32, torch.int64):
+            src = src.long()
+        src = src.contiguous()
+        assert src.numel() == B * n_max
+        S.doc_sources, S.doc_sources_i64 = src.data_ptr(), 1 if src.dtype == torch.int64 else 0
+        keep.append(src)
+    if m.use_claim_source:
+        qs = kargs[K.QuerySources]
+        if qs.dtype not in (torch.int32, torch.int64):
+            qs = qs.long()
+        qs = qs.contiguous()
+        assert qs.numel() == B
+        S.query_sources, S.query_sources_i64 = qs.data_ptr(), 1 if qs.dtype == torch.int64 else 0
+        keep.append(qs)
+    dc = document
+    if dc.dtype not in (torch.int32, torch.int64):
+        dc = dc.long()
+    dc = dc.contiguous()
+    assert dc.numel() == B * n_max * R
+    S.document, S.document_i64 = dc.data_ptr(), 1 if dc.dtype == torch.int64 else 0
+    keep.append(dc)
+    p_claim = float(m.ggnn4claim_1.dropout.p) if (training and hasattr(m.ggnn4claim_1, "dropout")) else 0.0
+    fp1 = m.ggnn_with_gsl.feat_prop1
+    p_gnn = float(fp1.dropout.p) if (training and hasattr(fp1, "dropout")) else 0.0
+    S.drop_claim, S.drop_gnn = p_claim, p_gnn
+    if p_claim > 0.0 or p_gnn > 0.0:
+        seeds = torch.randint(0, 2 ** 31 - 1, (4,)).tolist()      # torch's CPU generator (follows torch.manual_seed)
+        S.seed_claim, S.seed_cell1, S.seed_scorer, S.seed_cell2 = seeds
+    P = _Prepared()
+    P.struct, P.keep, P.b, P.b1, P.r, P.plan, P.n_max = S, keep, B, b1, R, plan, n_max
+    P.hw, P.he, P.rows, P.w, P.c = m.num_att_heads_for_words, m.num_att_heads_for_evds, rows, (R + 63) // 64, m.out[1].weight.shape[0]
+    return P
+
+
+class _GetFused(torch.autograd.Function):
+    """graph_based_semantic_structure.py:76-125 in one forward and one backward library call."""
+
+    @staticmethod
+    def forward(ctx, binding: Binding, prep: _Prepared, side, *anchors):
+        dev = anchors[0].device
+        M, _, _, _ = binding.get(False)
+        plan = GetPlan()
+        _lib.call("gh_get_plan_buffers", ctypes.addressof(M), ctypes.addressof(prep.struct), ctypes.addressof(plan))
+        arena = torch.empty(plan.fwd_floats, device=dev, dtype=torch.float32)
+        main = _lib.stream()
+        side_raw = side.cuda_stream if side is not None else main
+        if side is not None:
+            arena.record_stream(side)
+        _lib.call("gh_get_forward", ctypes.addressof(M), ctypes.addressof(prep.struct), arena.data_ptr(), main, side_raw)
+        B, b1, R = prep.b, prep.b1, prep.r
+        phi = arena[plan.phi:plan.phi + B * prep.c].view(B, prep.c)
+        word_w = arena[plan.word_w:plan.word_w + prep.rows * prep.hw].view(prep.rows, prep.hw)
+        evd_w = arena[plan.evd_w:plan.evd_w + B * prep.n_max * prep.he].view(B, prep.n_max, prep.he)
+        score = arena[plan.score:plan.score + b1 * R].view(b1, R)
+        keep = arena[plan.keep:plan.keep + b1 * prep.w * 2].view(torch.int64).view(b1, prep.w)
+        ctx.binding, ctx.prep, ctx.side, ctx.arena, ctx.plan_bwd = binding, prep, side, arena, int(plan.bwd_floats)
+        ctx.anchor_ids = [id(a) for a in anchors]
+        ctx.mark_non_differentiable(word_w, evd_w, score, keep)
+        return phi, word_w, evd_w, score, keep
+
+    @staticmethod
+    def backward(ctx, g_phi, *_unused):
+        binding, prep, side, arena = ctx.binding, ctx.prep, ctx.side, ctx.arena
+        dev = arena.device
+        g_phi = ops._f32(g_phi)
+        M, direct, gbuf, views = binding.get(True)
+        main = _lib.stream()
+        side_raw = side.cuda_stream if side is not None else main
+        _lib.ensure_workspace(dev)
+        if side is not None and not _lib.has_workspace(dev, side_raw):
+            with torch.cuda.stream(side):
+                _lib.ensure_workspace(dev)
+        work = torch.empty(ctx.plan_bwd, device=dev, dtype=torch.float32)
+        if side is not None:
+            work.record_stream(side)
+            g_phi.record_stream(side)
+            if gbuf is not None:
+                gbuf.record_stream(side)
+        args = (ctypes.addressof(M), ctypes.addressof(prep.struct), arena.data_ptr(), work.data_ptr(), g_phi.data_ptr(), None, None)
+        hook = binding.model.ggnn_with_gsl.grad_milestone_hook
+        if hook is None:
+            _lib.call("gh_get_backward", *args, 0, main, side_raw)
+        else:
+            # data-parallel overlap (dist.FlatTrainer.attach_overlap): every gradient outside the first evidence cell and
+            # the claim branch is final in stream order after phase 1 -- the early all-reduce starts underneath phase 2
+            _lib.call("gh_get_backward", *args, 1, main, side_raw)
+            if side is not None:
+                ops._side_pending.add(dev.index if dev.index is not None else torch.cuda.current_device())
+            hook()
+            _lib.call("gh_get_backward", *args, 2, main, side_raw)
+        ctx.arena = None
+        if direct:
+            return (None, None, None) + (None,) * len(ctx.anchor_ids)
+        return (None, None, None) + tuple(views.get(i) for i in ctx.anchor_ids)
+
+
+def eligible(model, query, kargs) -> bool:
+    if not ENABLED or not query.is_cuda or _lib.gemm_mode() != "fp32":
+        return False
+    if K.DocContentNoPaddingEvidence not in kargs or kargs[K.DocContentNoPaddingEvidence].shape[0] == 0:
+        return False
+    return _binding(model).eligible()
+
+
+def forward(model, query, document, kargs):
+    """Returns (phi, word_w (rows, hw) -- compact rows when the batch carries a plan --, evd_w, plan)."""
+    binding = _binding(model)
+    doc = kargs[K.DocContentNoPaddingEvidence]
+    q_adj = ops.as_packed(kargs[K.Query_Adj])
+    d_adj = ops.as_packed(kargs[K.Evd_Docs_Adj])
+    plan = d_adj.plan
+    if plan is not None and plan.m_real <= 0:
+        plan = None
+    prep = _prepare(model, query, document, kargs, q_adj, d_adj, plan, doc)
+    side = ops.side_stream(query.device) if ops.CLAIM_SIDE_STREAM else None
+    # anchors: the tensors autograd tracks.  With a FlatTrainer every gradient lands in the bucket directly, so ONE
+    # parameter is enough to keep the graph connected; otherwise all live parameters are inputs and get their gradients
+    # back from the backward call.
+    params = binding.params + [t for t in binding.tables if t.requires_grad]
+    if torch.is_grad_enabled() and all(ops._direct(p) for p in params):
+        anchors = (params[-1],)
+    else:
+        anchors = tuple(params)
+    phi, word_w, evd_w, score, keep = _GetFused.apply(binding, prep, side, *anchors)
+    gw = model.ggnn_with_gsl
+    gw.last_score, gw.last_keep = score, keep
+    return phi, word_w, evd_w, plan
+
+
+class _CrossEntropy(torch.autograd.Function):
+    """losses.py:29-32 (mean CE): loss and its gradient in one kernel; the backward is one scale."""
+
+    @staticmethod
+    def forward(ctx, phi, labels):
+        phi = ops._f32(phi)
+        b, c = phi.shape
+        labels = labels.to(torch.int64).contiguous()
+        out = torch.empty(1 + b * c, device=phi.device, dtype=torch.float32)
+        _lib.call("gh_cross_entropy", phi.data_ptr(), labels.data_ptr(), b, c, out.data_ptr(), out[1:].data_ptr(), _lib.stream())
+        ctx.save_for_backward(out)
+        ctx.shape = (b, c)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        return out[1:].view(ctx.shape) * g, None
+
+
+def cross_entropy(phi: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """Mean cross-entropy of (B, C) logits against (B,) labels (losses.py:29-32), one launch forward + one backward."""
+    _lib.require_cuda(phi, labels)
+    return _CrossEntropy.apply(phi, labels)

@@ -382,6 +382,17 @@ class Graph_basedSemantiStructure(nn.Module):
             assert d_lens.shape[0] == doc.size(0)
         b1 = doc.size(0)
         n_max = kargs[K.FIXED_NUM_EVIDENCES]
+        # The whole forward (and, through autograd, the whole backward) as ONE library call each when the model and
+        # the batch qualify (get_amd/fused.py: fp32, frozen word table, float4-shaped widths with d <= h <= 320); the
+        # module-by-module path below is the general one.
+        from . import fused
+        if fused.eligible(self, query, kargs):
+            phi, word_w, evd_att_weight, plan = fused.forward(self, query, document, kargs)
+            if kargs.get(K.OutputRankingKey, False):
+                hw = self.num_att_heads_for_words
+                word_att_weights = plan.to_padded(word_w) if plan is not None else word_w.view(b1, R, hw)
+                return phi, (word_att_weights, evd_att_weight)
+            return phi
         seg = ops.Segments(kargs[K.EvidenceCountPerQuery], b1, n_max)
 
         # claim branch (:144-155): GGNN -> masked mean over the unique claim nodes -> one row per pair

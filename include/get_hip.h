@@ -56,7 +56,7 @@ extern "C" {
 
 typedef void* gh_stream_t;
 
-#define GH_ABI_VERSION 4
+#define GH_ABI_VERSION 5
 
 int gh_abi_version(void);
 /* Thread-local message of the last failing call on this thread (never NULL). */
@@ -279,6 +279,91 @@ int gh_masked_mean_bwd(const float* g, const int32_t* ids, const float* lens, fl
  *      on one flat fp32 bucket (the same bucket the RCCL gradient all-reduce uses) ---- */
 int gh_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, float grad_scale, gh_stream_t stream);
+
+/* ==== a7  the whole model in two calls: Graph_basedSemantiStructure.forward (graph_based_semantic_structure.py:76-125) ====
+ * gh_get_forward / gh_get_backward chain every kernel of the path -- claim cell + masked mean (:144-155), evidence cells
+ * with the GSL refinement (:107; wrapper.py:165-172), word-level attention (:173-193), evidence-level assembly and
+ * attention (:157-171, :195-221), head (:251-267, :69-74) -- on caller-provided buffers, so that a training step costs
+ * the host two library calls instead of ~120 (the per-module entry points above remain the building blocks and the
+ * API for callers that use the modules one by one).  Everything is fp32; the word-embedding table is frozen (as
+ * master_get.py:143 constructs it); the claim branch runs on `side_stream` (may equal `stream`) underneath the evidence
+ * cells.  Pointers are device pointers; the structs themselves live on the host. */
+typedef struct gh_cell_params {            /* one GGNN cell, Models/BiDAF/wrapper.py:177-183 */
+  const float *w_p, *w_z0, *w_z1, *w_r0, *w_r1, *w_h0, *w_h1;          /* linear.weight as stored: w_p[h][din], others [h][h] */
+  const float *b_z0, *b_z1, *b_r0, *b_r1, *b_h0, *b_h1;
+  const float *wt_p, *wt_z0, *wt_z1, *wt_r0, *wt_r1, *wt_h0, *wt_h1;   /* transposes (gh_transpose_batch); backward only */
+  float *dw_p, *dw_z0, *dw_z1, *dw_r0, *dw_r1, *dw_h0, *dw_h1;          /* gradients, ACCUMULATED (+=); backward only */
+  float *db_z0, *db_z1, *db_r0, *db_r1, *db_h0, *db_h1;
+} gh_cell_params;
+typedef struct gh_att_params {             /* ConcatNotEqualSelfAtt, thirdparty/two_branches_attention.py:112-148 */
+  const float *w1, *w2, *w1t;              /* linear1.weight [ha][xl+dr], linear2.weight [heads][ha], linear1.weight^T */
+  float *dw1, *dw2;                        /* ACCUMULATED */
+} gh_att_params;
+typedef struct gh_get_model {
+  int d, h, word_heads, evd_heads, n_classes;       /* embedding width, hidden size, heads, output_size */
+  int claim_src_dim, article_src_dim;               /* 0 = that source embedding is not used */
+  const float* embedding;                           /* [vocab][d] word table (frozen) */
+  gh_cell_params claim, cell1, cell2;               /* ggnn4claim_1, ggnn_with_gsl.feat_prop1 / feat_prop2 */
+  const float* scorer_w;                            /* ggnn_with_gsl.word_scorer1.proj weight [h] */
+  const float* scorer_gate;                         /* its six 1x1 linears packed as gh_scorer_gsl's gate[12] */
+  gh_att_params att_word, att_evd;                  /* self_att_word, self_att_evd */
+  const float *claim_src_table, *article_src_table; /* [.][claim_src_dim], [.][article_src_dim] or NULL */
+  float *d_claim_src_table, *d_article_src_table;   /* ACCUMULATED; NULL = no gradient wanted */
+  const float *out0_w, *out0_b, *out0_wt;           /* head: out.0 weight [h][e] (+ transpose [e][h]), bias */
+  const float *out1_w, *out1_b, *out1_wt;           /* out.1 weight [n_classes][h] (+ transpose), bias */
+  float *d_out0_w, *d_out0_b, *d_out1_w, *d_out1_b; /* ACCUMULATED */
+} gh_get_model;
+typedef struct gh_get_batch {
+  int b, b1, l, r, n_max;                           /* claims, pairs, claim length, evidence length, evidence slots per claim */
+  int m_real;                                       /* node-compact layout: total real evidence nodes (needs goff..maskf); < 0: padded layout */
+  int collapsed;                                    /* node-compact evaluation: the first cell runs on m_real + 1 rows (gh_scorer_gsl pads_collapsed) */
+  int k_keep;                                       /* GSL: int(rate * r) */
+  const int32_t* q_ids;                             /* [b][l] claim node ids (int32) */
+  const void* q_lens; int q_lens_kind;              /* [b] unique claim nodes; kind 0 = float32, 1 = int32, 2 = int64 */
+  const uint64_t* q_bits; const float* q_dinv; const float* q_vals;      /* claim graphs (packed adjacency, see top) */
+  const int32_t* d_ids;                             /* [b1][r] evidence node ids (padded indexing) */
+  const uint64_t* d_bits; const float* d_dinv; const float* d_vals;      /* evidence graphs */
+  const int32_t *goff, *rowg, *cids; const float* maskf;                 /* gh_ragged_plan outputs, or all NULL (padded layout) */
+  const int64_t* counts;                            /* [b] evidences per claim (sum = b1) */
+  int counts_fit;                                   /* 1: the caller guarantees counts[i] <= n_max (saves a memset in the backward) */
+  const void* doc_sources; int doc_sources_i64;     /* [b][n_max], -1 = padding slot (article source ids) */
+  const void* query_sources; int query_sources_i64; /* [b] claim source ids (claim_src_dim > 0) */
+  const void* document; int document_i64;           /* [b][n_max][r] padded evidence node ids (slot mask only) */
+  float drop_claim, drop_gnn;                       /* input dropout of the claim cell / of the three evidence-side cells (0 = eval) */
+  uint32_t seed_claim, seed_cell1, seed_scorer, seed_cell2;
+} gh_get_batch;
+/* Buffer plan: float offsets into the two arenas for (model, batch).  fwd_floats / bwd_floats = arena sizes (in floats). */
+typedef struct gh_get_plan {
+  int64_t fwd_floats, bwd_floats;
+  int64_t phi, word_w, evd_w, score, keep;          /* offsets (floats) of the observable results inside the forward arena:
+                                                       phi [b][n_classes]; word_w [rows][word_heads] (rows = m_real, or b1*r padded);
+                                                       evd_w [b][n_max][evd_heads]; score [b1][r]; keep [b1][W] uint64 (8-byte aligned) */
+} gh_get_plan;
+int gh_get_plan_buffers(const gh_get_model* model, const gh_get_batch* batch, gh_get_plan* plan);
+/* sizeof of {gh_get_model, gh_get_batch, gh_get_plan, gh_cell_params}: lets a binding verify its mirror of the structs. */
+int gh_get_struct_sizes(int64_t* out4_host);
+/* Forward into `arena_fwd` (plan.fwd_floats floats, 256-byte aligned, kept until the backward has run). */
+int gh_get_forward(const gh_get_model* model, const gh_get_batch* batch, float* arena_fwd, gh_stream_t stream, gh_stream_t side_stream);
+/* Backward from g_phi [b][n_classes] (+ optional g_word_w / g_evd_w, shaped like the forward's weights outputs, or NULL).
+ * phase 0: everything; 1: down to and including the second evidence cell -- every gradient outside the first evidence cell
+ * and the claim branch is final in stream order when it returns (the data-parallel early all-reduce starts here);
+ * 2: the rest (first evidence cell; joins the side stream).  Gradients are ACCUMULATED into model->d*. */
+int gh_get_backward(const gh_get_model* model, const gh_get_batch* batch, const float* arena_fwd, float* arena_bwd,
+                    const float* g_phi, const float* g_word_w, const float* g_evd_w, int phase,
+                    gh_stream_t stream, gh_stream_t side_stream);
+/* Mean cross-entropy of logits [b][c] against labels [b] (int64), fused with its gradient (losses.py:29-32 CrossEntropyLoss):
+ * loss[0] = mean_b(logsumexp(phi_b) - phi_b[y_b]); dphi [b][c] = (softmax(phi_b) - onehot(y_b)) / b. */
+int gh_cross_entropy(const float* phi, const int64_t* labels, int b, int c, float* loss, float* dphi, gh_stream_t stream);
+/* Batch preparation in one call (interactions.py:334-351 for both sides + basic_fc_model.py:94-121's padded document):
+ * graph build of the b claims and b1 evidences, node-compact plan (m_real must be known to the host; < 0 = skip the plan)
+ * and the scatter of the evidence node ids into document[b][n_max][r] (slot[b1] = row of each pair; rows of unused slots
+ * must be zero already and stay untouched). */
+int gh_get_prepare(const int32_t* claim_tokens, const int32_t* claim_len, int b, int l,
+                   const int32_t* evd_tokens, const int32_t* evd_len, int b1, int r, int window,
+                   int32_t* q_ids, int32_t* q_n, uint64_t* q_bits, float* q_dinv,
+                   int32_t* d_ids, int32_t* d_n, uint64_t* d_bits, float* d_dinv,
+                   int m_real, int32_t* goff, int32_t* rowg, int32_t* src, int32_t* cids, float* maskf,
+                   const int64_t* slot, int32_t* document, gh_stream_t stream);
 
 /* ---- measurement hook (bench.py): HIP events around every kernel launch on its own stream ----
  * rows of `out` (each {total ms, total algorithmic work, launches}; work = flops for GEMMs, bytes otherwise):

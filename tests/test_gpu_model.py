@@ -752,3 +752,103 @@ def test_bump_weight_epoch_drops_frozen_derived_entries():
     with torch.no_grad():
         model(query, document, **kargs)
     assert not torch.equal(model.ggnn_with_gsl.last_score, s0), "the scorer still ran on its stale packed gates"
+
+
+@pytest.mark.parametrize("name", list(MODEL_CASES))
+@pytest.mark.parametrize("native", [False, True, "compact"])
+def test_composite_entry_points_equal_the_module_by_module_path(name, native, monkeypatch):
+    """get_amd/fused.py (gh_get_forward / gh_get_backward: the whole model in one library call each) against the
+    module-by-module path on the same inputs: same kernels underneath, so logits, attention weights, scores, keep-sets
+    and every gradient agree to fp32 summation-order noise (the composite sums the claim vector's gradient in a different
+    order and projects the word attention's left input once per claim instead of once per pair)."""
+    from get_amd import fused
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(fused, "ENABLED", on)
+        cfg, model, inp, phi, ww, ew, loss = run_case(name, native_graphs=native)
+        assert (getattr(model, "_gh_binding", None) is not None) == on, "the wrong path ran"
+        loss.backward()
+        torch.cuda.synchronize()
+        res[on] = dict(phi=phi.detach().clone(), ww=ww.detach().clone(), ew=ew.detach().clone(),
+                       score=model.ggnn_with_gsl.last_score.clone(), keep=model.ggnn_with_gsl.last_keep.clone(),
+                       grads={k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    a, b = res[False], res[True]
+    assert torch.equal(a["keep"], b["keep"])
+    for k in ("phi", "ww", "ew", "score"):
+        assert float((a[k] - b[k]).abs().max()) <= 2e-6 * max(1.0, float(a[k].abs().max())), k
+    assert set(a["grads"]) == set(b["grads"])
+    for k, g in a["grads"].items():
+        scale = max(float(g.abs().max()), 1e-8)
+        assert float((g - b["grads"][k]).abs().max()) <= 2e-5 * scale, k
+
+
+def test_composite_path_with_flat_trainer_matches_autograd_gradients():
+    """The composite backward accumulates straight into the FlatTrainer bucket (no gradient returned to autograd): the
+    bucket must equal the gradients plain autograd collects from the same call, for three steps in a row (persistent
+    transposes, cached descriptor)."""
+    from get_amd import ops
+    from get_amd.dist import FlatTrainer
+    cfg, model, inp, phi, ww, ew, loss = run_case("small", native_graphs="compact")
+    loss.backward()
+    ref = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    trainer = FlatTrainer(model, lr=0.0, weight_decay=0.0)
+    ops.bump_weight_epoch()
+    query = torch.from_numpy(inp["query"]).to(DEV)
+    document = torch.from_numpy(inp["document"]).to(DEV)
+    labels = torch.from_numpy(inp["labels"]).to(DEV)
+    for _ in range(3):
+        trainer.zero_grad()
+        kargs = to_dev(reference_kargs(inp, torch, output_ranking=False))
+        ops.cross_entropy(model(query, document, **kargs), labels).backward()
+        for k, p in model.named_parameters():
+            if k in ref:
+                scale = max(float(ref[k].abs().max()), 1e-8)
+                assert float((p.grad - ref[k]).abs().max()) <= 2e-5 * scale, k
+        trainer.step()          # lr = 0: parameters unchanged, but transposes are refreshed in place and epochs move on
+
+
+def test_fused_cross_entropy_matches_torch():
+    from get_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for b, c in ((32, 2), (7, 5), (300, 3)):
+        phi = (torch.randn(b, c, generator=g) * 3).to(DEV).requires_grad_(True)
+        y = torch.randint(0, c, (b,), generator=g).to(DEV)
+        l1 = ops.cross_entropy(phi, y)
+        (l1 * 1.7).backward()
+        g1 = phi.grad.clone()
+        phi.grad = None
+        l2 = torch.nn.functional.cross_entropy(phi, y)
+        (l2 * 1.7).backward()
+        assert abs(l1.item() - l2.item()) <= 1e-6 * max(1.0, abs(l2.item()))
+        assert float((g1 - phi.grad).abs().max()) <= 1e-6
+
+
+def test_native_batch_prepare_call_equals_the_separate_launches():
+    """NativeBatch.inputs() (one gh_get_prepare call into persistent buffers) against ops.graph_build + ops.RaggedPlan +
+    the index_copy_ it replaces: bit-exact, also on the second call (buffers rewritten in place)."""
+    from get_amd import ops
+    from get_amd.batch import NativeBatch
+    from get_amd.keywords import KeyWordSettings as K
+    cfg, seed = MODEL_CASES["small"]
+    raw = make_raw_batch(cfg, seed)
+    for compact in (True, False):
+        nb = NativeBatch(raw["claim_tokens"], raw["claim_len"], raw["evd_tokens"], raw["evd_len"], raw["evd_counts"],
+                         raw["doc_sources"], raw["query_sources"], raw["labels"], window=cfg.window,
+                         n_max=cfg.fixed_num_evidences, device=DEV, compact=compact)
+        for _ in range(2):
+            q_ids, document, kargs = nb.inputs()
+            qa, q2, qn = ops.graph_build(nb.claim_tokens, nb.claim_len, cfg.window)
+            da, d2, dn = ops.graph_build(nb.evd_tokens, nb.evd_len, cfg.window)
+            assert torch.equal(q_ids, q2) and torch.equal(kargs[K.Query_lens], qn)
+            assert torch.equal(kargs[K.DocContentNoPaddingEvidence], d2)
+            assert torch.equal(kargs[K.Query_Adj].bits, qa.bits) and torch.equal(kargs[K.Query_Adj].dinv, qa.dinv)
+            assert torch.equal(kargs[K.Evd_Docs_Adj].bits, da.bits) and torch.equal(kargs[K.Evd_Docs_Adj].dinv, da.dinv)
+            doc_ref = torch.zeros((nb.b * nb.n_max, d2.shape[1]), device=DEV, dtype=torch.int32)
+            doc_ref.index_copy_(0, nb._slot, d2)
+            assert torch.equal(document.reshape(doc_ref.shape), doc_ref)
+            plan = kargs[K.Evd_Docs_Adj].plan
+            assert (plan is not None) == compact
+            if compact:
+                ref = ops.RaggedPlan(dn, d2, nb.m_real)
+                for f in ("goff", "rowg", "src", "cids", "maskf"):
+                    assert torch.equal(getattr(plan, f), getattr(ref, f)), f
