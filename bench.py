@@ -325,6 +325,7 @@ def make_step(args, wl, trainer, source="resident"):
     "reference" (ReferenceApiBatch: dense float64 hand-over, padded layout) or "streamed" (StreamedBatches: a fresh
     NativeBatch per step, H2D + read-back included).  Returns (step_fn, pairs_fn) -- pairs_fn() = pairs of the steps
     issued since its last call."""
+    from get_amd import ops
     model = wl["model"]
     state = {"i": 0, "pairs": 0}
     batches = wl["ref_batches"] if source == "reference" else wl["batches"]
@@ -344,7 +345,7 @@ def make_step(args, wl, trainer, source="resident"):
         trainer.zero_grad()
         query, document, kargs = b.inputs()
         phi = model(query, document, **kargs)
-        loss = torch.nn.functional.cross_entropy(phi, b.labels)
+        loss = ops.cross_entropy(phi, b.labels)        # losses.py:29-32, loss + gradient in one launch
         loss.backward()
         trainer.step()
         if streamed is not None:
@@ -429,7 +430,7 @@ def phase_split(wl, trainer, steps=5):
         e[0].record()
         query, document, kargs = b.inputs()
         e[1].record()
-        loss = torch.nn.functional.cross_entropy(model(query, document, **kargs), b.labels)
+        loss = ops.cross_entropy(model(query, document, **kargs), b.labels)
         e[2].record()
         loss.backward()
         e[3].record()

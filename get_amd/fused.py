@@ -318,12 +318,15 @@ class _GetFused(torch.autograd.Function):
         ctx.binding, ctx.prep, ctx.side, ctx.arena, ctx.plan_bwd = binding, prep, side, arena, int(plan.bwd_floats)
         ctx.anchor_ids = [id(a) for a in anchors]
         ctx.mark_non_differentiable(word_w, evd_w, score, keep)
+        ctx.set_materialize_grads(False)      # no zero-filled gradient tensors for the four observables (4 fill launches per step)
         return phi, word_w, evd_w, score, keep
 
     @staticmethod
     def backward(ctx, g_phi, *_unused):
         binding, prep, side, arena = ctx.binding, ctx.prep, ctx.side, ctx.arena
         dev = arena.device
+        if g_phi is None:          # nothing upstream depends on phi
+            return (None, None, None) + (None,) * len(ctx.anchor_ids)
         g_phi = ops._f32(g_phi)
         M, direct, gbuf, views = binding.get(True)
         main = _lib.stream()
@@ -406,7 +409,7 @@ class _CrossEntropy(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (out,) = ctx.saved_tensors
-        return out[1:].view(ctx.shape) * g, None
+        return out[1:].view(ctx.shape) * g, None          # (one scale launch; g is the scalar upstream gradient)
 
 
 def cross_entropy(phi: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
