@@ -107,7 +107,8 @@ int cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const float* 
                   const float* wt_h1, const float* xp, const float* a, const float* z, const float* rr, const float* rx,
                   const float* hh, const float* g, float* dhp, float* dzp, float* drp, float* dxp, float* da, float* dx,
                   float* dw_p, float* dw_z0, float* dw_z1, float* dw_r0, float* dw_r1, float* dw_h0, float* dw_h1, float* db_z,
-                  float* db_r, float* db_h, float* db_z1, float* db_r1, float* db_h1, float drop_p, uint32_t drop_seed, void* stream);
+                  float* db_r, float* db_h, float* db_z1, float* db_r1, float* db_h1, float drop_p, uint32_t drop_seed, void* stream,
+                  void* wstream, hipEvent_t ev_l1, hipEvent_t ev_agg);      // wstream: weight-gradient stream (NULL = stream)
 int att_fwd_impl(const float* left, int nl, const int32_t* rowu, const float* right, const float* mask, const int32_t* goff,
                  const int32_t* rowg, int m_real, int b, int l, int xl, int dr, int ha, int heads, const float* w1, const float* w2,
                  float* u, float* t, float* e, float* weights, float* attended, hipStream_t s);

@@ -677,8 +677,15 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
                                 float* dx, float* dw_p, float* dw_z0, float* dw_z1, float* dw_r0, float* dw_r1,
                                 float* dw_h0, float* dw_h1, float* db_z, float* db_r, float* db_h,
                                 float* db_z1, float* db_r1, float* db_h1, float drop_p, uint32_t drop_seed,
-                                gh_stream_t stream) {
+                                gh_stream_t stream, gh_stream_t wstream, hipEvent_t ev_l1, hipEvent_t ev_agg) {
   hipStream_t s = (hipStream_t)stream;
+  // Weight-gradient stream (composite backward, model_ops.hip): the split-K weight-gradient GEMMs only need dzp / drp / dhp
+  // (final after the first dX launch) and, for dW_proj, dxp (final after the aggregation).  On their own stream they run
+  // underneath the rest of the chain -- the streaming kernels of one stream (gate_bwd_pre, aggregation, gather, partial
+  // reduces) hide under the other stream's MFMA-bound launches, which two launches on ONE stream never do.
+  hipStream_t sw = wstream ? (hipStream_t)wstream : s;
+  const bool two = sw != s;
+  GH_REQUIRE(!two || (ev_l1 && ev_agg), "ggnn_cell_bwd: a separate weight-gradient stream needs its two events");
   GH_REQUIRE(n > 0 && r > 0 && din > 0 && h > 0, "ggnn_cell_bwd: bad sizes");
   GH_REQUIRE(!bf || (din % 8 == 0 && h % 8 == 0 && din <= h), "ggnn_cell_bwd_bf16: needs din %% 8 == 0, h %% 8 == 0, din <= h (din=%d h=%d)", din, h);
   if (!goff) m_real = n * r;
@@ -698,6 +705,26 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
     b.flush();
     GH_CHECK_HIP(b.err);
   }
+  const bool cs = bf ? true : ((h % 4 == 0) && (h <= 320));
+  bool colsum_done = false;
+  if (two) {  // six of the seven weight gradients start here, on the weight-gradient stream
+    GH_CHECK_HIP(hipEventRecord(ev_l1, s));
+    GH_CHECK_HIP(hipStreamWaitEvent(sw, ev_l1, 0));
+    Batch b(true, M, sw);
+    b.add(tn_problem(h, h, dw_z0, h, dzp, h, a, h, M, nullptr, bf));  if (cs) b.want_colsum(db_z, db_z1);
+    b.add(tn_problem(h, h, dw_z1, h, dzp, h, xp, h, M, nullptr, bf));
+    b.add(tn_problem(h, h, dw_r0, h, drp, h, a, h, M, nullptr, bf));  if (cs) b.want_colsum(db_r, db_r1);
+    b.add(tn_problem(h, h, dw_r1, h, drp, h, xp, h, M, nullptr, bf));
+    b.add(tn_problem(h, h, dw_h0, h, dhp, h, a, h, M, nullptr, bf));  if (cs) b.want_colsum(db_h, db_h1);
+    b.add(tn_problem(h, h, dw_h1, h, dhp, h, rx, h, M, nullptr, bf));
+    b.flush();
+    GH_CHECK_HIP(b.err);
+    colsum_done = b.colsum_fused;
+    if (!colsum_done) {
+      GH_REQUIRE(!bf, "ggnn_cell_bwd_bf16: the bias gradients need the split-K workspace (gh_set_workspace)");
+      if (int e = launch_colsum3(dzp, drp, dhp, db_z, db_r, db_h, M, h, sw, db_z1, db_r1, db_h1)) return e;
+    }
+  }
   {  // da += dzp Wz0 + drp Wr0 ; dxp += dzp Wz1 + drp Wr1
     Batch b(false, M, s, wide);
     Problem p0 = gemm_problem(M, h, EPI_STORE, da, h, dzp, h, wt_z0, h, h, nullptr, bf);
@@ -712,6 +739,10 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
     GH_CHECK_HIP(b.err);
   }
   if (int e = launch_spmm(bits, dinv, vals, keep, goff, m_real, da, dxp, n, r, h, 1, 1, s, bf)) return e;   // dxp += A_hat^T da
+  if (two) {
+    GH_CHECK_HIP(hipEventRecord(ev_agg, s));
+    GH_CHECK_HIP(hipStreamWaitEvent(sw, ev_agg, 0));
+  }
   if (dx) {  // dx = (dxp Wp) . mask/(1-p)
     Batch b(false, M, s, wide && din % 256 == 0);
     Problem p = gemm_problem(M, din, EPI_STORE, dx, din, dxp, h, wt_p, h, h, nullptr, bf);      // dx itself is fp32
@@ -723,18 +754,19 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
   {  // weight gradients: G^T X over the M rows, split-K partial tiles + reduce.  The bias gradients are the column
      // sums of dzp / drp / dhp: they ride along with the first GEMM that streams each of them (no separate
      // column-sum pass over 3 x M x h values) whenever the launch takes the workspace path.
-    Batch b(true, M, s);
-    const bool cs = bf ? true : ((h % 4 == 0) && (h <= 320));
-    b.add(tn_problem(h, h, dw_z0, h, dzp, h, a, h, M, nullptr, bf));  if (cs) b.want_colsum(db_z, db_z1);
-    b.add(tn_problem(h, h, dw_z1, h, dzp, h, xp, h, M, nullptr, bf));
-    b.add(tn_problem(h, h, dw_r0, h, drp, h, a, h, M, nullptr, bf));  if (cs) b.want_colsum(db_r, db_r1);
-    b.add(tn_problem(h, h, dw_r1, h, drp, h, xp, h, M, nullptr, bf));
-    b.add(tn_problem(h, h, dw_h0, h, dhp, h, a, h, M, nullptr, bf));  if (cs) b.want_colsum(db_h, db_h1);
-    b.add(tn_problem(h, h, dw_h1, h, dhp, h, rx, h, M, nullptr, bf));
+    Batch b(true, M, sw);
+    if (!two) {
+      b.add(tn_problem(h, h, dw_z0, h, dzp, h, a, h, M, nullptr, bf));  if (cs) b.want_colsum(db_z, db_z1);
+      b.add(tn_problem(h, h, dw_z1, h, dzp, h, xp, h, M, nullptr, bf));
+      b.add(tn_problem(h, h, dw_r0, h, drp, h, a, h, M, nullptr, bf));  if (cs) b.want_colsum(db_r, db_r1);
+      b.add(tn_problem(h, h, dw_r1, h, drp, h, xp, h, M, nullptr, bf));
+      b.add(tn_problem(h, h, dw_h0, h, dhp, h, a, h, M, nullptr, bf));  if (cs) b.want_colsum(db_h, db_h1);
+      b.add(tn_problem(h, h, dw_h1, h, dhp, h, rx, h, M, nullptr, bf));
+    }
     if ((ids || drop_p > 0.f || bf) && din <= h) {
       // operand rows materialised once into the (now free) `da` scratch -- embedding gather and/or the forward's
       // dropout mask applied in that one streaming pass -- so the split-K GEMM loader stays a plain copy
-      if (int e = launch_gather_rows(x, ids, da, M, din, s, drop_p, drop_seed, bf)) return e;
+      if (int e = launch_gather_rows(x, ids, da, M, din, sw, drop_p, drop_seed, bf)) return e;
       b.add(tn_problem(h, din, dw_p, din, dxp, h, da, din, M, nullptr, bf));
     } else {
       GH_REQUIRE(drop_p == 0.f, "ggnn_cell_bwd: fused dropout needs din (%d) <= h (%d)", din, h);
@@ -742,7 +774,7 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
     }
     b.flush();
     GH_CHECK_HIP(b.err);
-    if (b.colsum_fused) return 0;
+    if (two || b.colsum_fused) return 0;
   }
   GH_REQUIRE(!bf, "ggnn_cell_bwd_bf16: the bias gradients need the split-K workspace (gh_set_workspace)");
   return launch_colsum3(dzp, drp, dhp, db_z, db_r, db_h, M, h, s, db_z1, db_r1, db_h1);
@@ -762,7 +794,7 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
                                 gh_stream_t stream) {
   return cell_bwd_impl(0, bits, dinv, vals, keep, goff, m_real, x, ids, n, r, din, h, wt_p, wt_z0, wt_z1, wt_r0, wt_r1, wt_h0, wt_h1,
                        xp, a, z, rr, rx, hh, g, dhp, dzp, drp, dxp, da, dx, dw_p, dw_z0, dw_z1, dw_r0, dw_r1, dw_h0, dw_h1,
-                       db_z, db_r, db_h, db_z1, db_r1, db_h1, drop_p, drop_seed, stream);
+                       db_z, db_r, db_h, db_z1, db_r1, db_h1, drop_p, drop_seed, stream, nullptr, nullptr, nullptr);
 }
 
 extern "C" int gh_ggnn_cell_bwd_bf16(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
@@ -782,7 +814,7 @@ extern "C" int gh_ggnn_cell_bwd_bf16(const uint64_t* bits, const float* dinv, co
   return cell_bwd_impl(1, bits, dinv, vals, keep, goff, m_real, (cf)x, ids, n, r, din, h, (cf)wt_p, (cf)wt_z0, (cf)wt_z1, (cf)wt_r0,
                        (cf)wt_r1, (cf)wt_h0, (cf)wt_h1, (cf)xp, (cf)a, (cf)z, (cf)rr, (cf)rx, (cf)hh, g, (mf)dhp, (mf)dzp, (mf)drp,
                        (mf)dxp, (mf)da, dx, dw_p, dw_z0, dw_z1, dw_r0, dw_r1, dw_h0, dw_h1, db_z, db_r, db_h, db_z1, db_r1,
-                       db_h1, drop_p, drop_seed, stream);
+                       db_h1, drop_p, drop_seed, stream, nullptr, nullptr, nullptr);
 }
 
 // Concat attention, generalised for the composite model entry points (model_ops.hip):

@@ -29,7 +29,7 @@ struct FwdBuf {
 };
 struct BwdBuf {
   int64_t d_y0, d_new_left, d_att_e, de_e, dpre_e, du_e, dright_e, d_avg;
-  int64_t de_w, dpre_w, du_w, du_c, d_q, g2, d_qhid, qs[5], sc[5], dx2;
+  int64_t de_w, dpre_w, du_w, du_c, d_q, g2, d_qhid, qs[5], sc2[5], sc1[5], dx2;
   int64_t total;
 };
 struct Bump {
@@ -105,14 +105,17 @@ static int layout(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d, FwdBu
   w.g2 = c.take((int64_t)d.Mr * d.H);
   w.d_qhid = c.take((int64_t)d.Mq * d.H);
   for (int i = 0; i < 5; ++i) w.qs[i] = c.take((int64_t)d.Mq * d.H);
-  for (int i = 0; i < 5; ++i) w.sc[i] = c.take((int64_t)d.Mr * d.H);
+  // one scratch set per evidence cell: the weight-gradient stream still reads the second cell's dzp / drp / dhp / dxp
+  // while the main stream already runs the first cell's chain
+  for (int i = 0; i < 5; ++i) w.sc2[i] = c.take((int64_t)d.Mr * d.H);
+  for (int i = 0; i < 5; ++i) w.sc1[i] = c.take((int64_t)d.Mr * d.H);
   w.dx2 = c.take((int64_t)d.Mr * d.H);
   w.total = c.off;
   return 0;
 }
 
 // ---------------------------------------------------------------------------------------------- stream fork / join events
-struct DevEvents { hipEvent_t ev[6]; };
+struct DevEvents { hipEvent_t ev[12]; };
 static std::mutex g_ev_mu;
 static std::unordered_map<int, DevEvents> g_events;
 static int get_events(DevEvents& out) {
@@ -122,7 +125,7 @@ static int get_events(DevEvents& out) {
   auto it = g_events.find(dev);
   if (it == g_events.end()) {
     DevEvents e;
-    for (int i = 0; i < 6; ++i) GH_CHECK_HIP(hipEventCreateWithFlags(&e.ev[i], hipEventDisableTiming));
+    for (int i = 0; i < 12; ++i) GH_CHECK_HIP(hipEventCreateWithFlags(&e.ev[i], hipEventDisableTiming));
     it = g_events.emplace(dev, e).first;
   }
   out = it->second;
@@ -258,12 +261,12 @@ static int cell_fwd(const gh_cell_params& c, const CellBuf& cb, float* A, const 
 static int cell_bwd(const gh_cell_params& c, const CellBuf& cb, const float* A, const uint64_t* bits, const float* dinv,
                     const float* vals, const uint64_t* keep, const int32_t* goff, int m_real, const float* x, const int32_t* ids, int n,
                     int r, int din, int h, const float* g, float* W, const int64_t* sc, float* dx, float drop_p, uint32_t seed,
-                    hipStream_t s) {
+                    hipStream_t s, hipStream_t sw = nullptr, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   GH_REQUIRE(c.wt_p && c.dw_p && c.db_z0 && c.db_z1, "get_backward: a cell's transposes / gradient outputs are missing");
   return cell_bwd_impl(0, bits, dinv, vals, keep, goff, m_real, x, ids, n, r, din, h, c.wt_p, c.wt_z0, c.wt_z1, c.wt_r0, c.wt_r1,
                        c.wt_h0, c.wt_h1, A + cb.xp, A + cb.a, A + cb.z, A + cb.rr, A + cb.rx, A + cb.hh, g, W + sc[0], W + sc[1],
                        W + sc[2], W + sc[3], W + sc[4], dx, c.dw_p, c.dw_z0, c.dw_z1, c.dw_r0, c.dw_r1, c.dw_h0, c.dw_h1, c.db_z0,
-                       c.db_r0, c.db_h0, c.db_z1, c.db_r1, c.db_h1, drop_p, seed, (void*)s);
+                       c.db_r0, c.db_h0, c.db_z1, c.db_r1, c.db_h1, drop_p, seed, (void*)s, (void*)sw, e0, e1);
 }
 
 extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, float* A, gh_stream_t stream, gh_stream_t side_stream) {
@@ -374,20 +377,24 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
     }
     // ---- word-level attention: per-pair du summed per claim; d(claim vector) accumulates on top of the head / evidence part
     GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
-                        A + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, Wb + w.g2, Mo->att_word.dw1,
+                        A + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, Wb + w.g2, nullptr,
                         Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, s));
-    // ---- claim branch backward on the side stream, underneath the evidence cells
+    // ---- side stream: linear1's weight gradient of the word attention, then the claim branch's backward -- underneath
+    //      the evidence cells' chain on the main stream
     GH_TRY(stream_after(ss, s, ev.ev[4]));
+    GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
+                        A + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, nullptr, nullptr, Mo->att_word.dw1,
+                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 0, ss));
     GH_TRY(gh_masked_mean_bwd(Wb + w.d_q, Ba->q_ids, A + f.lens_eff, Wb + w.d_qhid, d.B, d.L, H, (void*)ss));
     GH_TRY(cell_bwd(Mo->claim, f.q, A, Ba->q_bits, Ba->q_dinv, Ba->q_vals, nullptr, nullptr, 0, Mo->embedding, Ba->q_ids, d.B, d.L, d.D, H,
                     Wb + w.d_qhid, Wb, w.qs, nullptr, Ba->drop_claim, Ba->seed_claim, ss));
-    // ---- second evidence cell
+    // ---- second evidence cell: dX chain on the main stream, weight gradients on the side stream
     GH_TRY(cell_bwd(Mo->cell2, f.c2, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, keep, goff, d.Mr, A + f.c1.out, nullptr, d.B1, d.R, H, H,
-                    Wb + w.g2, Wb, w.sc, Wb + w.dx2, Ba->drop_gnn, Ba->seed_cell2, s));
+                    Wb + w.g2, Wb, w.sc2, Wb + w.dx2, Ba->drop_gnn, Ba->seed_cell2, s, ss, ev.ev[6], ev.ev[7]));
   }
   if (phase != 1) {
     GH_TRY(cell_bwd(Mo->cell1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, Mo->embedding, ids1, d.B1, d.R, d.D, H,
-                    Wb + w.dx2, Wb, w.sc, nullptr, Ba->drop_gnn, Ba->seed_cell1, s));
+                    Wb + w.dx2, Wb, w.sc1, nullptr, Ba->drop_gnn, Ba->seed_cell1, s, ss, ev.ev[8], ev.ev[9]));
     GH_TRY(stream_after(s, ss, ev.ev[5]));
   }
   return 0;

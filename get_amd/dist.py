@@ -185,21 +185,34 @@ class FlatTrainer:
         (gradient accumulation): its early gradients would be added to an already reduced range, so this is rejected
         -- accumulate with the overlap detached, or call ``allreduce()`` after every backward."""
         from . import ops
-        ops.side_join()        # weight gradients issued on the auxiliary stream belong to the early range
         if self._early_work is not None:
             raise RuntimeError("get_amd: a second backward pass reached the all-reduce milestone while the first early "
                                "all-reduce is still pending; gradient accumulation needs detach_overlap() (one "
                                "all-reduce per step) or an allreduce() after every backward")
-        if self._reducing() and 0 < self.n_early < self.numel and self._overlap_ok:
-            if self._check_overlap:
-                self._early_snapshot = self.flat_g[:self.n_early].clone()
-            try:
+        if not (self._reducing() and 0 < self.n_early < self.numel and self._overlap_ok):
+            return
+        # Early-range gradients come from two streams: the caller's (head, attentions' dX side) and the auxiliary one
+        # (few-row weight gradients, the second evidence cell's weight-gradient GEMMs).  The collective is issued FROM the
+        # auxiliary stream after it has been ordered behind the caller's stream: it then waits for both, while the
+        # caller's stream -- the first evidence cell's dX chain -- is not held up by the weight-gradient GEMMs.
+        side = ops.pending_side_stream()
+        if self._check_overlap:
+            ops.side_join()
+            side = None
+            self._early_snapshot = self.flat_g[:self.n_early].clone()
+        try:
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(side.device))
+                with torch.cuda.stream(side):
+                    self._early_work = self._all_reduce(self.flat_g[:self.n_early], async_op=True)
+            else:
+                ops.side_join()
                 self._early_work = self._all_reduce(self.flat_g[:self.n_early], async_op=True)
-            except Exception as e:      # a backend without async collectives: keep training with the single all-reduce
-                self._overlap_ok = False
-                self._early_work = None
-                import warnings
-                warnings.warn(f"get_amd: overlapped all-reduce disabled ({e!r}); falling back to one all-reduce per step")
+        except Exception as e:      # a backend without async collectives: keep training with the single all-reduce
+            self._overlap_ok = False
+            self._early_work = None
+            import warnings
+            warnings.warn(f"get_amd: overlapped all-reduce disabled ({e!r}); falling back to one all-reduce per step")
 
     def allreduce(self):
         """All-reduce(sum) of the gradient bucket (RCCL over xGMI on GPUs, gloo in CPU tests): the whole bucket in one

@@ -45,6 +45,12 @@ def side_join():
         _side_pending.discard(idx)
 
 
+def pending_side_stream():
+    """The auxiliary stream of the current device if work of the running backward pass is pending on it, else None."""
+    idx = torch.cuda.current_device() if torch.cuda.is_available() else None
+    return _SIDE_STREAMS.get(idx) if idx in _side_pending else None
+
+
 def side_mark_backward(device):
     """Called from inside a backward pass when work of that pass runs (or is about to run) on the auxiliary stream -- the
     claim branch's backward, which autograd replays on its forward stream: marks the device pending and queues the join
