@@ -388,13 +388,15 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
     GH_TRY(gh_masked_mean_bwd(Wb + w.d_q, Ba->q_ids, A + f.lens_eff, Wb + w.d_qhid, d.B, d.L, H, (void*)ss));
     GH_TRY(cell_bwd(Mo->claim, f.q, A, Ba->q_bits, Ba->q_dinv, Ba->q_vals, nullptr, nullptr, 0, Mo->embedding, Ba->q_ids, d.B, d.L, d.D, H,
                     Wb + w.d_qhid, Wb, w.qs, nullptr, Ba->drop_claim, Ba->seed_claim, ss));
-    // ---- second evidence cell: dX chain on the main stream, weight gradients on the side stream
+    // ---- second evidence cell.  (cell_bwd_impl can put the weight-gradient GEMMs on the side stream -- measured on the
+    //      bench step: 6.31 -> 6.23 ms, two MFMA-bound streams mostly slow each other down, while every kernel's wall time
+    //      and with it the per-kernel roofline figures inflate by 20-30 %.  Not used: one stream, honest kernel times.)
     GH_TRY(cell_bwd(Mo->cell2, f.c2, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, keep, goff, d.Mr, A + f.c1.out, nullptr, d.B1, d.R, H, H,
-                    Wb + w.g2, Wb, w.sc2, Wb + w.dx2, Ba->drop_gnn, Ba->seed_cell2, s, ss, ev.ev[6], ev.ev[7]));
+                    Wb + w.g2, Wb, w.sc2, Wb + w.dx2, Ba->drop_gnn, Ba->seed_cell2, s));
   }
   if (phase != 1) {
     GH_TRY(cell_bwd(Mo->cell1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, Mo->embedding, ids1, d.B1, d.R, d.D, H,
-                    Wb + w.dx2, Wb, w.sc1, nullptr, Ba->drop_gnn, Ba->seed_cell1, s, ss, ev.ev[8], ev.ev[9]));
+                    Wb + w.dx2, Wb, w.sc1, nullptr, Ba->drop_gnn, Ba->seed_cell1, s));
     GH_TRY(stream_after(s, ss, ev.ev[5]));
   }
   return 0;

@@ -602,7 +602,9 @@ def test_early_gradients_are_final_at_the_milestone(name):
             da = da.with_plan(ops.RaggedPlan(d_n, d_ids, int(d_n.sum().item())))
         kargs["docs_adj"] = da
         snaps = []
-        model.ggnn_with_gsl.grad_milestone_hook = lambda: snaps.append(tr.flat_g[:tr.n_early].clone())
+        # (the early range is final in stream order on BOTH streams of the backward: join the auxiliary one, as the
+        # trainer's own hook does before it starts the collective)
+        model.ggnn_with_gsl.grad_milestone_hook = lambda: (ops.side_join(), snaps.append(tr.flat_g[:tr.n_early].clone()))
         tr.zero_grad()
         phi = model(torch.from_numpy(inp["query"]).to(DEV), torch.from_numpy(inp["document"]).to(DEV), **kargs)
         torch.nn.functional.cross_entropy(phi, labels).backward()
