@@ -90,11 +90,13 @@ _GEMM_MODE = "fp32"
 
 
 def set_gemm_mode(mode: str):
-    """"fp32" (default, exact fp32 MFMA everywhere) or "bf16" (BASELINE configs[4]): the evidence cells run the bf16
+    """"fp32" (default, exact fp32 MFMA everywhere); "bf16" (BASELINE configs[4]): the evidence cells run the bf16
     STORAGE pipeline (bf16 activations/weights in HBM, v_mfma_f32_16x16x32_bf16, fp32 accumulate) where their shape
-    allows it, every other activation-sized GEMM rounds its operands to bf16 in registers."""
+    allows it, every other activation-sized GEMM rounds its operands to bf16 in registers; "fp32x3" (opt-in): fp32
+    storage and fp32 results, every product formed on the bf16 MFMA from 3-way bf16 splits of both operands (six of the
+    nine cross terms, error below one fp32 rounding of the product; csrc/gemm_nt.hip.h MODE 3)."""
     global _GEMM_MODE
-    call("gh_set_gemm_mode", {"fp32": 0, "bf16": 1}[mode])
+    call("gh_set_gemm_mode", {"fp32": 0, "bf16": 1, "fp32x3": 2}[mode])
     _GEMM_MODE = mode
 
 

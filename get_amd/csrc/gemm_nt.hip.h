@@ -44,8 +44,22 @@ __device__ __forceinline__ unsigned nt_pack_bf16(float a, float b) {
 //         columns (768 = 2.4 x 320) and re-reads the 320-row weight panel from L2 for every 64 rows; 128 x 256 covers 768
 //         exactly, halves the weight traffic per FLOP and needs 12 instead of 24 ds_read_b128 per 32 MFMAs.  128
 //         accumulator registers per lane -> two workgroups per CU.
+// MODE 3: fp32 storage and fp32 results on the bf16 MFMA ("fp32x3", gh_set_gemm_mode(2)).  fp32 MFMA runs at 1/16 of the bf16
+//         rate on gfx950, so an fp32 product is formed from bf16 pieces instead: every operand value x is split in registers
+//         into x = hi + mid + lo, three bf16 numbers (round-to-nearest at each level, the remainders are exact fp32
+//         subtractions, |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|), and a . b is accumulated in fp32 from the six largest of the
+//         nine cross products: ah.bh + am.bh + al.bh + ah.bm + am.bm + ah.bl.  The dropped terms (am.bl, al.bm, al.bl) are
+//         below 2^-23 |a.b| -- the size of ONE fp32 rounding of the product -- and the sums are fp32 adds as in the exact
+//         mode.  v_mfma_f32_16x16x32_bf16 contracts 32 k-slots per instruction; a K tile has 16 real k, so each instruction
+//         carries TWO of the six terms (slots 0-3 of a lane: one piece of its four k values, slots 4-7: another piece):
+//         three MFMAs of 16 cycles per 16 x 16 x 16 product instead of four fp32 MFMAs of 32 cycles.  Measured: in registers
+//         (tools/split_probe.hip) 260 fp32-equivalent TFLOP/s against 154 for the fp32 MFMA; in THIS kernel only +3-5 %
+//         (M = 96 000, N = 300: 101.7 / 113.9 / 131.9 TF at K = 300 / 600 / 1200 against 97.5 / 110.0 / 127.8 exact, same
+//         error against fp64): the ~350 VALU instructions per K tile that split the 12 fragments (48 floats per lane, most of
+//         them the WEIGHT fragments every workgroup splits again) take as long as the MFMAs they replace.  The mode stays
+//         opt-in and experimental; the way to its 2x is weights pre-split once per optimiser step.
 template <int WM, int WN, int NI, int MI = 2, int MODE = 0>
-__global__ void __launch_bounds__(WM * WN * 64, MI == 4 ? 2 : 3)
+__global__ void __launch_bounds__(WM * WN * 64, (MI == 4 || MODE == 3) ? 2 : 3)
 gemm_nt_kernel(const Launch L_byval) {
   (void)L_byval;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -65,6 +79,8 @@ gemm_nt_kernel(const Launch L_byval) {
   // tile waits most of a DMA latency (PMC: waves parked 55 % of the time), so it runs three stages / distance 2, waits
   // with vmcnt(DMA instructions of ONE tile) and synchronises with a bare s_barrier (a __syncthreads() would drain the
   // newest tile's DMA as well).  73.5 KB of LDS -> dynamic allocation.
+  // (fp32x3, MODE 3, measured with three stages as well: slower -- 122 vs 132 TF at K = 1200 -- its K loop is bound by the
+  // VALU work of the in-register splits, not by DMA latency)
   constexpr int NST = (MI == 4) ? 3 : 2;
   constexpr int SMEM = NST * STAGE > EP_BYTES ? NST * STAGE : EP_BYTES;
   constexpr unsigned OOB = 0x80000000u;
@@ -220,6 +236,44 @@ gemm_nt_kernel(const Launch L_byval) {
         for (int mi = 0; mi < MI; ++mi)
           acc[mi][ni0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[i]), __builtin_bit_cast(bf16x8, a[mi]),
                                                                     acc[mi][ni0 + i], 0, 0, 0);
+      return;
+    }
+    if constexpr (MODE == 3) {
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      // pieces of a fragment's four k values as packed bf16 pairs: {hi, mid, lo} x {k0k1, k2k3}
+      auto split = [](const f32x4 v, unsigned* hi, unsigned* mid, unsigned* lo) __attribute__((always_inline)) {
+        hi[0] = nt_pack_bf16(v[0], v[1]); hi[1] = nt_pack_bf16(v[2], v[3]);
+        const float r0 = v[0] - __builtin_bit_cast(float, hi[0] << 16), r1 = v[1] - __builtin_bit_cast(float, hi[0] & 0xffff0000u);
+        const float r2 = v[2] - __builtin_bit_cast(float, hi[1] << 16), r3 = v[3] - __builtin_bit_cast(float, hi[1] & 0xffff0000u);
+        mid[0] = nt_pack_bf16(r0, r1); mid[1] = nt_pack_bf16(r2, r3);
+        const float q0 = r0 - __builtin_bit_cast(float, mid[0] << 16), q1 = r1 - __builtin_bit_cast(float, mid[0] & 0xffff0000u);
+        const float q2 = r2 - __builtin_bit_cast(float, mid[1] << 16), q3 = r3 - __builtin_bit_cast(float, mid[1] & 0xffff0000u);
+        lo[0] = nt_pack_bf16(q0, q1); lo[1] = nt_pack_bf16(q2, q3);
+      };
+      auto cat = [](const unsigned* x, const unsigned* y) __attribute__((always_inline)) {
+        const u32x4 u = {x[0], x[1], y[0], y[1]};
+        return __builtin_bit_cast(bf16x8, u);
+      };
+      bf16x8 a_hm[MI], a_lh[MI], a_mh[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        unsigned h[2], m[2], l[2];
+        split(a[mi], h, m, l);
+        a_hm[mi] = cat(h, m); a_lh[mi] = cat(l, h); a_mh[mi] = cat(m, h);
+      }
+#pragma unroll
+      for (int i = 0; i < cnt; ++i) {
+        unsigned h[2], m[2], l[2];
+        split(b[i], h, m, l);
+        const bf16x8 b_hh = cat(h, h), b_hm = cat(h, m), b_ml = cat(m, l);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          acc[mi][ni0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hh, a_hm[mi], acc[mi][ni0 + i], 0, 0, 0);   // ah.bh + am.bh
+          acc[mi][ni0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hm, a_lh[mi], acc[mi][ni0 + i], 0, 0, 0);   // al.bh + ah.bm
+          acc[mi][ni0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_ml, a_mh[mi], acc[mi][ni0 + i], 0, 0, 0);   // am.bm + ah.bl
+        }
+      }
       return;
     }
     if constexpr (BF) {

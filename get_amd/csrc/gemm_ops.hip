@@ -52,7 +52,7 @@ static bool wants_dropout(const Launch& L) {
 // kernel is the correctness net for odd shapes and unaligned operands; a LARGE GEMM landing on it is a performance
 // bug upstream (e.g. a misaligned parameter view), which tests assert against through gh_gemm_path_counters.
 static long long g_path_counts[3] = {0, 0, 0};
-static int g_gemm_mode = 0;       // 0: fp32 MFMA everywhere (default); 1: bf16 MFMA in the big-tile NT/NN GEMMs (gh_set_gemm_mode)
+static int g_gemm_mode = 0;       // 0: fp32 MFMA everywhere (default); 1: bf16 MFMA in the big-tile NT/NN GEMMs; 2: fp32x3 (gh_set_gemm_mode)
 
 template <int WM, int WN, int NI, int MI = 2>
 static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
@@ -110,6 +110,8 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
     if (g_gemm_mode == 1 && WM == 2 && WN == 2 && NI == 10) {
       if constexpr (WM == 2 && WN == 2 && NI == 10)
         hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 10, 2, true>), dim3(grid), dim3(256), 0, s, L);
+    } else if (g_gemm_mode == 2) {      // fp32x3 (experimental): fp32 values and results, products from 3-way bf16 splits on the bf16 MFMA
+      hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, NI, 2, 3>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
     } else
       hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, NI, 2>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
     launched = true;
@@ -450,7 +452,7 @@ struct Batch {
       if (mode < 0) mode = measure_env("GH_NT_TILE_RULE", 1);
       const double r = (double)L.m_tiles * L.nprob / 768.0;
       const double frac = r - (double)(long long)r;
-      if (mode == 1 && g_gemm_mode == 0 && r < 3.0 && frac > 0.02 && frac < 0.45) {
+      if (mode == 1 && g_gemm_mode != 1 && r < 3.0 && frac > 0.02 && frac < 0.45) {
         int mt = 0;
         for (int i = 0; i < L.nprob; ++i) { const int t = (L.p[i].M + 31) / 32; if (t > mt) mt = t; }
         L.m_tiles = mt;
@@ -993,7 +995,7 @@ int gh::linear2_bwd(const float* x0, int k0, const float* x1, int k1, const floa
 }
 
 extern "C" int gh_set_gemm_mode(int mode) {
-  GH_REQUIRE(mode == 0 || mode == 1, "set_gemm_mode: %d is not 0 (fp32) or 1 (bf16 operands in the big NT/NN GEMMs)", mode);
+  GH_REQUIRE(mode == 0 || mode == 1 || mode == 2, "set_gemm_mode: %d is not 0 (fp32), 1 (bf16 operands in the big NT/NN GEMMs) or 2 (fp32x3)", mode);
   g_gemm_mode = mode;
   return 0;
 }

@@ -13,8 +13,8 @@ from get_amd._lib import call, ptr, stream  # noqa: E402
 
 def bench(m, k, n, reps=20, mode="fwd"):
     dev = "cuda:0"
-    if os.environ.get("GEMM_MODE") == "bf16":
-        _lib.set_gemm_mode("bf16")
+    if os.environ.get("GEMM_MODE") in ("bf16", "fp32x3"):
+        _lib.set_gemm_mode(os.environ["GEMM_MODE"])
     x = torch.randn(m, k, device=dev)
     w = torch.randn(n, k, device=dev) / k ** 0.5
     wt = w.t().contiguous()
@@ -47,8 +47,8 @@ def bench(m, k, n, reps=20, mode="fwd"):
         if os.environ.get("GEMM_MODE") == "bf16":       # compare against the same operand rounding
             ref = x.bfloat16().float() @ w.bfloat16().float().t() + b
         else:
-            ref = x @ w.t() + b
-        err = float((y - ref).abs().max())
+            ref = (x.double() @ w.double().t() + b.double())
+        err = float((y.double() - ref).abs().max())
     else:
         err = float("nan")
     print(f"{mode:4s} M={m:6d} K={k:5d} N={n:5d}: {ms:8.4f} ms  {tf:7.2f} TFLOP/s  ({100*tf/157.3:5.1f}% of f32 MFMA peak)  maxerr {err:.2e}")
