@@ -88,9 +88,12 @@ int launch_att_softmax_fwd(const float* e, const float* mask, const float* right
                            int b, int l, int dr, int heads, float* weights, float* attended, hipStream_t s);
 int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w,
                            const int32_t* goff, int m_real, int b, int l, int dr, int heads, float* de, float* dright,
-                           hipStream_t s);
+                           hipStream_t s, const int32_t* rowg = nullptr, float* dw_tmp = nullptr, int* dw_written = nullptr);
+// (rowg + dw_tmp [rows][heads] + dw_written: many-pair launches may take the row-balanced kernel, which leaves the raw
+//  dw in dw_tmp instead of de -- *dw_written says so -- and launch_att_dpre(dw_in = dw_tmp, weights, de_out = de) finishes de)
 int launch_att_dpre(const float* de, const float* w2, const float* t, const int32_t* goff, int m_real, int b, int l,
-                    int ha, int heads, float* dpre, float* du, float* dw2_part, hipStream_t s);
+                    int ha, int heads, float* dpre, float* du, float* dw2_part, hipStream_t s, const float* dw_in = nullptr,
+                    const float* weights = nullptr, float* de_out = nullptr);
 
 // fused building blocks shared by the per-module entry points (gemm_ops.hip) and the composite model entry points
 // (model_ops.hip); argument meaning as the gh_* functions of the same name in include/get_hip.h
@@ -115,7 +118,8 @@ int att_fwd_impl(const float* left, int nl, const int32_t* rowu, const float* ri
 int att_bwd_impl(const float* left, const float* right, const int32_t* goff, int m_real, int b, int l, int xl, int dr, int ha,
                  int heads, const float* w1t, const float* w2, const float* t, const float* weights, const float* g_att,
                  const float* g_w, float* de, float* dpre, float* du, float* dleft, float* dright, float* dw1, float* dw2,
-                 const int32_t* claim_offsets, int nl, float* du_c, int dleft_accumulate, hipStream_t s);
+                 const int32_t* claim_offsets, int nl, float* du_c, int dleft_accumulate, hipStream_t s,
+                 const int32_t* rowg = nullptr, float* dw_tmp = nullptr);
 int linear2_fwd(const float* x0, int k0, const float* x1, int k1, const float* w, const float* bias, float* y, int m, int n, hipStream_t s);
 int linear2_bwd(const float* x0, int k0, const float* x1, int k1, const float* wt, const float* g, int m, int n, float* dx0,
                 int dx0_accumulate, float* dx1, float* dw, float* db, hipStream_t s);

@@ -882,7 +882,8 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
                  int xl, int dr, int ha, int heads, const float* w1t, const float* w2, const float* t, const float* weights,
                  const float* g_att, const float* g_w, float* de, float* dpre, float* du,
                  float* dleft, float* dright, float* dw1, float* dw2,
-                 const int32_t* claim_offsets, int nl, float* du_c, int dleft_accumulate, hipStream_t s) {
+                 const int32_t* claim_offsets, int nl, float* du_c, int dleft_accumulate, hipStream_t s,
+                 const int32_t* rowg, float* dw_tmp) {
   GH_REQUIRE(heads >= 1 && heads <= 8, "concat_att: heads=%d not in [1,8]", heads);
   if (!goff) m_real = b * l;
   GH_REQUIRE(m_real >= 0 && m_real <= b * l, "concat_att_bwd: node-compact rows %d do not fit b*l=%d", m_real, b * l);
@@ -898,12 +899,14 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
   GH_REQUIRE(!weights_only || dw1, "concat_att_bwd: dright == NULL asks for the dw1-only phase, which needs dw1");
   float* dw2_part = nullptr;
   if (!weights_only) {
-  if (int e = launch_att_softmax_bwd(right, weights, g_att, g_w, goff, m_real, b, l, dr, heads, de, dright, s)) return e;
+  int dw_written = 0;
+  if (int e = launch_att_softmax_bwd(right, weights, g_att, g_w, goff, m_real, b, l, dr, heads, de, dright, s, rowg, dw_tmp, &dw_written)) return e;
   // dW2 = de^T t rides along with the dpre pass (per-pair partials in the workspace, one reduce)
   const size_t dw2_bytes = (size_t)b * heads * ha * sizeof(float);
   const Workspace wsp = workspace_for(s);
   dw2_part = (wsp.p && dw2_bytes <= wsp.bytes && ha % 4 == 0) ? wsp.p : nullptr;
-  if (int e = launch_att_dpre(de, w2, t, goff, m_real, b, l, ha, heads, dpre, du, dw2_part, s)) return e;
+  if (int e = launch_att_dpre(de, w2, t, goff, m_real, b, l, ha, heads, dpre, du, dw2_part, s, dw_written ? dw_tmp : nullptr,
+                              dw_written ? weights : nullptr, dw_written ? de : nullptr)) return e;
   if (dw2_part) {
     ReduceArgs R;
     R.n = 1;

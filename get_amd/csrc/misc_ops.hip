@@ -649,11 +649,128 @@ att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict_
   }
 }
 
+
+// Row-balanced first half of the same backward for the word level (Dr <= 512): one workgroup per PAIR left 960 workgroups
+// of 158 VGPRs for 768 resident slots -- 1.25 rounds, 2.0 TB/s.  Here every WAVE owns an equal run of consecutive rows
+// of the whole batch (pair boundaries are crossed by reloading the pair's g_att columns, 4 C floats per lane and chunk,
+// contiguous in g_att's [Dr][C] layout), writes dright rows and the raw dw[row][c] = right[row] . g_att[pair][:, c] (+ g_w);
+// the per-pair part of the softmax backward (de = w (dw - sum_l w dw)) moves into att_dpre_kernel's prologue, which
+// stages those few values per pair anyway.  <= 128 VGPRs: 16 waves per CU, three rows in flight per wave.
+template <int CT>      // exact number of heads
+__global__ void __launch_bounds__(256, CT <= 5 ? 4 : 3)
+att_rows_bwd_kernel(const float* __restrict__ right, const float* __restrict__ weights, const float* __restrict__ g_att,
+                    const float* __restrict__ g_w, const int32_t* __restrict__ rowg, int Lmax, int Dr, int C, int M,
+                    int rows_per_wave, float* __restrict__ dw_out, float* __restrict__ dright) {
+  constexpr int NCH = 2;
+  const int lane = threadIdx.x & 63;
+  const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int r0 = gw * rows_per_wave, r1 = min(M, r0 + rows_per_wave);
+  if (r0 >= r1) return;
+  const int D4 = Dr / 4;
+  int dcl[NCH];
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) dcl[h] = min(lane + 64 * h, D4 - 1);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* rp = reinterpret_cast<const float4*>(right);
+  // three rows in flight (loads unconditional from clamped rows; duplicates are never consumed)
+  float4 ra[NCH], rb[NCH], rc[NCH];
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) {
+    ra[h] = rp[(size_t)r0 * D4 + dcl[h]];
+    rb[h] = rp[(size_t)min(r0 + 1, r1 - 1) * D4 + dcl[h]];
+    rc[h] = rp[(size_t)min(r0 + 2, r1 - 1) * D4 + dcl[h]];
+  }
+  float4 gq[CT][NCH];
+  int cur = -1;
+  for (int l = r0; l < r1; ++l) {
+    const int pair = rowg ? rowg[l] : l / Lmax;
+    if (pair != cur) {          // wave-uniform: this pair's g_att columns, 4 C consecutive floats per lane and chunk
+      cur = pair;
+      const float4* gp = reinterpret_cast<const float4*>(g_att + (size_t)pair * Dr * CT);
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        float G[4 * CT];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          const float4 v = gp[(size_t)dcl[h] * CT + j];
+          G[4 * j] = v.x; G[4 * j + 1] = v.y; G[4 * j + 2] = v.z; G[4 * j + 3] = v.w;
+        }
+        const bool live = lane + 64 * h < D4;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          // element (d = 4 d4 + k, c) sits at G[k * C + c] (the kernel is instantiated for the exact head count: C == CT)
+          gq[c][h] = live ? make_float4(G[0 * CT + c], G[1 * CT + c], G[2 * CT + c], G[3 * CT + c]) : zero4;
+        }
+      }
+    }
+    float4 cu[NCH];
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) { cu[h] = ra[h]; ra[h] = rb[h]; rb[h] = rc[h]; }
+    if (l + 3 < r1) {
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) rc[h] = rp[(size_t)(l + 3) * D4 + dcl[h]];
+    }
+    float4 aa[NCH];
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) aa[h] = zero4;
+    float pa[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      pa[c] = 0.f;
+      {
+        const float wv = weights[(size_t)l * CT + c];
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) {
+          const float4 q = gq[c][h];
+          aa[h].x += wv * q.x; aa[h].y += wv * q.y; aa[h].z += wv * q.z; aa[h].w += wv * q.w;
+          pa[c] += cu[h].x * q.x + cu[h].y * q.y + cu[h].z * q.z + cu[h].w * q.w;
+        }
+      }
+    }
+    float4* dp = reinterpret_cast<float4*>(dright + (size_t)l * Dr);
+#pragma unroll
+    for (int h = 0; h < NCH; ++h)
+      if (lane + 64 * h < D4) dp[lane + 64 * h] = aa[h];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      {
+        const float v = wave_sum_dpp(pa[c]);
+        if (lane == 0) dw_out[(size_t)l * CT + c] = v + (g_w ? g_w[(size_t)l * CT + c] : 0.f);
+      }
+  }
+}
+
 int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w,
                            const int32_t* goff, int m_real, int b, int l, int dr, int heads, float* de, float* dright,
-                           hipStream_t s) {
+                           hipStream_t s, const int32_t* rowg, float* dw_tmp, int* dw_written) {
   GH_REQUIRE(dr % 4 == 0 && (reinterpret_cast<uintptr_t>(right) & 15) == 0 && (reinterpret_cast<uintptr_t>(dright) & 15) == 0,
              "att_softmax_bwd: right rows must be float4-shaped (dr=%d)", dr);
+  if (dw_written) *dw_written = 0;
+  // many pairs, rows that fit two float4 chunks per lane, 16-byte aligned g_att rows: the row-balanced kernel; de is then
+  // finished by att_dpre's prologue (launch_att_dpre with dw_in)
+  if (dw_tmp && dw_written && dr / 4 <= 128 && (goff == nullptr || rowg != nullptr) &&
+      (reinterpret_cast<uintptr_t>(g_att) & 15) == 0 && heads >= 1 && heads <= 8) {
+    const int M = goff ? m_real : b * l;
+    if (M <= 0) return 0;
+    const int waves = 256 * 4 * 4;                       // 16 waves per CU
+    const int rpw = (M + waves - 1) / waves < 4 ? 4 : (M + waves - 1) / waves;
+    const int nwg = ((M + rpw - 1) / rpw + 3) / 4;
+    const int ptag = b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_SOFTMAX_BWD;
+    prof_begin(s, ptag);
+    static const void* const fns[8] = {(const void*)att_rows_bwd_kernel<1>, (const void*)att_rows_bwd_kernel<2>,
+                                       (const void*)att_rows_bwd_kernel<3>, (const void*)att_rows_bwd_kernel<4>,
+                                       (const void*)att_rows_bwd_kernel<5>, (const void*)att_rows_bwd_kernel<6>,
+                                       (const void*)att_rows_bwd_kernel<7>, (const void*)att_rows_bwd_kernel<8>};
+    const void* fn = fns[heads - 1];
+    int Mv = M, rpwv = rpw;
+    void* args[] = {(void*)&right, (void*)&weights, (void*)&g_att, (void*)&g_w, (void*)&rowg, (void*)&l, (void*)&dr, (void*)&heads,
+                    (void*)&Mv, (void*)&rpwv, (void*)&dw_tmp, (void*)&dright};
+    (void)hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, s);
+    prof_end(ptag, 4.0 * (2.0 * M * dr + 3.0 * M * heads + (double)b * dr * heads), s);
+    GH_LAUNCH_CHECK();
+    *dw_written = 1;
+    return 0;
+  }
   const size_t lds = ((size_t)dr * heads + 2 * (size_t)l * heads) * 4;
   GH_REQUIRE(lds <= 160 * 1024, "att_softmax_bwd: %zu B of LDS needed", lds);
   GH_REQUIRE(heads >= 1 && heads <= 8, "att_softmax_bwd: %d heads (1..8 supported)", heads);
@@ -680,7 +797,8 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
 // to a third -- the one-workgroup-per-pair version was latency-bound at 2.0 TB/s.
 __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __restrict__ w2, const float* __restrict__ t,
                                 const int32_t* __restrict__ goff, int Lmax, int Ha, int C, int RL, int S4,
-                                float* __restrict__ dpre, float* __restrict__ du, float* __restrict__ dw2_part) {
+                                float* __restrict__ dpre, float* __restrict__ du, float* __restrict__ dw2_part,
+                                const float* __restrict__ dw_in, const float* __restrict__ wts, float* __restrict__ de_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   float4* red = reinterpret_cast<float4*>(dsm);           // [RL][1 + C][S4]
   const int b = blockIdx.x;
@@ -706,7 +824,28 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
 #pragma unroll
     for (int u = 0; u < RB; ++u) nxt[u] = tb[(size_t)min(rl + u * RL, L - 1) * n4];
   }
-  for (int i = threadIdx.x; i < L * C; i += blockDim.x) des[i] = de[(size_t)row0 * C + i];
+  if (dw_in) {
+    // second half of the softmax backward, per pair (att_rows_bwd_kernel left the raw dw): de = w (dw - sum_l w dw)
+    float* wl = des + (size_t)Lmax * C;                    // [L][C] softmax weights
+    for (int i = threadIdx.x; i < L * C; i += blockDim.x) { des[i] = dw_in[(size_t)row0 * C + i]; wl[i] = wts[(size_t)row0 * C + i]; }
+    __syncthreads();
+    float* sums = wl + (size_t)Lmax * C;                   // [C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    for (int c = wave; c < C; c += nwv) {
+      float sm = 0.f;
+      for (int l = lane; l < L; l += 64) sm += wl[l * C + c] * des[l * C + c];
+      for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+      if (lane == 0) sums[c] = sm;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * C; i += blockDim.x) {
+      const float v = wl[i] * (des[i] - sums[i % C]);
+      des[i] = v;
+      if (de_out && blockIdx.y == 0) de_out[(size_t)row0 * C + i] = v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < L * C; i += blockDim.x) des[i] = de[(size_t)row0 * C + i];
+  }
   float4 wc[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
@@ -768,7 +907,8 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
 }
 
 int launch_att_dpre(const float* de, const float* w2, const float* t, const int32_t* goff, int m_real, int b, int l,
-                    int ha, int heads, float* dpre, float* du, float* dw2_part, hipStream_t s) {
+                    int ha, int heads, float* dpre, float* du, float* dw2_part, hipStream_t s, const float* dw_in,
+                    const float* weights, float* de_out) {
   GH_REQUIRE(ha % 4 == 0 && ha / 4 <= 256, "att_dpre: attention hidden %d must be a multiple of 4 and <= 1024", ha);
   const int n4 = ha / 4;
   // column slabs of <= 32 float4 (512 B of a row per lane group: whole 128-byte lines), ~3 slabs at ha = 300; few pairs
@@ -782,9 +922,11 @@ int launch_att_dpre(const float* de, const float* w2, const float* t, const int3
   const int S4 = (n4 + nsl - 1) / nsl;
   const int RL = (256 / S4) > 0 ? (256 / S4) : 1;
   const int threads = ((S4 * RL + 63) / 64) * 64;
-  const size_t lds = (size_t)RL * (1 + heads) * S4 * 16 + (size_t)l * heads * 4;
+  GH_REQUIRE(!dw_in || weights, "att_dpre: dw_in needs the softmax weights");
+  const size_t lds = (size_t)RL * (1 + heads) * S4 * 16 + (size_t)l * heads * 4 * (dw_in ? 2 : 1) + (dw_in ? 64 : 0);
   prof_begin(s, b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_DPRE);
-  hipLaunchKernelGGL(att_dpre_kernel, dim3(b, nsl), dim3(threads), lds, s, de, w2, t, goff, l, ha, heads, RL, S4, dpre, du, dw2_part);
+  hipLaunchKernelGGL(att_dpre_kernel, dim3(b, nsl), dim3(threads), lds, s, de, w2, t, goff, l, ha, heads, RL, S4, dpre, du, dw2_part,
+                     dw_in, weights, de_out);
   const double rows = goff ? (double)m_real : (double)b * l;
   prof_end(b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_DPRE, 4.0 * (2.0 * rows * ha + rows * heads + (double)b * ha), s);
   GH_LAUNCH_CHECK();

@@ -29,7 +29,7 @@ struct FwdBuf {
 };
 struct BwdBuf {
   int64_t d_y0, d_new_left, d_att_e, de_e, dpre_e, du_e, dright_e, d_avg;
-  int64_t de_w, dpre_w, du_w, du_c, d_q, g2, d_qhid, qs[5], sc2[5], sc1[5], dx2;
+  int64_t de_w, dw_w, dpre_w, du_w, du_c, d_q, g2, d_qhid, qs[5], sc2[5], sc1[5], dx2;
   int64_t total;
 };
 struct Bump {
@@ -99,7 +99,7 @@ static int layout(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d, FwdBu
   w.de_e = c.take((int64_t)d.B * d.n * d.he); w.dpre_e = c.take((int64_t)d.B * d.n * d.H); w.du_e = c.take((int64_t)d.B * d.H);
   w.dright_e = c.take((int64_t)d.B * d.n * d.Dre);
   w.d_avg = c.take((int64_t)d.B1 * d.Xa);
-  w.de_w = c.take((int64_t)d.Mr * d.hw); w.dpre_w = c.take((int64_t)d.Mr * d.H); w.du_w = c.take((int64_t)d.B1 * d.H);
+  w.de_w = c.take((int64_t)d.Mr * d.hw); w.dw_w = c.take((int64_t)d.Mr * d.hw); w.dpre_w = c.take((int64_t)d.Mr * d.H); w.du_w = c.take((int64_t)d.B1 * d.H);
   w.du_c = c.take((int64_t)d.B * d.H);
   w.d_q = d.cs > 0 ? c.take((int64_t)d.B * d.H) : w.d_new_left;
   w.g2 = c.take((int64_t)d.Mr * d.H);
@@ -378,7 +378,7 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
     // ---- word-level attention: per-pair du summed per claim; d(claim vector) accumulates on top of the head / evidence part
     GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
                         A + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, Wb + w.g2, nullptr,
-                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, s));
+                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, s, d.compact ? Ba->rowg : nullptr, Wb + w.dw_w));
     // ---- side stream: linear1's weight gradient of the word attention, then the claim branch's backward -- underneath
     //      the evidence cells' chain on the main stream
     GH_TRY(stream_after(ss, s, ev.ev[4]));
