@@ -672,6 +672,15 @@ att_rows_bwd_kernel(const float* __restrict__ right, const float* __restrict__ w
   for (int h = 0; h < NCH; ++h) dcl[h] = min(lane + 64 * h, D4 - 1);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4* rp = reinterpret_cast<const float4*>(right);
+  // this wave's softmax weights and pair ids, staged once into its private LDS region: a per-row global load in the
+  // loop (weights[l][c], rowg[l]) put one unhidden memory latency into every iteration
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  float* wl = reinterpret_cast<float*>(dsm) + (size_t)(threadIdx.x >> 6) * rows_per_wave * (2 * CT + 1);
+  int* pl = reinterpret_cast<int*>(wl + (size_t)rows_per_wave * CT);
+  float* dwl = wl + (size_t)rows_per_wave * (CT + 1);      // this wave's dw values: written out in one coalesced pass at the end
+  const int nr = r1 - r0;
+  for (int i = lane; i < nr * CT; i += 64) wl[i] = weights[(size_t)r0 * CT + i];
+  for (int i = lane; i < nr; i += 64) pl[i] = rowg ? rowg[r0 + i] : (r0 + i) / Lmax;
   // three rows in flight (loads unconditional from clamped rows; duplicates are never consumed)
   float4 ra[NCH], rb[NCH], rc[NCH];
 #pragma unroll
@@ -682,8 +691,12 @@ att_rows_bwd_kernel(const float* __restrict__ right, const float* __restrict__ w
   }
   float4 gq[CT][NCH];
   int cur = -1;
-  for (int l = r0; l < r1; ++l) {
-    const int pair = rowg ? rowg[l] : l / Lmax;
+  // one row: `buf` holds it (requested three rows ago); its slot is re-requested for row l + 3 right away.  The three slots
+  // keep their roles (the loop is unrolled by three): rotating them through register moves would make every iteration wait
+  // for ALL outstanding loads -- a move out of a register that a load is still filling waits for that load.
+  auto step = [&](int l, float4 (&buf)[NCH]) __attribute__((always_inline)) {
+    if (l >= r1) return;
+    const int pair = pl[l - r0];
     if (pair != cur) {          // wave-uniform: this pair's g_att columns, 4 C consecutive floats per lane and chunk
       cur = pair;
       const float4* gp = reinterpret_cast<const float4*>(g_att + (size_t)pair * Dr * CT);
@@ -697,18 +710,17 @@ att_rows_bwd_kernel(const float* __restrict__ right, const float* __restrict__ w
         }
         const bool live = lane + 64 * h < D4;
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
+        for (int c = 0; c < CT; ++c)
           // element (d = 4 d4 + k, c) sits at G[k * C + c] (the kernel is instantiated for the exact head count: C == CT)
           gq[c][h] = live ? make_float4(G[0 * CT + c], G[1 * CT + c], G[2 * CT + c], G[3 * CT + c]) : zero4;
-        }
       }
     }
     float4 cu[NCH];
 #pragma unroll
-    for (int h = 0; h < NCH; ++h) { cu[h] = ra[h]; ra[h] = rb[h]; rb[h] = rc[h]; }
+    for (int h = 0; h < NCH; ++h) cu[h] = buf[h];
     if (l + 3 < r1) {
 #pragma unroll
-      for (int h = 0; h < NCH; ++h) rc[h] = rp[(size_t)(l + 3) * D4 + dcl[h]];
+      for (int h = 0; h < NCH; ++h) buf[h] = rp[(size_t)(l + 3) * D4 + dcl[h]];
     }
     float4 aa[NCH];
 #pragma unroll
@@ -717,14 +729,12 @@ att_rows_bwd_kernel(const float* __restrict__ right, const float* __restrict__ w
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       pa[c] = 0.f;
-      {
-        const float wv = weights[(size_t)l * CT + c];
+      const float wv = wl[(l - r0) * CT + c];
 #pragma unroll
-        for (int h = 0; h < NCH; ++h) {
-          const float4 q = gq[c][h];
-          aa[h].x += wv * q.x; aa[h].y += wv * q.y; aa[h].z += wv * q.z; aa[h].w += wv * q.w;
-          pa[c] += cu[h].x * q.x + cu[h].y * q.y + cu[h].z * q.z + cu[h].w * q.w;
-        }
+      for (int h = 0; h < NCH; ++h) {
+        const float4 q = gq[c][h];
+        aa[h].x += wv * q.x; aa[h].y += wv * q.y; aa[h].z += wv * q.z; aa[h].w += wv * q.w;
+        pa[c] += cu[h].x * q.x + cu[h].y * q.y + cu[h].z * q.z + cu[h].w * q.w;
       }
     }
     float4* dp = reinterpret_cast<float4*>(dright + (size_t)l * Dr);
@@ -732,14 +742,22 @@ att_rows_bwd_kernel(const float* __restrict__ right, const float* __restrict__ w
     for (int h = 0; h < NCH; ++h)
       if (lane + 64 * h < D4) dp[lane + 64 * h] = aa[h];
 #pragma unroll
-    for (int c = 0; c < CT; ++c)
-      {
-        const float v = wave_sum_dpp(pa[c]);
-        if (lane == 0) dw_out[(size_t)l * CT + c] = v + (g_w ? g_w[(size_t)l * CT + c] : 0.f);
-      }
+    for (int c = 0; c < CT; ++c) {
+      const float v = wave_sum_dpp(pa[c]);
+      if (lane == 0) dwl[(l - r0) * CT + c] = v;
+    }
+  };
+  for (int l = r0; l < r1; l += 3) {
+    step(l, ra);
+    step(l + 1, rb);
+    step(l + 2, rc);
+  }
+  if (g_w) {
+    for (int i = lane; i < nr * CT; i += 64) dw_out[(size_t)r0 * CT + i] = dwl[i] + g_w[(size_t)r0 * CT + i];
+  } else {
+    for (int i = lane; i < nr * CT; i += 64) dw_out[(size_t)r0 * CT + i] = dwl[i];
   }
 }
-
 int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w,
                            const int32_t* goff, int m_real, int b, int l, int dr, int heads, float* de, float* dright,
                            hipStream_t s, const int32_t* rowg, float* dw_tmp, int* dw_written) {
@@ -753,8 +771,10 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
     const int M = goff ? m_real : b * l;
     if (M <= 0) return 0;
     const int waves = 256 * 4 * 4;                       // 16 waves per CU
-    const int rpw = (M + waves - 1) / waves < 4 ? 4 : (M + waves - 1) / waves;
+    int rpw = (M + waves - 1) / waves < 4 ? 4 : (M + waves - 1) / waves;
+    if (rpw > 256) rpw = 256;                            // (LDS staging of a wave's weights: more waves instead of longer runs)
     const int nwg = ((M + rpw - 1) / rpw + 3) / 4;
+    const size_t lds_rows = (size_t)4 * rpw * (2 * heads + 1) * 4;
     const int ptag = b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_SOFTMAX_BWD;
     prof_begin(s, ptag);
     static const void* const fns[8] = {(const void*)att_rows_bwd_kernel<1>, (const void*)att_rows_bwd_kernel<2>,
@@ -765,7 +785,7 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
     int Mv = M, rpwv = rpw;
     void* args[] = {(void*)&right, (void*)&weights, (void*)&g_att, (void*)&g_w, (void*)&rowg, (void*)&l, (void*)&dr, (void*)&heads,
                     (void*)&Mv, (void*)&rpwv, (void*)&dw_tmp, (void*)&dright};
-    (void)hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, s);
+    (void)hipLaunchKernel(fn, dim3(nwg), dim3(256), args, lds_rows, s);
     prof_end(ptag, 4.0 * (2.0 * M * dr + 3.0 * M * heads + (double)b * dr * heads), s);
     GH_LAUNCH_CHECK();
     *dw_written = 1;
