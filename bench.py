@@ -490,7 +490,8 @@ def spawn_ranks(n_gpus: int) -> int:
     GPU of this node (RCCL needs one device per rank: fewer visible GPUs than ranks is an error, not a silent 1-rank run)."""
     import subprocess
     have = torch.cuda.device_count()
-    if have < n_gpus:
+    # (GET_AMD_BENCH_BACKEND=gloo: rehearsal of the launch / barrier / reduction path with ranks sharing devices)
+    if have < n_gpus and os.environ.get("GET_AMD_BENCH_BACKEND", "nccl") == "nccl":
         sys.stderr.write(f"bench.py: --gpus {n_gpus} needs {n_gpus} visible GPUs, this node shows {have}; RCCL runs one rank per "
                          f"device, so the {n_gpus}-rank measurement cannot be taken here (no line printed).\n")
         return 3
