@@ -95,6 +95,10 @@ int launch_att_dpre(const float* de, const float* w2, const float* t, const int3
                     int ha, int heads, float* dpre, float* du, float* dw2_part, hipStream_t s, const float* dw_in = nullptr,
                     const float* weights = nullptr, float* de_out = nullptr);
 
+// Where the gradient w.r.t. a GGNN cell's output goes when the GEMM that produces it applies that cell's gate head in its
+// epilogue (EPI_GATE_PRE): the cell's saved z / hh / xp and its dhp / dzp / dxp scratch (all [rows][h] fp32).
+struct GateFuse { const float* z; const float* hh; const float* xp; float* dhp; float* dzp; float* dxp; };
+
 // fused building blocks shared by the per-module entry points (gemm_ops.hip) and the composite model entry points
 // (model_ops.hip); argument meaning as the gh_* functions of the same name in include/get_hip.h
 int cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
@@ -111,7 +115,9 @@ int cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const float* 
                   const float* hh, const float* g, float* dhp, float* dzp, float* drp, float* dxp, float* da, float* dx,
                   float* dw_p, float* dw_z0, float* dw_z1, float* dw_r0, float* dw_r1, float* dw_h0, float* dw_h1, float* db_z,
                   float* db_r, float* db_h, float* db_z1, float* db_r1, float* db_h1, float drop_p, uint32_t drop_seed, void* stream,
-                  void* wstream, hipEvent_t ev_l1, hipEvent_t ev_agg);      // wstream: weight-gradient stream (NULL = stream)
+                  void* wstream, hipEvent_t ev_l1, hipEvent_t ev_agg,       // wstream: weight-gradient stream (NULL = stream)
+                  int pre_done, const GateFuse* next);   // pre_done: dhp / dzp / dxp already hold the gate head (skip gate_bwd_pre);
+                                                         // next: write the dX product into the previous cell's gate head instead of dx
 int att_fwd_impl(const float* left, int nl, const int32_t* rowu, const float* right, const float* mask, const int32_t* goff,
                  const int32_t* rowg, int m_real, int b, int l, int xl, int dr, int ha, int heads, const float* w1, const float* w2,
                  float* u, float* t, float* e, float* weights, float* attended, hipStream_t s);
@@ -119,7 +125,7 @@ int att_bwd_impl(const float* left, const float* right, const int32_t* goff, int
                  int heads, const float* w1t, const float* w2, const float* t, const float* weights, const float* g_att,
                  const float* g_w, float* de, float* dpre, float* du, float* dleft, float* dright, float* dw1, float* dw2,
                  const int32_t* claim_offsets, int nl, float* du_c, int dleft_accumulate, hipStream_t s,
-                 const int32_t* rowg = nullptr, float* dw_tmp = nullptr);
+                 const int32_t* rowg = nullptr, float* dw_tmp = nullptr, const GateFuse* next = nullptr);
 int linear2_fwd(const float* x0, int k0, const float* x1, int k1, const float* w, const float* bias, float* y, int m, int n, hipStream_t s);
 int linear2_bwd(const float* x0, int k0, const float* x1, int k1, const float* wt, const float* g, int m, int n, float* dx0,
                 int dx0_accumulate, float* dx1, float* dw, float* db, hipStream_t s);

@@ -32,6 +32,9 @@ enum EpiKind : int {
   EPI_ATT,         // t = tanh(v + u[rowg ? rowg[row] : row/R][col]) -> C ; e[row][c] = sum_col t*w2[c][col]
   EPI_BWD_DRX,     // v = d(r*xp): C(drp) = v*xp*r*(1-r) ; out1(dxp) += v*r  (in0 = xp, in1 = r)
   EPI_ATOMIC,      // atomicAdd(C, v)   (TN split-K)
+  EPI_GATE_PRE,    // g = v (+ gin): the GGNN cell backward's elementwise head fused into the GEMM that PRODUCES g (fast NT
+                   // kernel only): C(dhp) = g z (1-h^2) ; out1(dzp) = g (h-xp) z (1-z) ; out2(dxp) = g (1-z)
+                   // (in0 = z, in1 = hh, in2 = xp of the cell that consumes g; g itself is never stored)
 };
 
 struct Seg {
@@ -68,6 +71,8 @@ struct Problem {
   // elements); io bits say which epilogue streams are bf16: 1 = C, 2 = out1, 4 = in0, 8 = in1; c32 (EPI_TANH_H): also
   // write the fp32 value of out1 there (the cell output the fp32 consumers read)
   int elt; int io; float* c32;
+  // EPI_GATE_PRE: optional addend of g (same shape as C), third input stream, third output stream
+  const float* gin; const float* in2; float* out2;
 };
 
 #define GH_MAX_PROBLEMS 8

@@ -475,7 +475,7 @@ gemm_nt_kernel(const Launch L_byval) {
       constexpr int CH = GH_EPI_CH;
 #pragma unroll
       for (int it0 = 0; it0 < NIT; it0 += CH) {
-        float4 xa[CH], xb[CH], xc[CH];
+        float4 xa[CH], xb[CH], xc[CH], xd[E == EPI_GATE_PRE ? CH : 1];
         auto where = [&](int j, int& row, int& col, float*& sp) __attribute__((always_inline)) {
           const int i = tid + (it0 + j) * NTHR;
           const int rr = i / C4, c4 = i - rr * C4;
@@ -497,6 +497,11 @@ gemm_nt_kernel(const Launch L_byval) {
                 xa[j] = ld4(in0, o, io & 4);
                 xb[j] = ld4(in1, o, io & 8);
                 xc[j] = ld4(out1, o, io & 2);
+              } else if (E == EPI_GATE_PRE) {
+                xa[j] = ld4(in0, o, false);
+                xb[j] = ld4(in1, o, false);
+                xc[j] = ld4(P.in2, o, false);
+                if (P.gin) xd[j] = ld4(P.gin, o, false);
               } else if (E == EPI_ATT)
                 xa[j] = *reinterpret_cast<const float4*>(P.u + (size_t)(P.rowg ? P.rowg[row] : row / P.R) * P.ldu + col);
             }
@@ -542,6 +547,21 @@ gemm_nt_kernel(const Launch L_byval) {
                                   w.z * x.z * r4.z * (1.f - r4.z), w.w * x.w * r4.w * (1.f - r4.w)), io & 1);
             d.x += w.x * r4.x; d.y += w.y * r4.y; d.z += w.z * r4.z; d.w += w.w * r4.w;
             st4(out1, o, d, io & 2);
+          } else if (E == EPI_GATE_PRE) {
+            if (drop_mode == 3)      // g is the gradient w.r.t. a dropped-out input (the producing cell's dX)
+              w = drop4(w, drop_seed, (unsigned)row * (unsigned)drop_ld + (unsigned)(P.drop_col0 + col), drop_thresh, drop_scale);
+            if (P.gin) { const float4 a4 = xd[j]; w.x += a4.x; w.y += a4.y; w.z += a4.z; w.w += a4.w; }
+            const float4 Z = xa[j], Hh = xb[j], X = xc[j];
+            float4 a, b, c;
+#define GH_ONE(f)                                      \
+            a.f = w.f * Z.f * (1.f - Hh.f * Hh.f);             \
+            b.f = w.f * (Hh.f - X.f) * Z.f * (1.f - Z.f);      \
+            c.f = w.f * (1.f - Z.f);
+            GH_ONE(x) GH_ONE(y) GH_ONE(z) GH_ONE(w)
+#undef GH_ONE
+            *reinterpret_cast<float4*>(C + o) = a;
+            *reinterpret_cast<float4*>(out1 + o) = b;
+            *reinterpret_cast<float4*>(P.out2 + o) = c;
           } else if (E == EPI_ATT) {
             const float4 u4 = xa[j];
             const float4 t4 = make_float4(tanhf_(w.x + u4.x), tanhf_(w.y + u4.y), tanhf_(w.z + u4.z), tanhf_(w.w + u4.w));
@@ -556,6 +576,7 @@ gemm_nt_kernel(const Launch L_byval) {
     else if (epi == EPI_SIGMOID_R) pass(std::integral_constant<int, EPI_SIGMOID_R>{});
     else if (epi == EPI_TANH_H) pass(std::integral_constant<int, EPI_TANH_H>{});
     else if (epi == EPI_BWD_DRX) pass(std::integral_constant<int, EPI_BWD_DRX>{});
+    else if (epi == EPI_GATE_PRE) { if constexpr (MODE != 2) pass(std::integral_constant<int, EPI_GATE_PRE>{}); }
     else if (epi == EPI_ATT) pass(std::integral_constant<int, EPI_ATT>{});
     if (rowred) {
       // e[row][c] = sum_k y[row][k] w2[c][k] for the 16*WM finished rows in LDS: a [16 x N] x [N x <=8] product per row

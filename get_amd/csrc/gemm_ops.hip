@@ -39,6 +39,8 @@ static bool fast_ok(const Launch& L, bool tn) {
       return false;
     if (p.epi == EPI_ATT && (!al16(p.u) || p.ldu % 4 || !al16(p.w2))) return false;
     if (p.epi == EPI_TANH_H && p.w2 && !al16(p.w2)) return false;
+    if (p.epi == EPI_GATE_PRE && (tn || !p.in0 || !p.in1 || !p.in2 || !p.out1 || !p.out2 || !al16(p.in2) || !al16(p.out2) ||
+                                  (p.gin && !al16(p.gin)) || p.elt)) return false;
   }
   return true;
 }
@@ -85,7 +87,7 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
   if (!fast && wants_dropout(L)) return hipErrorInvalidValue;     // fused dropout exists in the fast kernels only
   if (!fast && !tn)
     for (int i = 0; i < L.nprob; ++i)
-      if (L.p[i].epi == EPI_TANH_H && L.p[i].w2) return hipErrorInvalidValue;   // so does the fused scorer projection
+      if ((L.p[i].epi == EPI_TANH_H && L.p[i].w2) || L.p[i].epi == EPI_GATE_PRE) return hipErrorInvalidValue;   // so do the fused scorer projection and the fused gate head
   bool launched = false;
   bool any_elt = false, all_elt = true;
   for (int i = 0; i < L.nprob; ++i) { any_elt = any_elt || L.p[i].elt; all_elt = all_elt && L.p[i].elt; }
@@ -367,6 +369,9 @@ struct Batch {
       if (q.in0) q.in0 = adv(q.in0, (size_t)n0, q.io & 4);
       if (q.in1) q.in1 = adv(q.in1, (size_t)n0, q.io & 8);
       if (q.c32) q.c32 += n0;
+      if (q.gin) q.gin += n0;
+      if (q.in2) q.in2 += n0;
+      if (q.out2) q.out2 += n0;
       if (L.nprob == GH_MAX_PROBLEMS) flush();
       L.p[L.nprob++] = q;
       const int mt = (q.M + bm - 1) / bm;
@@ -471,7 +476,7 @@ struct Batch {
     int tmax = 0;          // K tiles over the concatenated segments (every problem of a launch is split alike)
     for (int i = 0; i < L.nprob; ++i) {
       const Problem& q = L.p[i];
-      if (q.epi == EPI_ATOMIC || q.drop_mode != 0 || (q.epi == EPI_TANH_H && q.w2) || q.seg0_rows > 0 || q.elt) return false;   // (fp32 problems only)
+      if (q.epi == EPI_ATOMIC || q.epi == EPI_GATE_PRE || q.drop_mode != 0 || (q.epi == EPI_TANH_H && q.w2) || q.seg0_rows > 0 || q.elt) return false;   // (fp32 problems only)
       int t = 0;
       for (int j = 0; j < q.nseg; ++j) t += (q.seg[j].K + 15) / 16;
       if (i > 0 && t != tmax) return false;
@@ -679,7 +684,8 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
                                 float* dx, float* dw_p, float* dw_z0, float* dw_z1, float* dw_r0, float* dw_r1,
                                 float* dw_h0, float* dw_h1, float* db_z, float* db_r, float* db_h,
                                 float* db_z1, float* db_r1, float* db_h1, float drop_p, uint32_t drop_seed,
-                                gh_stream_t stream, gh_stream_t wstream, hipEvent_t ev_l1, hipEvent_t ev_agg) {
+                                gh_stream_t stream, gh_stream_t wstream, hipEvent_t ev_l1, hipEvent_t ev_agg,
+                                int pre_done, const GateFuse* next) {
   hipStream_t s = (hipStream_t)stream;
   // Weight-gradient stream (composite backward, model_ops.hip): the split-K weight-gradient GEMMs only need dzp / drp / dhp
   // (final after the first dX launch) and, for dW_proj, dxp (final after the aggregation).  On their own stream they run
@@ -695,7 +701,11 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
   const int M = m_real;      // padding rows receive no gradient and contribute none
   if (M == 0) return 0;
   // out = h z + xp (1-z):  dhp = g z (1-h^2), dzp = g (h-xp) z (1-z), dxp = g (1-z)
-  if (int e = launch_gate_bwd_pre(g, z, hh, xp, dhp, dzp, dxp, (size_t)M * h, s, bf)) return e;
+  // (pre_done: the GEMM that produced g already wrote the three straight from its epilogue, EPI_GATE_PRE -- g itself was
+  //  never stored and gate_bwd_pre's 4 reads + 3 writes shrink to the 3 + 3 the producing epilogue added)
+  GH_REQUIRE(!(pre_done && bf), "ggnn_cell_bwd: the fused gate head exists for the fp32 pipeline only");
+  if (!pre_done)
+    if (int e = launch_gate_bwd_pre(g, z, hh, xp, dhp, dzp, dxp, (size_t)M * h, s, bf)) return e;
   const bool wide = bf && h % 256 == 0;
   {  // hp = a Wh0^T + (r xp) Wh1^T:  da = dhp Wh0 ; d(r xp) = dhp Wh1 -> drp, dxp += .
     Batch b(false, M, s, wide);
@@ -745,9 +755,13 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
     GH_CHECK_HIP(hipEventRecord(ev_agg, s));
     GH_CHECK_HIP(hipStreamWaitEvent(sw, ev_agg, 0));
   }
-  if (dx) {  // dx = (dxp Wp) . mask/(1-p)
+  if (dx || next) {  // dx = (dxp Wp) . mask/(1-p)
+    GH_REQUIRE(!next || (!bf && din % 4 == 0), "ggnn_cell_bwd: the fused gate head needs the fp32 pipeline and float4-shaped rows");
     Batch b(false, M, s, wide && din % 256 == 0);
-    Problem p = gemm_problem(M, din, EPI_STORE, dx, din, dxp, h, wt_p, h, h, nullptr, bf);      // dx itself is fp32
+    Problem p = gemm_problem(M, din, next ? EPI_GATE_PRE : EPI_STORE, next ? next->dhp : dx, din, dxp, h, wt_p, h, h, nullptr, bf);      // dx itself is fp32
+    if (next) {      // dx IS the gradient w.r.t. the previous cell's output: write that cell's dhp / dzp / dxp instead of dx
+      p.in0 = next->z; p.in1 = next->hh; p.in2 = next->xp; p.out1 = next->dzp; p.out2 = next->dxp;
+    }
     set_dropout(p, 3, din, drop_p, drop_seed);
     b.add(p);
     b.flush();
@@ -796,7 +810,7 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
                                 gh_stream_t stream) {
   return cell_bwd_impl(0, bits, dinv, vals, keep, goff, m_real, x, ids, n, r, din, h, wt_p, wt_z0, wt_z1, wt_r0, wt_r1, wt_h0, wt_h1,
                        xp, a, z, rr, rx, hh, g, dhp, dzp, drp, dxp, da, dx, dw_p, dw_z0, dw_z1, dw_r0, dw_r1, dw_h0, dw_h1,
-                       db_z, db_r, db_h, db_z1, db_r1, db_h1, drop_p, drop_seed, stream, nullptr, nullptr, nullptr);
+                       db_z, db_r, db_h, db_z1, db_r1, db_h1, drop_p, drop_seed, stream, nullptr, nullptr, nullptr, 0, nullptr);
 }
 
 extern "C" int gh_ggnn_cell_bwd_bf16(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
@@ -816,7 +830,7 @@ extern "C" int gh_ggnn_cell_bwd_bf16(const uint64_t* bits, const float* dinv, co
   return cell_bwd_impl(1, bits, dinv, vals, keep, goff, m_real, (cf)x, ids, n, r, din, h, (cf)wt_p, (cf)wt_z0, (cf)wt_z1, (cf)wt_r0,
                        (cf)wt_r1, (cf)wt_h0, (cf)wt_h1, (cf)xp, (cf)a, (cf)z, (cf)rr, (cf)rx, (cf)hh, g, (mf)dhp, (mf)dzp, (mf)drp,
                        (mf)dxp, (mf)da, dx, dw_p, dw_z0, dw_z1, dw_r0, dw_r1, dw_h0, dw_h1, db_z, db_r, db_h, db_z1, db_r1,
-                       db_h1, drop_p, drop_seed, stream, nullptr, nullptr, nullptr);
+                       db_h1, drop_p, drop_seed, stream, nullptr, nullptr, nullptr, 0, nullptr);
 }
 
 // Concat attention, generalised for the composite model entry points (model_ops.hip):
@@ -883,7 +897,7 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
                  const float* g_att, const float* g_w, float* de, float* dpre, float* du,
                  float* dleft, float* dright, float* dw1, float* dw2,
                  const int32_t* claim_offsets, int nl, float* du_c, int dleft_accumulate, hipStream_t s,
-                 const int32_t* rowg, float* dw_tmp) {
+                 const int32_t* rowg, float* dw_tmp, const GateFuse* next) {
   GH_REQUIRE(heads >= 1 && heads <= 8, "concat_att: heads=%d not in [1,8]", heads);
   if (!goff) m_real = b * l;
   GH_REQUIRE(m_real >= 0 && m_real <= b * l, "concat_att_bwd: node-compact rows %d do not fit b*l=%d", m_real, b * l);
@@ -916,7 +930,14 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
   }
   if (claim_offsets && xl > 0)
     if (int e = gh_seg_sum(du, claim_offsets, du_c, nl, ha, (gh_stream_t)s)) return e;
-  if (M > 0) {  // dright += dpre W1[:, xl:]
+  if (M > 0 && next) {  // dright (= the gradient of the cell that produced `right`) is consumed by that cell's gate head only:
+    Batch bt(false, M, s);      // g = softmax part (in dright) + dpre W1[:, xl:] goes straight into dhp / dzp / dxp
+    Problem p = gemm_problem(M, dr, EPI_GATE_PRE, next->dhp, dr, dpre, ha, w1t + (size_t)xl * ha, ha, ha);
+    p.gin = dright; p.in0 = next->z; p.in1 = next->hh; p.in2 = next->xp; p.out1 = next->dzp; p.out2 = next->dxp;
+    bt.add(p);
+    bt.flush();
+    GH_CHECK_HIP(bt.err);
+  } else if (M > 0) {  // dright += dpre W1[:, xl:]
     Batch bt(false, M, s);
     Problem p = gemm_problem(M, dr, EPI_STORE, dright, dr, dpre, ha, w1t + (size_t)xl * ha, ha, ha);
     p.accumulate = 1;
@@ -960,7 +981,7 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, const in
                                  const float* g_att, const float* g_w, float* de, float* dpre, float* du,
                                  float* dleft, float* dright, float* dw1, float* dw2, gh_stream_t stream) {
   return att_bwd_impl(left, right, goff, m_real, b, l, xl, dr, ha, heads, w1t, w2, t, weights, g_att, g_w, de, dpre, du, dleft, dright,
-                      dw1, dw2, nullptr, b, nullptr, 0, (hipStream_t)stream);
+                      dw1, dw2, nullptr, b, nullptr, 0, (hipStream_t)stream, nullptr, nullptr, nullptr);
 }
 
 // y[m][n] = [x0 | x1] . W^T + bias with W [n][k0 + k1] as stored: the head's first layer on the concatenation

@@ -261,12 +261,12 @@ static int cell_fwd(const gh_cell_params& c, const CellBuf& cb, float* A, const 
 static int cell_bwd(const gh_cell_params& c, const CellBuf& cb, const float* A, const uint64_t* bits, const float* dinv,
                     const float* vals, const uint64_t* keep, const int32_t* goff, int m_real, const float* x, const int32_t* ids, int n,
                     int r, int din, int h, const float* g, float* W, const int64_t* sc, float* dx, float drop_p, uint32_t seed,
-                    hipStream_t s, hipStream_t sw = nullptr, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+                    hipStream_t s, int pre_done = 0, const GateFuse* next = nullptr) {
   GH_REQUIRE(c.wt_p && c.dw_p && c.db_z0 && c.db_z1, "get_backward: a cell's transposes / gradient outputs are missing");
   return cell_bwd_impl(0, bits, dinv, vals, keep, goff, m_real, x, ids, n, r, din, h, c.wt_p, c.wt_z0, c.wt_z1, c.wt_r0, c.wt_r1,
                        c.wt_h0, c.wt_h1, A + cb.xp, A + cb.a, A + cb.z, A + cb.rr, A + cb.rx, A + cb.hh, g, W + sc[0], W + sc[1],
                        W + sc[2], W + sc[3], W + sc[4], dx, c.dw_p, c.dw_z0, c.dw_z1, c.dw_r0, c.dw_r1, c.dw_h0, c.dw_h1, c.db_z0,
-                       c.db_r0, c.db_h0, c.db_z1, c.db_r1, c.db_h1, drop_p, seed, (void*)s, (void*)sw, e0, e1);
+                       c.db_r0, c.db_h0, c.db_z1, c.db_r1, c.db_h1, drop_p, seed, (void*)s, nullptr, nullptr, nullptr, pre_done, next);
 }
 
 extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, float* A, gh_stream_t stream, gh_stream_t side_stream) {
@@ -346,6 +346,9 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
   const int32_t* goff = d.compact ? Ba->goff : nullptr;
   const int32_t* ids1 = d.compact ? Ba->cids : Ba->d_ids;
   const uint64_t* keep = reinterpret_cast<const uint64_t*>(A + f.keep);
+  // gate heads fused into the producing GEMMs' epilogues: cell scratch order is {dhp, dzp, drp, dxp, da}
+  const GateFuse gf2 = {A + f.c2.z, A + f.c2.hh, A + f.c2.xp, Wb + w.sc2[0], Wb + w.sc2[1], Wb + w.sc2[3]};
+  const GateFuse gf1 = {A + f.c1.z, A + f.c1.hh, A + f.c1.xp, Wb + w.sc1[0], Wb + w.sc1[1], Wb + w.sc1[3]};
   if (phase != 2) {
     // ---- head
     GH_TRY(gh_linear_bwd(A + f.y0, Mo->out1_wt, Mo->out1_w, g_phi, d.B, H, d.C, Wb + w.d_y0, Mo->d_out1_w, Mo->d_out1_b, (void*)s));
@@ -375,10 +378,12 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
                            A + f.has, Wb + w.d_q, Mo->d_claim_src_table, d.B, d.cs, H);
       GH_LAUNCH_CHECK();
     }
-    // ---- word-level attention: per-pair du summed per claim; d(claim vector) accumulates on top of the head / evidence part
+    // ---- word-level attention: per-pair du summed per claim; d(claim vector) accumulates on top of the head / evidence part.
+    //      Its dright GEMM produces the gradient of the second evidence cell's output and nothing else reads it: the GEMM's
+    //      epilogue applies that cell's gate head (gf2); likewise the second cell's dX GEMM feeds the first cell's (gf1).
     GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
                         A + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, Wb + w.g2, nullptr,
-                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, s, d.compact ? Ba->rowg : nullptr, Wb + w.dw_w));
+                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, s, d.compact ? Ba->rowg : nullptr, Wb + w.dw_w, &gf2));
     // ---- side stream: linear1's weight gradient of the word attention, then the claim branch's backward -- underneath
     //      the evidence cells' chain on the main stream
     GH_TRY(stream_after(ss, s, ev.ev[4]));
@@ -392,11 +397,11 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
     //      bench step: 6.31 -> 6.23 ms, two MFMA-bound streams mostly slow each other down, while every kernel's wall time
     //      and with it the per-kernel roofline figures inflate by 20-30 %.  Not used: one stream, honest kernel times.)
     GH_TRY(cell_bwd(Mo->cell2, f.c2, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, keep, goff, d.Mr, A + f.c1.out, nullptr, d.B1, d.R, H, H,
-                    Wb + w.g2, Wb, w.sc2, Wb + w.dx2, Ba->drop_gnn, Ba->seed_cell2, s));
+                    Wb + w.g2, Wb, w.sc2, nullptr, Ba->drop_gnn, Ba->seed_cell2, s, 1, &gf1));
   }
   if (phase != 1) {
     GH_TRY(cell_bwd(Mo->cell1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, Mo->embedding, ids1, d.B1, d.R, d.D, H,
-                    Wb + w.dx2, Wb, w.sc1, nullptr, Ba->drop_gnn, Ba->seed_cell1, s));
+                    nullptr, Wb, w.sc1, nullptr, Ba->drop_gnn, Ba->seed_cell1, s, 1, nullptr));
     GH_TRY(stream_after(s, ss, ev.ev[5]));
   }
   return 0;
