@@ -57,7 +57,8 @@ __device__ __forceinline__ unsigned nt_pack_bf16(float a, float b) {
 //         (M = 96 000, N = 300: 101.7 / 113.9 / 131.9 TF at K = 300 / 600 / 1200 against 97.5 / 110.0 / 127.8 exact, same
 //         error against fp64): the ~350 VALU instructions per K tile that split the 12 fragments (48 floats per lane, most of
 //         them the WEIGHT fragments every workgroup splits again) take as long as the MFMAs they replace.  The mode stays
-//         opt-in and experimental; the way to its 2x is weights pre-split once per optimiser step.
+//         opt-in and experimental.  Upper bound with the weight pieces pre-split once per optimiser step (measured by feeding the
+//         raw fragment bits as "pieces", results invalid): 130.8 / 151.0 / 184.3 TF at K = 300 / 600 / 1200.
 template <int WM, int WN, int NI, int MI = 2, int MODE = 0>
 __global__ void __launch_bounds__(WM * WN * 64, (MI == 4 || MODE == 3) ? 2 : 3)
 gemm_nt_kernel(const Launch L_byval) {

@@ -70,7 +70,12 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
   const int n_inner = tn ? L.m_tiles * L.nprob : L.nprob * L.ksplit;
   const int grid = 8 * ((n_outer + 7) / 8) * n_inner;
   if (grid <= 0) return hipSuccess;
-  const int tag = (WM * WN == 4 && WN != 4 ? PROF_GEMM_BIG : PROF_GEMM_SMALL) + (tn ? 1 : 0);
+  // profiler row: by the SIZE of the launch, not by the tile configuration it runs on -- the activation-sized single-problem
+  // launches that the occupancy rule moves to the 32-row tile belong with the big GEMMs (booked under
+  // gemm_small they made gemm_big look better than the path is)
+  int max_rows = 0;
+  for (int i = 0; i < L.nprob; ++i) { const int rws = tn ? L.p[i].seg[0].K : L.p[i].M; if (rws > max_rows) max_rows = rws; }
+  const int tag = (max_rows >= 8192 ? PROF_GEMM_BIG : PROF_GEMM_SMALL) + (tn ? 1 : 0);
   double flops = 0.0;
   if (prof_enabled()) {
     for (int i = 0; i < L.nprob; ++i)

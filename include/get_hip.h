@@ -367,7 +367,7 @@ int gh_get_prepare(const int32_t* claim_tokens, const int32_t* claim_len, int b,
 
 /* ---- measurement hook (bench.py): HIP events around every kernel launch on its own stream ----
  * rows of `out` (each {total ms, total algorithmic work, launches}; work = flops for GEMMs, bytes otherwise):
- * 0 gemm big-M tile (64x320) NT/NN, 1 same TN, 2 gemm few-row tile (32x320) NT/NN, 3 same TN, 4 spmm, 5 scorer_gsl,
+ * 0 activation-sized GEMM launches (>= 8192 rows) NT/NN, 1 same TN, 2 few-row GEMM launches NT/NN, 3 same TN, 4 spmm, 5 scorer_gsl,
  * 6 graph_build, 7 att_softmax_fwd, 8 att_softmax_bwd, 9 att_dpre, 10 gate_bwd_pre, 11 colsum, 12 adam */
 #define GH_PROFILE_ROWS 13
 int gh_profile_enable(int on);

@@ -3,7 +3,7 @@
 # configs, the step timeline, the 2-rank rehearsal (GPU box, repo root).  usage: tools/collect_r03.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03; mkdir -p $O
-git rev-parse HEAD > $O/commit.txt 2>/dev/null
+[ -f tools/_commit.txt ] && cp tools/_commit.txt $O/commit.txt
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_err.log
 tail -c 300 $O/bench_line.json
 rm -rf /tmp/stats
@@ -15,6 +15,7 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_
   ( cd /tmp && timeout 600 rocprofv3 --pmc $c --output-format csv -d $d -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-series --no-side-modes > $GRAFT_REPO_ROOT/$O/pmc_$n.log 2>&1 )
   python tools/pmc_sum.py $d > $O/pmc_$n.txt 2>&1
 done
+python tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "$(cat $O/commit.txt 2>/dev/null)" > $O/pmc_traffic.json 2>> $O/bench_err.log
 bash tools/trace_r3.sh r03 > /dev/null 2>&1; cp gpurun_out/r3/trace_r03.txt $O/step_timeline.txt
 bash tools/trace_r3.sh r03_snopes --evd-dist snopes > /dev/null 2>&1; cp gpurun_out/r3/trace_r03_snopes.txt $O/step_timeline_snopes.txt
 # BASELINE configs[2] (PolitiFact-shaped) and configs[4] (h = 768, fp32 and bf16 storage)
