@@ -572,6 +572,119 @@ gemm_nt_kernel(const Launch L_byval) {
         }
       }
     };
+    // bf16 storage pipeline (MODE 2): the same linear pass on items of EIGHT columns -- one 16-byte access per bf16
+    // stream and item (two float4 of the staged row) instead of the 8-byte accesses a float4 item gives: the epilogue of
+    // the 128 x 256 tile was the larger half of its launch at ~2.5 TB/s.  Column blocks of the bf16
+    // pipeline are multiples of 8 wide (h % 8 == 0).
+    auto pass8 = [&](auto EPI) __attribute__((always_inline)) {
+      constexpr int E = decltype(EPI)::value;
+      constexpr int C8 = BN / 8;
+      constexpr int ITEMS8 = 16 * WM * C8;
+      constexpr int NIT8 = (ITEMS8 + NTHR - 1) / NTHR;
+      constexpr int CH = 2;
+      struct F8 { float4 a, b; };
+      auto ld8 = [&](const float* p, size_t o, bool bf) __attribute__((always_inline)) {
+        F8 r;
+        if (bf) {
+          const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p) + o);
+          r.a = make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                            __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+          r.b = make_float4(__builtin_bit_cast(float, u.z << 16), __builtin_bit_cast(float, u.z & 0xffff0000u),
+                            __builtin_bit_cast(float, u.w << 16), __builtin_bit_cast(float, u.w & 0xffff0000u));
+        } else {
+          r.a = *reinterpret_cast<const float4*>(p + o);
+          r.b = *reinterpret_cast<const float4*>(p + o + 4);
+        }
+        return r;
+      };
+      auto st8 = [&](float* p, size_t o, const float4 a, const float4 b, bool bf) __attribute__((always_inline)) {
+        if (bf) {
+          *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p) + o) =
+              make_uint4(nt_pack_bf16(a.x, a.y), nt_pack_bf16(a.z, a.w), nt_pack_bf16(b.x, b.y), nt_pack_bf16(b.z, b.w));
+        } else {
+          *reinterpret_cast<float4*>(p + o) = a;
+          *reinterpret_cast<float4*>(p + o + 4) = b;
+        }
+      };
+      auto sig4 = [](const float4 v) __attribute__((always_inline)) { return make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w)); };
+      auto tanh4 = [](const float4 v) __attribute__((always_inline)) { return make_float4(tanhf_(v.x), tanhf_(v.y), tanhf_(v.z), tanhf_(v.w)); };
+      auto mul4 = [](const float4 a, const float4 b) __attribute__((always_inline)) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); };
+      auto add4 = [](const float4 a, const float4 b) __attribute__((always_inline)) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+      auto mix4 = [](const float4 h, const float4 z, const float4 x) __attribute__((always_inline)) {      // h z + x (1 - z)
+        return make_float4(h.x * z.x + x.x * (1.f - z.x), h.y * z.y + x.y * (1.f - z.y), h.z * z.z + x.z * (1.f - z.z), h.w * z.w + x.w * (1.f - z.w));
+      };
+      auto drx4 = [](const float4 w, const float4 x, const float4 r) __attribute__((always_inline)) {      // w x r (1 - r)
+        return make_float4(w.x * x.x * r.x * (1.f - r.x), w.y * x.y * r.y * (1.f - r.y), w.z * x.z * r.z * (1.f - r.z), w.w * x.w * r.w * (1.f - r.w));
+      };
+#pragma unroll
+      for (int it0 = 0; it0 < NIT8; it0 += CH) {
+        F8 xa[CH], xb[CH], xc[CH];
+        auto where = [&](int j, int& row, int& col, float*& sp) __attribute__((always_inline)) {
+          const int i = tid + (it0 + j) * NTHR;
+          const int rr = i / C8, c8 = i - rr * C8;
+          row = m0 + (rr >> 4) * 16 * MI + mi * 16 + (rr & 15);
+          col = 8 * c8;
+          sp = ep + rr * EP_PITCH + col;
+          return (it0 + j < NIT8) && (ITEMS8 % NTHR == 0 || i < ITEMS8) && col < N && row < M;
+        };
+        if (E != EPI_SIGMOID_Z) {
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            int row, col; float* sp;
+            if (where(j, row, col, sp)) {
+              const size_t o = (size_t)row * ldc + col;
+              if (E == EPI_STORE) { if (accumulate) xa[j] = ld8(C, o, io & 1); }
+              else if (E == EPI_SIGMOID_R) xa[j] = ld8(in0, o, io & 4);
+              else if (E == EPI_TANH_H) { xa[j] = ld8(in0, o, io & 4); xb[j] = ld8(in1, o, io & 8); }
+              else if (E == EPI_BWD_DRX) { xa[j] = ld8(in0, o, io & 4); xb[j] = ld8(in1, o, io & 8); xc[j] = ld8(out1, o, io & 2); }
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          int row, col; float* sp;
+          if (!where(j, row, col, sp)) continue;
+          float4 wa = add4(*reinterpret_cast<const float4*>(sp), *reinterpret_cast<const float4*>(bsum + col));
+          float4 wb = add4(*reinterpret_cast<const float4*>(sp + 4), *reinterpret_cast<const float4*>(bsum + col + 4));
+          const size_t o = (size_t)row * ldc + col;
+          if (E == EPI_STORE) {
+            if (drop_mode == 3) {
+              const unsigned idx = (unsigned)row * (unsigned)drop_ld + (unsigned)(P.drop_col0 + col);
+              wa = drop4(wa, drop_seed, idx, drop_thresh, drop_scale);
+              wb = drop4(wb, drop_seed, idx + 4u, drop_thresh, drop_scale);
+            }
+            if (accumulate) { wa = add4(wa, xa[j].a); wb = add4(wb, xa[j].b); }
+            st8(C, o, wa, wb, io & 1);
+          } else if (E == EPI_SIGMOID_Z) {
+            st8(C, o, sig4(wa), sig4(wb), io & 1);
+          } else if (E == EPI_SIGMOID_R) {
+            const float4 ra = sig4(wa), rb = sig4(wb);
+            st8(C, o, ra, rb, io & 1);
+            st8(out1, o, mul4(ra, xa[j].a), mul4(rb, xa[j].b), io & 2);
+          } else if (E == EPI_TANH_H) {
+            const float4 ha = tanh4(wa), hb = tanh4(wb);
+            const float4 ya = mix4(ha, xa[j].a, xb[j].a), yb = mix4(hb, xa[j].b, xb[j].b);
+            st8(C, o, ha, hb, io & 1);
+            st8(out1, o, ya, yb, io & 2);
+            if (c32) { *reinterpret_cast<float4*>(c32 + o) = ya; *reinterpret_cast<float4*>(c32 + o + 4) = yb; }
+          } else if (E == EPI_BWD_DRX) {
+            st8(C, o, drx4(wa, xa[j].a, xb[j].a), drx4(wb, xa[j].b, xb[j].b), io & 1);
+            st8(out1, o, add4(xc[j].a, mul4(wa, xb[j].a)), add4(xc[j].b, mul4(wb, xb[j].b)), io & 2);
+          }
+        }
+      }
+    };
+    constexpr bool WIDE8 = (MODE == 2) && (BN % 8 == 0);
+    if constexpr (WIDE8) {
+      if (!rowred && epi != EPI_GATE_PRE && epi != EPI_ATT) {
+        if (epi == EPI_STORE) pass8(std::integral_constant<int, EPI_STORE>{});
+        else if (epi == EPI_SIGMOID_Z) pass8(std::integral_constant<int, EPI_SIGMOID_Z>{});
+        else if (epi == EPI_SIGMOID_R) pass8(std::integral_constant<int, EPI_SIGMOID_R>{});
+        else if (epi == EPI_TANH_H) pass8(std::integral_constant<int, EPI_TANH_H>{});
+        else if (epi == EPI_BWD_DRX) pass8(std::integral_constant<int, EPI_BWD_DRX>{});
+        return;
+      }
+    }
     if (epi == EPI_STORE) pass(std::integral_constant<int, EPI_STORE>{});
     else if (epi == EPI_SIGMOID_Z) pass(std::integral_constant<int, EPI_SIGMOID_Z>{});
     else if (epi == EPI_SIGMOID_R) pass(std::integral_constant<int, EPI_SIGMOID_R>{});
