@@ -355,17 +355,32 @@ def test_h768_bf16_gemm_mode_tracks_the_fp32_oracle():
     q, d = torch.from_numpy(inp["query"]).to(DEV), torch.from_numpy(inp["document"]).to(DEV)
     with torch.no_grad():
         phi32, (ww32, _) = model(q, d, **kargs)
+        keep32, score32 = model.ggnn_with_gsl.last_keep.clone(), model.ggnn_with_gsl.last_score.clone()
         _lib.set_gemm_mode("bf16")
         try:
             _lib.gemm_path_counters(reset=True)
             phi16, (ww16, ew16) = model(q, d, **kargs)
+            keep16, score16 = model.ggnn_with_gsl.last_keep.clone(), model.ggnn_with_gsl.last_score.clone()
         finally:
             _lib.set_gemm_mode("fp32")
         phi32b, _ = model(q, d, **kargs)
     assert torch.equal(phi32, phi32b)
+    # stated bf16 bounds per quantity (measured on MI355X: logits 9.5e-5 at scale 0.07, word weights 1.0e-3, scorer scores
+    # 1.9e-3 at scale 0.45, 12 of 180 graphs / 16 of 9690 real nodes with a different GSL keep decision)
     diff = float((phi16 - phi32).abs().max())
-    assert 1e-6 < diff <= 5e-2 * max(1.0, float(phi32.abs().max())), diff
-    assert float((ww16 - ww32).abs().max()) <= 2e-2
+    assert 1e-6 < diff <= 2e-2 * max(1.0, float(phi32.abs().max())), diff
+    assert diff <= 2e-3, diff
+    assert float((ww16 - ww32).abs().max()) <= 5e-3
+    assert float((score16 - score32).abs().max()) <= 1e-2
+    R = cfg.len_right
+    unpack = lambda k: ((k.cpu().numpy().astype(np.uint64)[:, :, None] >> np.arange(64, dtype=np.uint64)[None, None, :])
+                        & np.uint64(1)).astype(bool).reshape(k.shape[0], -1)[:, :R]
+    real = d_ids.cpu().numpy() > 0
+    mism = (unpack(keep32) != unpack(keep16)) & real
+    graphs_off, nodes_off = int(mism.any(1).sum()), int(mism.sum())
+    print(f"bf16 vs fp32: logits {diff:.2e}, GSL keep decisions differ in {graphs_off} of {mism.shape[0]} graphs "
+          f"({nodes_off} of {int(real.sum())} real nodes)")
+    assert nodes_off <= 0.005 * real.sum() and graphs_off <= 0.15 * mism.shape[0]
     assert torch.allclose(ww16.sum(1), torch.ones_like(ww16.sum(1)), atol=1e-5)
     assert torch.allclose(ew16.sum(1), torch.ones_like(ew16.sum(1)), atol=1e-5)
     # training step in both modes: every live gradient of the bf16 storage pipeline stays within 6e-2 of the fp32 one
