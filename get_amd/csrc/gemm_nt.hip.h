@@ -82,7 +82,7 @@ gemm_nt_kernel(const Launch L_byval) {
   // newest tile's DMA as well).  73.5 KB of LDS -> dynamic allocation.
   // (fp32x3, MODE 3, measured with three stages as well: slower -- 122 vs 132 TF at K = 1200 -- its K loop is bound by the
   // VALU work of the in-register splits, not by DMA latency)
-  constexpr int NST = (MI == 4) ? 3 : 2;
+  constexpr int NST = (MI == 4 && WM == 4) ? 4 : (MI == 4) ? 3 : 2;      // (256 x 256 / 8 waves: one workgroup per CU, four stages)
   constexpr int SMEM = NST * STAGE > EP_BYTES ? NST * STAGE : EP_BYTES;
   constexpr unsigned OOB = 0x80000000u;
   constexpr int NH = NI / 2;                                       // B fragment batches: X = tiles [0,NH), Y = [NH,NI)
@@ -342,17 +342,26 @@ gemm_nt_kernel(const Launch L_byval) {
   // ---- main loop: 2 LDS stages, one barrier per K tile.  Instantiated for the common tile counts so that the MFMA
   //      stream is branch-free: every column tile valid / the last one of the Y batch all padding (N = 300).
   auto run = [&](auto CX, auto CY) __attribute__((always_inline)) {
-    if constexpr (NST == 3) {
-      static_assert(SA * NW == NAI && SB * NW == NBI && SA + SB == 6, "vmcnt(6) below = the DMA instructions of one K tile per wave");
-      dma_tile(0, 0);
-      if (T > 1) dma_tile(1, 1);
-      if (T > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NST >= 3) {
+      // NST stages, DMA prefetch distance NST - 1.  vmcnt counts DMA instructions: VM per K tile and wave, so "at most n
+      // tiles still in flight" is vmcnt(n * VM); the barriers are bare (a __syncthreads() would drain the newest tiles too).
+      static_assert(SA * NW == NAI && SB * NW == NBI && (SA + SB == 6 || SA + SB == 4) && NST <= 4, "vmcnt immediates below");
+      constexpr int VM = SA + SB;
+      auto wait_inflight = [&](int n) __attribute__((always_inline)) {      // n = tiles allowed to stay in flight (0..2)
+        if (n >= 2) { if constexpr (VM == 6) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
+        else if (n == 1) { if constexpr (VM == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      };
+#pragma unroll
+      for (int i = 0; i < NST - 1; ++i)
+        if (i < T) dma_tile(i, i);
+      wait_inflight(min(T, NST - 1) - 1);            // tile 0 landed
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       int st = 0;
       for (int t = 0; t < T; ++t) {
-        const int st2 = st == 0 ? 2 : st - 1;            // (st + 2) % 3: the stage tile t-1 was read from, free since the last barrier
-        if (t + 2 < T) dma_tile(t + 2, st2);
+        const int stn = st == 0 ? NST - 1 : st - 1;      // the stage tile t-1 was read from, free since the last barrier
+        if (t + NST - 1 < T) dma_tile(t + NST - 1, stn);
         read_a(st, aC);
         read_b(st, bX, 0, NH);
         __builtin_amdgcn_sched_barrier(0);
@@ -365,11 +374,11 @@ gemm_nt_kernel(const Launch L_byval) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) aP[mi] = aC[mi];
-        // tile t+1 landed (the newest tile may stay in flight), this wave's LDS reads of tile t are done
-        if (t + 2 < T) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // tile t+1 landed (newer tiles may stay in flight), this wave's LDS reads of tile t are done
+        wait_inflight(min(T - 1, t + NST - 1) - (t + 1));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        st = st == 2 ? 0 : st + 1;
+        st = st == NST - 1 ? 0 : st + 1;
       }
       mma(aP, bY, NH, CY);
       __syncthreads();

@@ -109,6 +109,13 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
       if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 2, 8, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); attr = true; }
       hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 8, 4, 2>), dim3(grid), dim3(256), kLds, s, L);
       launched = true;
+    } else if constexpr (WM == 4 && WN == 2 && NI == 8 && MI == 4) {      // 256 x 256 tile, 8 waves (NT only)
+      if (tn) return hipErrorInvalidValue;
+      constexpr int kLds = 4 * (256 + 256) * 64;          // four K-loop stages
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<4, 2, 8, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); attr = true; }
+      hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 8, 4, 2>), dim3(grid), dim3(512), kLds, s, L);
+      launched = true;
     } else return hipErrorInvalidValue;
   } else if (MI == 4) {
     return hipErrorInvalidValue;          // the 128 x 256 tile exists for the bf16 storage pipeline only
@@ -329,6 +336,7 @@ struct Batch {
   float* g_ws = nullptr;
   size_t g_ws_bytes = 0;
   bool wide = false;      // 128 x 256 bf16 tile (launch_cfg<2, 2, 8, 4>)
+  bool wide256 = false;   // 256 x 256 bf16 tile, 8 waves (launch_cfg<4, 2, 8, 4>)
   // wide_bf16: every problem of this batch is a bf16-storage NT problem whose widths are multiples of 256 (h = 768)
   Batch(bool tn_, int rows_hint, hipStream_t s_, bool wide_bf16 = false) : tn(tn_), s(s_) {
     const Workspace w = workspace_for(s_);
@@ -341,6 +349,12 @@ struct Batch {
     static int no_wide = -1;
     if (no_wide < 0) no_wide = measure_env("GH_BF16_TILE", 0) == 320 ? 1 : 0;
     if (wide_bf16 && big && !tn_ && !no_wide) { wide = true; bm = 128; bn = 256; }
+    // 256 x 256 / 8 waves (one workgroup per CU, four LDS stages) halves the L2 -> LDS bytes per FLOP of the 128 x 256 tile.
+    // Measured on configs[4] (B = 32): 0.200 (three stages) / 0.198 (four) of the bf16 peak against 0.207 -- with one workgroup
+    // per CU nothing runs underneath its epilogue.  Kept for the tool build only (GH_BF16_TILE=256).
+    static int tile256 = -1;
+    if (tile256 < 0) tile256 = measure_env("GH_BF16_TILE", 0) == 256 ? 1 : 0;
+    if (wide && tile256 && rows_hint >= 32768) { wide256 = true; bm = 256; }
     reset();
   }
   void reset() {
@@ -469,6 +483,7 @@ struct Batch {
         return launch_cfg<1, 4, 5>(L, tn, s);
       }
     }
+    if (wide256) return launch_cfg<4, 2, 8, 4>(L, tn, s);
     if (wide) return launch_cfg<2, 2, 8, 4>(L, tn, s);
     return big ? launch_cfg<2, 2, 10>(L, tn, s) : launch_cfg<1, 4, 5>(L, tn, s);
   }
