@@ -295,7 +295,7 @@ def _prepare(model, query, document, kargs, q_adj: PackedAdj, d_adj: PackedAdj, 
 
 
 def _arena_floats(n: int) -> int:
-    """Arena sizes in coarse classes (1/16 of the next power of two, at least 4 Mi floats): the node count differs from
+    """Arena sizes in coarse classes (multiples of 1/16 of the enclosing power of two, at least 4 Mi floats: at most 1/8 above the request): the node count differs from
     batch to batch, and a caching allocator that sees a new multi-GB size every step keeps returning blocks to the driver
     and asking for new ones (measured: the first 20-step block of a B = 256 run took 3.0 s instead of 0.23 s)."""
     n = int(n)

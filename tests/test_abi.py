@@ -137,3 +137,39 @@ print('ok')
 """ % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-3000:]
+
+
+def test_composite_descriptor_mirrors_and_buffer_plan(lib_path):
+    """The ctypes mirrors in get_amd/fused.py must have the C structs' sizes (gh_get_struct_sizes), and gh_get_plan_buffers --
+    pure host arithmetic, no device call -- must lay the observables out 256-byte aligned inside an arena that grows with the
+    batch and rejects shapes the composite path does not take."""
+    import ctypes
+    from get_amd import _lib, fused
+    _lib.load()
+    sz = (ctypes.c_int64 * 4)()
+    _lib.call("gh_get_struct_sizes", ctypes.cast(sz, ctypes.c_void_p))
+    assert tuple(sz) == (ctypes.sizeof(fused.GetModel), ctypes.sizeof(fused.GetBatch), ctypes.sizeof(fused.GetPlan),
+                         ctypes.sizeof(fused.CellParams))
+
+    def plan(b, b1, m_real, h=300, d=300):
+        M, B, P = fused.GetModel(), fused.GetBatch(), fused.GetPlan()
+        M.d, M.h, M.word_heads, M.evd_heads, M.n_classes, M.article_src_dim = d, h, 5, 2, 2, 128
+        B.b, B.b1, B.l, B.r, B.n_max, B.m_real, B.k_keep = b, b1, 30, 100, 30, m_real, 60
+        if m_real >= 0:
+            B.goff = B.rowg = B.cids = B.maskf = 4096        # (only checked for being non-NULL)
+        _lib.call("gh_get_plan_buffers", ctypes.addressof(M), ctypes.addressof(B), ctypes.addressof(P))
+        return P
+
+    small, big, padded = plan(4, 40, 2600), plan(32, 960, 62128), plan(32, 960, -1)
+    for p in (small, big, padded):
+        for off in (p.phi, p.word_w, p.evd_w, p.score, p.keep):
+            assert off % 64 == 0 and 0 <= off < p.fwd_floats
+    assert small.fwd_floats < big.fwd_floats < padded.fwd_floats and small.bwd_floats < big.bwd_floats
+    assert 1.2e9 < 4 * big.fwd_floats < 2.5e9          # ~1.5 GB of saved activations at the bench shape
+    with pytest.raises(RuntimeError, match="320"):
+        plan(4, 40, 2600, h=768, d=768)
+    with pytest.raises(RuntimeError, match="m_real"):
+        plan(4, 40, 40 * 100 + 1)
+    # arena size classes: at most 1/8 above the request for large sizes
+    f = fused._arena_floats
+    assert f(1000) == 1000 and all(n <= f(n) <= n * 1.125 + 1 for n in (10 ** 8, 4 * 10 ** 8, 3 * 10 ** 9))
