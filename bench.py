@@ -136,7 +136,7 @@ class ReferenceApiBatch:
     196-223): padded (B,n,R) node ids, dense float64 (B,n,R,R) evidence adjacency and (B,L,L) claim adjacency
     (handlers/mz_sampler.py:146-160), counts, sources.  inputs() runs the compatibility shim
     (batch.kargs_from_reference_tensors: one mask gather instead of the per-claim loop); the model then packs the dense
-    adjacency on the device (PackedAdj.from_dense) and runs the reference's padded layout."""
+    adjacency on the device (PackedAdj.from_dense) and derives the node-compact plan from the ids (fused._plan_from_dense)."""
 
     def __init__(self, nb):
         from get_amd import ops
@@ -544,7 +544,7 @@ def main():
                     help="run every layer on all R padded node rows (the reference's layout) instead of the node-compact one")
     ap.add_argument("--reference-api", action="store_true",
                     help="ALSO time the path an unchanged fitter drives: dense float64 (B,n,R,R) adjacency handed over per step "
-                         "through batch.kargs_from_reference_tensors, packed on the device, padded layout (printed beside the headline)")
+                         "through batch.kargs_from_reference_tensors, packed on the device (printed beside the headline)")
     ap.add_argument("--streamed", action="store_true",
                     help="ALSO time a fresh NativeBatch per step (H2D of the ids + m_real read-back, one batch ahead on a side stream)")
     ap.add_argument("--no-side-modes", action="store_true", help="skip the --reference-api / --streamed legs the headline run adds by default")
@@ -770,7 +770,7 @@ def main():
                                       "bytes_handed_over_per_step": hb,
                                       "pairs_per_s_if_shipped_over_pcie_63GBps": wl["ref_batches"][0].b1 / (sr["ms_per_step"] * 1e-3 + hb / 63e9),
                                       "what": "dense float64 (B,n,R,R) adjacency + padded ids resident in HBM -> kargs_from_reference_tensors "
-                                              "(one mask gather) -> PackedAdj.from_dense on the device -> padded layout; same model, "
+                                              "(one mask gather) -> PackedAdj.from_dense on the device -> node-compact plan derived from the ids (one 8-byte read-back); same model, "
                                               "same optimiser step (mz_sampler.py:146-160, char_man_fitter_query_repr1.py:92-107,204-250)"}
             del wl["ref_batches"]
             torch.cuda.empty_cache()

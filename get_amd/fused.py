@@ -387,6 +387,8 @@ def forward(model, query, document, kargs):
     plan = d_adj.plan
     if plan is not None and plan.m_real <= 0:
         plan = None
+    if plan is None and AUTO_COMPACT and not isinstance(kargs[K.Evd_Docs_Adj], PackedAdj):
+        plan = _plan_from_dense(d_adj, doc)
     prep = _prepare(model, query, document, kargs, q_adj, d_adj, plan, doc)
     side = ops.side_stream(query.device) if ops.CLAIM_SIDE_STREAM else None
     # anchors: the tensors autograd tracks.  With a FlatTrainer every gradient lands in the bucket directly, so ONE
@@ -401,6 +403,30 @@ def forward(model, query, document, kargs):
     gw = model.ggnn_with_gsl
     gw.last_score, gw.last_keep = score, keep
     return phi, word_w, evd_w, plan
+
+
+# Dense adjacencies handed over through the reference API (handlers/mz_sampler.py:146-160) carry no node-compact plan, so
+# the model used to run the reference's padded layout for them: every layer on all R rows of every evidence, a third of
+# them padding nodes (0.80 instead of 0.56 GFLOP per pair).  The plan only needs the node counts, and those are in the
+# ids: convert_text zero-pads the node list behind the unique tokens (interactions.py:349).  One 8-byte read-back per
+# forward (the total m_real sizes the launches) -- the fitter that hands over dense tensors synchronises after every step
+# anyway (loss.item(), char_man_fitter_query_repr1.py:123).  Guard: an adjacency whose padding rows are not empty (never
+# produced by the reference, but legal input) keeps the padded layout.  GET_AMD_AUTO_COMPACT=0 turns this off.
+AUTO_COMPACT = os.environ.get("GET_AMD_AUTO_COMPACT", "1") != "0"
+
+
+def _plan_from_dense(d_adj: PackedAdj, doc: torch.Tensor):
+    n, r = d_adj.n, d_adj.r
+    with torch.no_grad():
+        real = doc.reshape(n, r) >= 1
+        n_nodes = real.sum(1, dtype=torch.int32)
+        prefix = torch.arange(r, device=doc.device, dtype=torch.int32)[None, :] < n_nodes[:, None]
+        row_has_edges = (d_adj.bits != 0).any(-1)
+        bad = ((real != prefix) | (row_has_edges & ~real)).sum()          # ids not prefix-shaped, or a padding node with edges
+        m_real, bad = torch.stack([n_nodes.sum().to(torch.int64), bad.to(torch.int64)]).tolist()
+    if bad or m_real <= 0 or m_real >= n * r:
+        return None
+    return ops.RaggedPlan(n_nodes, _i32(doc.reshape(n, r)), int(m_real))
 
 
 class _CrossEntropy(torch.autograd.Function):

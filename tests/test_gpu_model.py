@@ -869,3 +869,45 @@ def test_native_batch_prepare_call_equals_the_separate_launches():
                 ref = ops.RaggedPlan(dn, d2, nb.m_real)
                 for f in ("goff", "rowg", "src", "cids", "maskf"):
                     assert torch.equal(getattr(plan, f), getattr(ref, f)), f
+
+
+def test_dense_hand_over_is_compacted_and_guarded(monkeypatch):
+    """fused._plan_from_dense: a dense adjacency from the reference API gets the node-compact plan from its ids (same
+    results as the padded layout, to summation-order noise); an adjacency whose PADDING rows carry edges -- legal input the
+    reference never produces -- must keep the padded layout, and then equals the module-by-module path exactly as before."""
+    from get_amd import fused
+    cfg, seed = MODEL_CASES["small"]
+    seen = []
+    orig = fused._plan_from_dense
+    monkeypatch.setattr(fused, "_plan_from_dense", lambda a, d: (seen.append(orig(a, d)), seen[-1])[1])
+    out = {}
+    for auto in (False, True):
+        monkeypatch.setattr(fused, "AUTO_COMPACT", auto)
+        cfg_, model, inp, phi, ww, ew, loss = run_case("small", native_graphs=False)
+        loss.backward()
+        out[auto] = (phi.detach().clone(), ww.detach().clone(), model.ggnn_with_gsl.last_keep.clone(),
+                     {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert len(seen) == 1 and seen[0] is not None and 0 < seen[0].m_real < inp["doc_ids"].size
+    assert torch.equal(out[False][2], out[True][2])
+    assert float((out[False][0] - out[True][0]).abs().max()) <= 2e-6 and float((out[False][1] - out[True][1]).abs().max()) <= 2e-6
+    for k, g in out[False][3].items():
+        assert float((g - out[True][3][k]).abs().max()) <= 2e-5 * max(float(g.abs().max()), 1e-8), k
+    # guard: give one padding node of one evidence graph a self-loop
+    model = build_model(cfg, seed)
+    raw = make_raw_batch(cfg, seed)
+    inp = assemble_inputs(raw, cfg, O.convert_text)
+    adj = inp["doc_adj"].copy()
+    g0 = 0
+    pad = int((inp["doc_ids"][g0] >= 1).sum())
+    assert pad < adj.shape[1]
+    adj[g0, pad, pad] = 0.5
+    inp2 = dict(inp, doc_adj=adj)
+    kargs = to_dev(reference_kargs(inp2, torch, output_ranking=False))
+    q, d = torch.from_numpy(inp["query"]).to(DEV), torch.from_numpy(inp["document"]).to(DEV)
+    seen.clear()
+    with torch.no_grad():
+        phi_c = model(q, d, **kargs)
+        assert seen == [None], "a padding node with an edge must keep the padded layout"
+        monkeypatch.setattr(fused, "ENABLED", False)
+        phi_m = model(q, d, **kargs)
+    assert float((phi_c - phi_m).abs().max()) <= 2e-6
