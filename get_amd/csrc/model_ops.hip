@@ -47,6 +47,7 @@ static int make_dims(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d) {
   GH_REQUIRE(d.D % 4 == 0 && d.H % 4 == 0 && d.D >= 4 && d.D <= d.H && d.H <= 320,
              "get: the composite path needs float4-shaped widths with d <= h <= 320 (d=%d h=%d); use the per-module entry points", d.D, d.H);
   GH_REQUIRE(d.hw >= 1 && d.hw <= 8 && d.he >= 1 && d.he <= 8, "get: heads %d / %d not in [1,8]", d.hw, d.he);
+  GH_REQUIRE(Ba->k_keep >= 0 && Ba->k_keep <= d.R, "get: k_keep=%d not in [0, r=%d]", Ba->k_keep, d.R);
   GH_REQUIRE(d.C >= 1 && d.cs >= 0 && d.as >= 0 && d.cs % 4 == 0 && d.as % 4 == 0, "get: bad class / source widths (%d, %d, %d)", d.C, d.cs, d.as);
   d.Xl = d.H + d.cs; d.Xa = d.H * d.hw; d.Dre = d.Xa + d.as; d.E = d.Xl + d.Dre * d.he; d.W = words_for(d.R);
   d.compact = Ba->m_real >= 0;
@@ -273,6 +274,11 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
   Dims d; FwdBuf f; BwdBuf w;
   GH_TRY(layout(Mo, Ba, d, f, w));
   GH_REQUIRE(A && (reinterpret_cast<uintptr_t>(A) & 255) == 0, "get_forward: the arena must be 256-byte aligned");
+  GH_REQUIRE(Ba->q_ids && Ba->q_lens && Ba->q_bits && (Ba->q_dinv || Ba->q_vals) && Ba->d_ids && Ba->d_bits && (Ba->d_dinv || Ba->d_vals) &&
+             Ba->counts && Ba->document, "get_forward: a batch tensor is missing (ids, lens, packed graphs, counts, document)");
+  GH_REQUIRE(Ba->q_lens_kind >= 0 && Ba->q_lens_kind <= 2, "get_forward: q_lens_kind %d not in {0,1,2}", Ba->q_lens_kind);
+  GH_REQUIRE(d.as == 0 || Ba->doc_sources, "get_forward: article-source ids are missing");
+  GH_REQUIRE(d.cs == 0 || Ba->query_sources, "get_forward: claim-source ids are missing");
   GH_REQUIRE(Mo->embedding && Mo->scorer_w && Mo->scorer_gate && Mo->out0_w && Mo->out1_w, "get_forward: missing model tensors");
   GH_REQUIRE((d.cs == 0) == (Mo->claim_src_table == nullptr) && (d.as == 0) == (Mo->article_src_table == nullptr),
              "get_forward: source tables and their widths must come together");
