@@ -535,8 +535,9 @@ def main():
     ap.add_argument("--window", type=int, default=3, help="gnn_window")
     ap.add_argument("--gsl-rate", type=float, default=0.6)
     ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the step loop rotates through")
-    ap.add_argument("--gemm-mode", choices=["fp32", "bf16"], default="fp32",
-                    help="bf16: opt-in bf16 MFMA path (configs[4]); the headline metric is fp32")
+    ap.add_argument("--gemm-mode", choices=["fp32", "bf16", "fp32x3", "fp32x3p"], default="fp32",
+                    help="bf16: opt-in bf16 MFMA path (configs[4]); fp32x3 / fp32x3p: opt-in fp32-accurate products from 3-way "
+                         "bf16 splits on the bf16 MFMA (p: weight pieces pre-split once per update); the headline metric is fp32")
     ap.add_argument("--eval-mode", action="store_true", help="disable dropout (parity mode)")
     ap.add_argument("--forward-only", action="store_true",
                     help="auxiliary serving measurement: evaluation-mode forward only (not the headline metric)")
@@ -665,7 +666,8 @@ def main():
             "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if args.global_batch > 0 else "weak", "vs_baseline": None,
-            "dtype": "f32" if args.gemm_mode == "fp32" else "bf16 operands / f32 accumulate in the big GEMMs, f32 elsewhere",
+            "dtype": {"fp32": "f32", "bf16": "bf16 operands / f32 accumulate in the big GEMMs, f32 elsewhere"}.get(
+                args.gemm_mode, "f32 storage and results; big NT GEMM products from 3-way bf16 splits on the bf16 MFMA (opt-in)"),
             "data": "synthetic",
             "claims_per_s": total_claims_block * value / max(float(np.median(world_pairs)), 1.0),
             "timed": summ["timed"],

@@ -58,6 +58,9 @@ SIGNATURES = {
     "gh_profile_collect": [_P, _I],
     "gh_gemm_path_counters": [_P, _I],
     "gh_set_gemm_mode": [_I],
+    "gh_weights_changed": [],
+    "gh_fp32x3_refresh": [_P],
+    "gh_fp32x3_clear": [],
     # composite entry points (get_amd/fused.py holds the ctypes mirrors of the descriptor structs)
     "gh_get_plan_buffers": [_P, _P, _P],
     "gh_get_forward": [_P, _P, _P, _P, _P],
@@ -96,7 +99,7 @@ def set_gemm_mode(mode: str):
     storage and fp32 results, every product formed on the bf16 MFMA from 3-way bf16 splits of both operands (six of the
     nine cross terms, error below one fp32 rounding of the product; csrc/gemm_nt.hip.h MODE 3)."""
     global _GEMM_MODE
-    call("gh_set_gemm_mode", {"fp32": 0, "bf16": 1, "fp32x3": 2}[mode])
+    call("gh_set_gemm_mode", {"fp32": 0, "bf16": 1, "fp32x3": 2, "fp32x3p": 3}[mode])
     _GEMM_MODE = mode
 
 

@@ -60,7 +60,7 @@ __device__ __forceinline__ unsigned nt_pack_bf16(float a, float b) {
 //         opt-in and experimental.  Upper bound with the weight pieces pre-split once per optimiser step (measured by feeding the
 //         raw fragment bits as "pieces", results invalid): 130.8 / 151.0 / 184.3 TF at K = 300 / 600 / 1200.
 template <int WM, int WN, int NI, int MI = 2, int MODE = 0>
-__global__ void __launch_bounds__(WM * WN * 64, (MI == 4 || MODE == 3) ? 2 : 3)
+__global__ void __launch_bounds__(WM * WN * 64, (MI == 4 || MODE == 3 || MODE == 4) ? 2 : 3)
 gemm_nt_kernel(const Launch L_byval) {
   (void)L_byval;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -70,9 +70,15 @@ gemm_nt_kernel(const Launch L_byval) {
   constexpr bool BF = MODE == 1;
   constexpr int ESZ = MODE == 2 ? 2 : 4, KQ = 16 / ESZ;          // element size, elements per 16-byte chunk
   constexpr int BM = 16 * MI * WM, BN = 16 * NI * WN, BK = 4 * KQ;
-  constexpr int NAI = BM / 16, NBI = BN / 16;                      // DMA instructions per K tile (1 KiB each)
+  // MODE 4 ("fp32x3" with PRE-SPLIT weights): B points at the weight's split image (split3_kernel: per row and group
+  // of four k the three bf16 pieces hi[4] | mid[4] | lo[4], 24 bytes; row pitch a multiple of 16 bytes, passed as ldb in
+  // 4-byte units).  A K tile of B is 96 bytes per row; its LDS image has a pitch of 7 chunks = 112 bytes (the seventh chunk
+  // is never written by real data) so that the 8-byte piece reads of 16 rows x 2 k-quads fall into distinct banks.
+  constexpr bool X3P = MODE == 4;
+  constexpr int BROW = X3P ? 112 : 64;                             // bytes of one B row per K tile in LDS
+  constexpr int NAI = BM / 16, NBI = X3P ? (BN * 7 + 63) / 64 : BN / 16;   // DMA instructions per K tile (1 KiB each)
   constexpr int SA = (NAI + NW - 1) / NW, SB = (NBI + NW - 1) / NW; // ... per wave
-  constexpr int STAGE = (BM + BN) * 64;
+  constexpr int STAGE = BM * 64 + BN * BROW;
   constexpr int EP_PITCH = BN + 4;                                 // floats: 16-byte rows, 8 consecutive rows cover all banks
   constexpr int EP_BYTES = 16 * WM * EP_PITCH * 4 + NW * 64 * 16 + BN * 4;  // staged rows + row-reduction partials + bias
   // K-loop LDS stages.  fp32: a K tile is ~2560 MFMA cycles per wave (~1 us), about one DMA round trip, so two stages
@@ -83,13 +89,14 @@ gemm_nt_kernel(const Launch L_byval) {
   // (fp32x3, MODE 3, measured with three stages as well: slower -- 122 vs 132 TF at K = 1200 -- its K loop is bound by the
   // VALU work of the in-register splits, not by DMA latency)
   constexpr int NST = (MI == 4 && WM == 4) ? 4 : (MI == 4) ? 3 : 2;      // (256 x 256 / 8 waves: one workgroup per CU, four stages)
+  constexpr bool DYN_LDS = NST != 2 || X3P;                              // more than 64 KB: dynamic allocation
   constexpr int SMEM = NST * STAGE > EP_BYTES ? NST * STAGE : EP_BYTES;
   constexpr unsigned OOB = 0x80000000u;
   constexpr int NH = NI / 2;                                       // B fragment batches: X = tiles [0,NH), Y = [NH,NI)
   static_assert(MI == 2 || (MI == 4 && MODE == 2), "two 16-row tiles per wave (four in the 128 x 256 bf16 configuration)");
   extern __shared__ __attribute__((aligned(16))) unsigned char nt_dyn_smem[];
-  __shared__ __attribute__((aligned(16))) unsigned char nt_static_smem[NST == 2 ? SMEM : 16];
-  unsigned char* const smem = NST == 2 ? nt_static_smem : nt_dyn_smem;
+  __shared__ __attribute__((aligned(16))) unsigned char nt_static_smem[DYN_LDS ? 16 : SMEM];
+  unsigned char* const smem = DYN_LDS ? nt_dyn_smem : nt_static_smem;
 
   // ---- XCD-aware work decode (as gemm.hip.h): the problems of one row tile run back to back on one XCD
   const int n_inner = L.nprob * L.ksplit;
@@ -165,10 +172,18 @@ gemm_nt_kernel(const Launch L_byval) {
 #pragma unroll
   for (int j = 0; j < SB; ++j) {
     const int ib = wave + NW * j;
-    const int n = 16 * ib + drow;
-    const bool ok = (NW * (j + 1) <= NBI || ib < NBI) && n < N;
-    b_vo0[j] = ok ? (unsigned)n * (unsigned)ldb0 * (unsigned)ESZ + (unsigned)dkq * 16u : OOB;
-    b_vo1[j] = ok ? (unsigned)n * (unsigned)ldb1 * (unsigned)ESZ + (unsigned)dkq * 16u : OOB;
+    if constexpr (X3P) {      // linear chunk c = (row c / 7, slot c % 7); slot 6 is the pitch padding
+      const int c = ib * 64 + lane;
+      const int n = c / 7, sl = c - 7 * n;
+      const bool ok = (NW * (j + 1) <= NBI || ib < NBI) && n < N && n < BN && sl < 6;
+      b_vo0[j] = ok ? (unsigned)n * (unsigned)ldb0 * 4u + (unsigned)sl * 16u : OOB;
+      b_vo1[j] = ok ? (unsigned)n * (unsigned)ldb1 * 4u + (unsigned)sl * 16u : OOB;
+    } else {
+      const int n = 16 * ib + drow;
+      const bool ok = (NW * (j + 1) <= NBI || ib < NBI) && n < N;
+      b_vo0[j] = ok ? (unsigned)n * (unsigned)ldb0 * (unsigned)ESZ + (unsigned)dkq * 16u : OOB;
+      b_vo1[j] = ok ? (unsigned)n * (unsigned)ldb1 * (unsigned)ESZ + (unsigned)dkq * 16u : OOB;
+    }
   }
 
   const int drop_mode = P.drop_mode;
@@ -199,9 +214,14 @@ gemm_nt_kernel(const Launch L_byval) {
 #pragma unroll
     for (int j = 0; j < SB; ++j) {
       const int ib = wave + NW * j;
-      if (NW * (j + 1) <= NBI || ib < NBI)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sb + BM * 64 + ib * 1024), 16,
-                                                 kok ? (s1 ? b_vo1[j] : b_vo0[j]) : OOB, k0 * ESZ, 0, 0);
+      if (NW * (j + 1) <= NBI || ib < NBI) {
+        if constexpr (X3P)      // 6 bytes of split image per k; k beyond the segment's K meets zero A fragments (kok above)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sb + BM * 64 + ib * 1024), 16,
+                                                   s1 ? b_vo1[j] : b_vo0[j], k0 * 6, 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (__attribute__((address_space(3))) void*)(sb + BM * 64 + ib * 1024), 16,
+                                                   kok ? (s1 ? b_vo1[j] : b_vo0[j]) : OOB, k0 * ESZ, 0, 0);
+      }
     }
   };
 
@@ -342,6 +362,107 @@ gemm_nt_kernel(const Launch L_byval) {
   // ---- main loop: 2 LDS stages, one barrier per K tile.  Instantiated for the common tile counts so that the MFMA
   //      stream is branch-free: every column tile valid / the last one of the Y batch all padding (N = 300).
   auto run = [&](auto CX, auto CY) __attribute__((always_inline)) {
+    if constexpr (X3P) {
+      // pre-split weights: the A fragments (8 floats per lane and K tile) are split in registers, the B pieces come out of LDS
+      // as 8-byte reads; per 16 x 16 x 16 product three v_mfma_f32_16x16x32_bf16, each carrying two of the six terms.
+      // The B reads are inline assembly with hand-placed lgkmcnt waits: the compiler puts s_waitcnt vmcnt(0) in front of
+      // merged ds_read2_b64 reads that follow an LDS-DMA instruction (it cannot see that they touch the other stage), which
+      // would serialise every K tile behind the prefetch of the next one.
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      constexpr int NX = decltype(CX)::value, NY = decltype(CY)::value;
+      static_assert(NX <= 5 && NY <= 5, "wait_b below names five column tiles");
+      const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+      const unsigned b3_fo = lds0 + (unsigned)(BM * 64) + (unsigned)(wcol + l15) * 112u + (unsigned)q * 24u;
+      auto split = [](const f32x4 v, unsigned* hi, unsigned* mid, unsigned* lo) __attribute__((always_inline)) {
+        hi[0] = nt_pack_bf16(v[0], v[1]); hi[1] = nt_pack_bf16(v[2], v[3]);
+        const float r0 = v[0] - __builtin_bit_cast(float, hi[0] << 16), r1 = v[1] - __builtin_bit_cast(float, hi[0] & 0xffff0000u);
+        const float r2 = v[2] - __builtin_bit_cast(float, hi[1] << 16), r3 = v[3] - __builtin_bit_cast(float, hi[1] & 0xffff0000u);
+        mid[0] = nt_pack_bf16(r0, r1); mid[1] = nt_pack_bf16(r2, r3);
+        const float q0 = r0 - __builtin_bit_cast(float, mid[0] << 16), q1 = r1 - __builtin_bit_cast(float, mid[0] & 0xffff0000u);
+        const float q2 = r2 - __builtin_bit_cast(float, mid[1] << 16), q3 = r3 - __builtin_bit_cast(float, mid[1] & 0xffff0000u);
+        lo[0] = nt_pack_bf16(q0, q1); lo[1] = nt_pack_bf16(q2, q3);
+      };
+      auto cat = [](const u32x2 x, const u32x2 y) __attribute__((always_inline)) {
+        const u32x4 u = {x[0], x[1], y[0], y[1]};
+        return __builtin_bit_cast(bf16x8, u);
+      };
+      struct Pieces { u32x2 h, m, l; };
+      Pieces bx[5], by[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) { bx[i].h = bx[i].m = bx[i].l = u32x2{0u, 0u}; by[i] = bx[i]; }
+      // pieces of `cnt` column tiles starting at tile ni0 of stage st (at most 15 reads in flight: lgkmcnt is a 4-bit counter)
+      auto issue_b = [&](int st, Pieces* b, auto NI0, auto CNT) __attribute__((always_inline)) {
+        constexpr int ni0 = decltype(NI0)::value, cnt = decltype(CNT)::value;
+        const unsigned addr = b3_fo + (unsigned)(st * STAGE);
+#pragma unroll
+        for (int i = 0; i < cnt; ++i) {
+          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b[i].h) : "v"(addr), "n"((ni0 + i) * (16 * 112)));
+          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b[i].m) : "v"(addr), "n"((ni0 + i) * (16 * 112) + 8));
+          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b[i].l) : "v"(addr), "n"((ni0 + i) * (16 * 112) + 16));
+        }
+      };
+      // every consumer of the pieces depends on this statement, so none can be scheduled above the wait
+      auto wait_b = [](Pieces* b) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(b[0].h), "+v"(b[0].m), "+v"(b[0].l), "+v"(b[1].h), "+v"(b[1].m), "+v"(b[1].l), "+v"(b[2].h), "+v"(b[2].m),
+                       "+v"(b[2].l), "+v"(b[3].h), "+v"(b[3].m), "+v"(b[3].l), "+v"(b[4].h), "+v"(b[4].m), "+v"(b[4].l)
+                     :: "memory");
+      };
+      struct APieces { bf16x8 hm, lh, mh; };
+      APieces apC[MI], apP[MI];
+      auto mma_b = [&](const APieces* ap, const Pieces* b, auto NI0, auto CNT) __attribute__((always_inline)) {
+        constexpr int ni0 = decltype(NI0)::value, cnt = decltype(CNT)::value;
+#pragma unroll
+        for (int i = 0; i < cnt; ++i) {
+          const bf16x8 b_hh = cat(b[i].h, b[i].h), b_hm = cat(b[i].h, b[i].m), b_ml = cat(b[i].m, b[i].l);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[mi][ni0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hh, ap[mi].hm, acc[mi][ni0 + i], 0, 0, 0);   // ah.bh + am.bh
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[mi][ni0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hm, ap[mi].lh, acc[mi][ni0 + i], 0, 0, 0);   // al.bh + ah.bm
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            acc[mi][ni0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_ml, ap[mi].mh, acc[mi][ni0 + i], 0, 0, 0);   // am.bm + ah.bl
+        }
+      };
+      constexpr std::integral_constant<int, 0> I0{};
+      constexpr std::integral_constant<int, NH> IH{};
+      dma_tile(0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      for (int t = 0; t < T; ++t) {
+        const int st = t & 1;
+        if (t + 1 < T) dma_tile(t + 1, st ^ 1);
+        read_a(st, aC);
+        issue_b(st, bx, I0, CX);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t > 0) mma_b(apP, by, IH, CY);          // second half of tile t-1 covers the latency of the reads above
+        if (drop_mode == 1) drop_a(t, aC);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          unsigned h[2], m[2], l[2];
+          split(aC[mi], h, m, l);
+          const u32x2 H = {h[0], h[1]}, Mm = {m[0], m[1]}, Lo = {l[0], l[1]};
+          apC[mi].hm = cat(H, Mm); apC[mi].lh = cat(Lo, H); apC[mi].mh = cat(Mm, H);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wait_b(bx);
+        issue_b(st, by, IH, CY);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_b(apC, bx, I0, CX);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) apP[mi] = apC[mi];
+        wait_b(by);                                  // this wave's reads of stage st are done before the barrier frees it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      mma_b(apP, by, IH, CY);
+      return;
+    }
     if constexpr (NST >= 3) {
       // NST stages, DMA prefetch distance NST - 1.  vmcnt counts DMA instructions: VM per K tile and wave, so "at most n
       // tiles still in flight" is vmcnt(n * VM); the barriers are bare (a __syncthreads() would drain the newest tiles too).

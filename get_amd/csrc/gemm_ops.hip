@@ -54,7 +54,10 @@ static bool wants_dropout(const Launch& L) {
 // kernel is the correctness net for odd shapes and unaligned operands; a LARGE GEMM landing on it is a performance
 // bug upstream (e.g. a misaligned parameter view), which tests assert against through gh_gemm_path_counters.
 static long long g_path_counts[3] = {0, 0, 0};
-static int g_gemm_mode = 0;       // 0: fp32 MFMA everywhere (default); 1: bf16 MFMA in the big-tile NT/NN GEMMs; 2: fp32x3 (gh_set_gemm_mode)
+static int g_gemm_mode = 0;       // 0: fp32 MFMA everywhere (default); 1: bf16 MFMA in the big-tile NT/NN GEMMs; 2: fp32x3; 3: fp32x3 with pre-split weights (gh_set_gemm_mode)
+// mode 3: replaces the B operands (weights) of an NT launch by their pre-split images (registry below); false = not every
+// operand could be served, the launch runs the in-register split (MODE 3) instead
+static bool x3p_substitute(Launch& L, hipStream_t s);
 
 template <int WM, int WN, int NI, int MI = 2>
 static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
@@ -124,8 +127,17 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
     if (g_gemm_mode == 1 && WM == 2 && WN == 2 && NI == 10) {
       if constexpr (WM == 2 && WN == 2 && NI == 10)
         hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 10, 2, true>), dim3(grid), dim3(256), 0, s, L);
-    } else if (g_gemm_mode == 2) {      // fp32x3 (experimental): fp32 values and results, products from 3-way bf16 splits on the bf16 MFMA
-      hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, NI, 2, 3>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
+    } else if (g_gemm_mode == 2 || g_gemm_mode == 3) {      // fp32x3 (experimental): fp32 values and results, products from 3-way bf16 splits on the bf16 MFMA
+      Launch L2;
+      bool pre = false;
+      if (g_gemm_mode == 3) { L2 = L; pre = x3p_substitute(L2, s); }
+      if (pre) {
+        constexpr int kLds = 2 * (16 * 2 * WM * 64 + 16 * NI * WN * 112);      // two K-loop stages, B rows at the 112-byte pitch
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<WM, WN, NI, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); attr = true; }
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, NI, 2, 4>), dim3(grid), dim3(WM * WN * 64), kLds, s, L2);
+      } else
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, NI, 2, 3>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
     } else
       hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, NI, 2>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
     launched = true;
@@ -151,7 +163,102 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
 }  // namespace gh
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 namespace gh {
+// ---- fp32x3 with pre-split weights (gh_set_gemm_mode(3)) ---------------------------------------------
+// Image of a weight view B[N][ldb] (K columns used): per row ceil(K / 16) K tiles of 96 bytes, each four groups of
+// {hi[4], mid[4], lo[4]} bf16 -- the three pieces of four consecutive k (zeros beyond K).  gemm_nt_kernel MODE 4 DMAs a
+// K tile of a row as six 16-byte chunks.  Images are made on first use (on the launching stream), re-made in one batched
+// launch by gh_fp32x3_refresh after the optimiser step, and individually when found stale (gh_weights_changed without
+// a refresh: correct, slow).
+struct X3Item { const float* src; unsigned char* dst; int N, ldb, K, pitch; };
+constexpr int X3_BATCH = 64;
+struct X3Args { int n; X3Item it[X3_BATCH]; };
+__global__ void __launch_bounds__(256) split3_kernel(const X3Args a) {
+  const X3Item& it = a.it[blockIdx.y];
+  const int G = it.pitch / 24;
+  const long long total = (long long)it.N * G;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int row = (int)(idx / G), g = (int)(idx - (long long)row * G);
+    const float* src = it.src + (size_t)row * it.ldb + 4 * g;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (4 * g + e < it.K) ? src[e] : 0.f;
+    unsigned hi[2], mid[2], lo[2];
+    hi[0] = nt_pack_bf16(v[0], v[1]); hi[1] = nt_pack_bf16(v[2], v[3]);
+    const float r0 = v[0] - __builtin_bit_cast(float, hi[0] << 16), r1 = v[1] - __builtin_bit_cast(float, hi[0] & 0xffff0000u);
+    const float r2 = v[2] - __builtin_bit_cast(float, hi[1] << 16), r3 = v[3] - __builtin_bit_cast(float, hi[1] & 0xffff0000u);
+    mid[0] = nt_pack_bf16(r0, r1); mid[1] = nt_pack_bf16(r2, r3);
+    const float q0 = r0 - __builtin_bit_cast(float, mid[0] << 16), q1 = r1 - __builtin_bit_cast(float, mid[0] & 0xffff0000u);
+    const float q2 = r2 - __builtin_bit_cast(float, mid[1] << 16), q3 = r3 - __builtin_bit_cast(float, mid[1] & 0xffff0000u);
+    lo[0] = nt_pack_bf16(q0, q1); lo[1] = nt_pack_bf16(q2, q3);
+    uint2* dst = reinterpret_cast<uint2*>(it.dst + (size_t)row * it.pitch + (size_t)g * 24);
+    dst[0] = make_uint2(hi[0], hi[1]); dst[1] = make_uint2(mid[0], mid[1]); dst[2] = make_uint2(lo[0], lo[1]);
+  }
+}
+struct X3Key {
+  const void* b; int ldb, K, N;
+  bool operator==(const X3Key& o) const { return b == o.b && ldb == o.ldb && K == o.K && N == o.N; }
+};
+struct X3Hash {
+  size_t operator()(const X3Key& k) const {
+    size_t h = std::hash<const void*>()(k.b);
+    h ^= std::hash<long long>()(((long long)k.ldb << 40) ^ ((long long)k.K << 20) ^ (long long)k.N) + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+    return h;
+  }
+};
+struct X3Ent { unsigned char* img; int pitch; long long epoch; };
+static std::mutex g_x3_mu;
+static std::unordered_map<X3Key, X3Ent, X3Hash> g_x3;
+static long long g_x3_epoch = 0;
+
+static void x3p_split(const X3Item* items, int n, hipStream_t s) {
+  for (int i0 = 0; i0 < n; i0 += X3_BATCH) {
+    X3Args a;
+    a.n = n - i0 < X3_BATCH ? n - i0 : X3_BATCH;
+    long long mx = 0;
+    for (int i = 0; i < a.n; ++i) {
+      a.it[i] = items[i0 + i];
+      const long long t = (long long)a.it[i].N * (a.it[i].pitch / 24);
+      if (t > mx) mx = t;
+    }
+    int gx = (int)((mx + 255) / 256);
+    if (gx > 256) gx = 256;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(split3_kernel, dim3(gx, a.n), dim3(256), 0, s, a);
+  }
+}
+
+static bool x3p_substitute(Launch& L, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_x3_mu);
+  X3Item todo[2 * GH_MAX_PROBLEMS];
+  int nt = 0;
+  for (int i = 0; i < L.nprob; ++i) {
+    Problem& q = L.p[i];
+    if (q.elt) return false;
+    for (int j = 0; j < q.nseg; ++j) {
+      Seg& g = q.seg[j];
+      if (g.K <= 0 || g.gatherB) return false;
+      const X3Key key{g.B, g.ldb, g.K, q.N};
+      auto f = g_x3.find(key);
+      if (f == g_x3.end()) {
+        X3Ent e;
+        e.pitch = ((g.K + 15) / 16) * 96;
+        e.epoch = -1;
+        if (hipMalloc((void**)&e.img, (size_t)q.N * e.pitch + 256) != hipSuccess) { (void)hipGetLastError(); return false; }
+        f = g_x3.emplace(key, e).first;
+      }
+      if (f->second.epoch != g_x3_epoch) {
+        todo[nt++] = X3Item{g.B, f->second.img, q.N, g.ldb, g.K, f->second.pitch};
+        f->second.epoch = g_x3_epoch;
+      }
+      g.B = reinterpret_cast<const float*>(f->second.img);
+      g.ldb = f->second.pitch / 4;
+    }
+  }
+  if (nt > 0) x3p_split(todo, nt, s);
+  return true;
+}
 static std::mutex g_ws_mu;
 static Workspace g_ws_default = {nullptr, 0, nullptr, 0};
 // keyed by (device, stream): the default stream has handle 0 on EVERY device, so the stream alone does not identify a
@@ -423,7 +530,7 @@ struct Batch {
         need += (size_t)L.ksplit * L.p[i].M * L.p[i].N * sizeof(float);
         if (cs_out[i]) { need += (size_t)L.ksplit * L.p[i].M * sizeof(float); any_cs = true; }
       }
-      if (any_cs && !(ws_ok && need <= g_ws_bytes && fast_ok(L, true) && (g_gemm_mode == 0 || L.p[0].elt))) any_cs = false;   // caller runs the column-sum kernels
+      if (any_cs && !(ws_ok && need <= g_ws_bytes && fast_ok(L, true) && (g_gemm_mode != 1 || L.p[0].elt))) any_cs = false;   // caller runs the column-sum kernels
       if (ws_ok && need <= g_ws_bytes) {
         ReduceArgs R;
         R.n = L.nprob;
@@ -1039,8 +1146,35 @@ int gh::linear2_bwd(const float* x0, int k0, const float* x1, int k1, const floa
 }
 
 extern "C" int gh_set_gemm_mode(int mode) {
-  GH_REQUIRE(mode == 0 || mode == 1 || mode == 2, "set_gemm_mode: %d is not 0 (fp32), 1 (bf16 operands in the big NT/NN GEMMs) or 2 (fp32x3)", mode);
+  GH_REQUIRE(mode >= 0 && mode <= 3, "set_gemm_mode: %d is not 0 (fp32), 1 (bf16 operands in the big NT/NN GEMMs), 2 (fp32x3) or 3 (fp32x3, pre-split weights)", mode);
   g_gemm_mode = mode;
+  return 0;
+}
+
+extern "C" int gh_weights_changed(void) {
+  std::lock_guard<std::mutex> lk(g_x3_mu);
+  ++g_x3_epoch;
+  return 0;
+}
+
+extern "C" int gh_fp32x3_refresh(gh_stream_t stream) {
+  std::lock_guard<std::mutex> lk(g_x3_mu);
+  if (g_x3.empty()) return 0;
+  std::vector<X3Item> items;
+  items.reserve(g_x3.size());
+  for (auto& kv : g_x3) {
+    items.push_back(X3Item{(const float*)kv.first.b, kv.second.img, kv.first.N, kv.first.ldb, kv.first.K, kv.second.pitch});
+    kv.second.epoch = g_x3_epoch;
+  }
+  x3p_split(items.data(), (int)items.size(), (hipStream_t)stream);
+  GH_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gh_fp32x3_clear(void) {
+  std::lock_guard<std::mutex> lk(g_x3_mu);
+  for (auto& kv : g_x3) (void)hipFree(kv.second.img);
+  g_x3.clear();
   return 0;
 }
 

@@ -371,7 +371,7 @@ class _GetFused(torch.autograd.Function):
 
 
 def eligible(model, query, kargs) -> bool:
-    if not ENABLED or not query.is_cuda or _lib.gemm_mode() != "fp32":
+    if not ENABLED or not query.is_cuda or _lib.gemm_mode() == "bf16":
         return False
     if K.DocContentNoPaddingEvidence not in kargs or kargs[K.DocContentNoPaddingEvidence].shape[0] == 0:
         return False

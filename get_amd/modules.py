@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import _lib, ops
 from .keywords import KeyWordSettings
 from .ops import PackedAdj
 
@@ -386,6 +386,8 @@ class Graph_basedSemantiStructure(nn.Module):
         # the batch qualify (get_amd/fused.py: fp32, frozen word table, float4-shaped widths with d <= h <= 320); the
         # module-by-module path below is the general one.
         from . import fused
+        if _lib.gemm_mode() == "fp32x3p":
+            ops.fp32x3p_guard(self)
         if fused.eligible(self, query, kargs):
             phi, word_w, evd_att_weight, plan = fused.forward(self, query, document, kargs)
             if kargs.get(K.OutputRankingKey, False):

@@ -93,6 +93,8 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH += 1
     _WT_CACHE.clear()
     _DERIVED_CACHE.clear()
+    if _lib.gemm_mode() == "fp32x3p":       # the library's pre-split weight images: drop them (weights may have been replaced)
+        call("gh_fp32x3_clear")
 
 
 def _bump_trainer_epoch():
@@ -104,6 +106,24 @@ def _bump_trainer_epoch():
     _WT_CACHE.clear()
     for k in [k for k, v in _DERIVED_CACHE.items() if v[0][-1] != -1]:
         del _DERIVED_CACHE[k]
+    if _lib.gemm_mode() == "fp32x3p":       # every image stale; refresh_transposes re-makes them all in one launch
+        call("gh_weights_changed")
+
+
+_X3P_SIG: dict = {}
+
+
+def fp32x3p_guard(module):
+    """gemm mode "fp32x3p" only: the library reads the weight operand of its activation-sized GEMMs from pre-split images
+    and cannot see in-place updates by a torch optimiser.  Called at the top of the model's forward: when any parameter's
+    `_version` or address moved since the last call, every image is marked stale (re-made by the launch that meets it).
+    FlatTrainer rewrites parameters through raw pointers and tells the library itself (_bump_trainer_epoch)."""
+    sig = 0
+    for q in module.parameters():
+        sig = (sig * 1000003 + q._version * 31 + q.data_ptr()) & 0xFFFFFFFFFFFF
+    if _X3P_SIG.get(id(module)) != sig:
+        _X3P_SIG[id(module)] = sig
+        call("gh_weights_changed")
 
 
 def _direct(p) -> bool:
@@ -134,6 +154,8 @@ def transposed(w: torch.Tensor) -> torch.Tensor:
     wc = _f32(w.detach())
     wt = torch.empty((wc.shape[1], wc.shape[0]), device=w.device, dtype=torch.float32)
     call("gh_transpose", ptr(wc), ptr(wt), wc.shape[0], wc.shape[1], stream())
+    if _lib.gemm_mode() == "fp32x3p":       # a new k-major copy, possibly at a recycled address: no image of it may survive
+        call("gh_weights_changed")
     if len(_WT_CACHE) > 512:
         for k in [k for k, v in _WT_CACHE.items() if v[0]() is None]:
             del _WT_CACHE[k]
@@ -187,6 +209,8 @@ def refresh_transposes(weights):
     cols = (ctypes.c_int * n)(*[w.shape[1] for w in ws])
     cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
     call("gh_transpose_batch", n, cast(src), cast(dst), cast(rows), cast(cols), stream())
+    if _lib.gemm_mode() == "fp32x3p":
+        call("gh_fp32x3_refresh", stream())
     for w, wt in zip(ws, wts):
         _WT_CACHE[id(w)] = (weakref.ref(w), w.data_ptr(), w._version, _WEIGHT_EPOCH, wt)
 

@@ -227,6 +227,15 @@ int gh_concat_att_bwd(const float* left, const float* right, const int32_t* goff
  *    storage, epilogues, bias gradients and all small GEMMs stay fp32.  For BASELINE configs[4] ("h=768 bf16"); results then
  *    match the fp32 oracle to bf16 accuracy only (~1e-2 relative on logits). */
 int gh_set_gemm_mode(int mode);
+/* 2 ("fp32x3", opt-in): fp32 storage and results; every product of the activation-sized NT launches is formed on the bf16 MFMA
+ *    from 3-way bf16 splits of both operands (six of the nine cross terms; error below one fp32 rounding of the product).
+ * 3 ("fp32x3 with pre-split weights", opt-in): as 2, with the weight operand's pieces read from an image the library keeps
+ *    per weight view (made on first use).  The caller tells the library when weights were rewritten: gh_weights_changed()
+ *    marks every image stale (a stale image is re-made by the launch that meets it), gh_fp32x3_refresh(stream) re-makes all
+ *    of them in one launch (call it after the optimiser step), gh_fp32x3_clear() frees them (before weights are freed). */
+int gh_weights_changed(void);
+int gh_fp32x3_refresh(gh_stream_t stream);
+int gh_fp32x3_clear(void);
 
 /* ---- split-K scratch for the weight-gradient GEMMs ----
  * Caller-owned device buffer (stays registered until replaced; NULL unregisters).  With it the

@@ -911,3 +911,81 @@ def test_dense_hand_over_is_compacted_and_guarded(monkeypatch):
         monkeypatch.setattr(fused, "ENABLED", False)
         phi_m = model(q, d, **kargs)
     assert float((phi_c - phi_m).abs().max()) <= 2e-6
+
+
+# ---------------------------------------------------------------- opt-in fp32x3 modes (3-way bf16 splits on the bf16 MFMA)
+@pytest.fixture(params=["fp32x3", "fp32x3p"])
+def x3_mode(request):
+    from get_amd import _lib, ops
+    _lib.set_gemm_mode(request.param)
+    yield request.param
+    ops.bump_weight_epoch()          # (frees the pre-split images while the mode is still set)
+    _lib.set_gemm_mode("fp32")
+
+
+@pytest.mark.parametrize("m,k,n", [(9000, 300, 300), (8300, 600, 640), (8200, 76, 300)])
+def test_fp32x3_linear_is_fp32_accurate_and_follows_weight_updates(x3_mode, m, k, n):
+    """Both fp32x3 modes against a float64 product: the error is the fp32 kernel's (six of nine cross terms of the 3-way
+    bf16 splits; bound 1e-5 of the largest output, the exact-fp32 kernel measures 5e-6 on these shapes).  The pre-split
+    mode must notice rewritten weights: through ops.bump_weight_epoch (images dropped) and through the library call a
+    trainer makes (gh_weights_changed + gh_fp32x3_refresh)."""
+    from get_amd import ops
+    rng = np.random.default_rng(m + k)
+    x = torch.from_numpy(rng.standard_normal((m, k)).astype(np.float32)).to(DEV).requires_grad_(True)
+    w = torch.from_numpy((rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)).to(DEV).requires_grad_(True)
+    b = torch.from_numpy(rng.standard_normal((n,)).astype(np.float32)).to(DEV)
+    g = torch.from_numpy(rng.standard_normal((m, n)).astype(np.float32)).to(DEV)
+
+    def check():
+        x.grad = None
+        y = ops.linear(x, w, b)
+        (y * g).sum().backward()
+        ref = x.detach().double() @ w.detach().double().t() + b.double()
+        assert float((y.detach().double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+        dx = g.double() @ w.detach().double()
+        assert float((x.grad.double() - dx).abs().max()) <= 1e-5 * max(1.0, float(dx.abs().max()))
+
+    check()
+    with torch.no_grad():
+        w.mul_(-1.7)
+    ops.bump_weight_epoch()
+    check()
+    w.data.add_(0.25)                 # a raw-pointer style update: no _version bump, the trainer's calls announce it
+    ops._bump_trainer_epoch()
+    ops.refresh_transposes([w])       # (transposes first, then -- in the pre-split mode -- every image in one launch)
+    check()
+
+
+def test_fp32x3p_training_steps_track_fp32(monkeypatch):
+    """Three FlatTrainer steps of the bench-shaped model (>= 8192 node rows: the big-tile launches read pre-split weights,
+    refreshed by the trainer after every update) against the same steps in exact fp32: losses within 2e-6 relative (a stale
+    image would show as ~1e-3), parameters within 1e-4 absolute after the third update (lr 1e-3; Adam's g / sqrt(v)
+    amplifies the relative noise of near-zero gradients, so this bound is loose by construction)."""
+    from bench import build_workload
+    from get_amd import _lib, ops
+    from get_amd.dist import FlatTrainer
+    out = {}
+    for mode in ("fp32", "fp32x3p"):
+        _lib.set_gemm_mode(mode)
+        try:
+            wl = build_workload(batch=12, n_evd=30, seed=77, device=DEV)
+            model = wl["model"].train(False)
+            ops.bump_weight_epoch()
+            trainer = FlatTrainer(model, lr=1e-3, weight_decay=0.0)
+            losses = []
+            for _ in range(3):
+                trainer.zero_grad()
+                loss = ops.cross_entropy(model(wl["query"], wl["document"], **wl["kargs"]), wl["labels"])
+                loss.backward()
+                losses.append(float(loss))
+                trainer.step()
+            out[mode] = (losses, {k: p.detach().clone() for k, p in model.named_parameters()})
+        finally:
+            ops.bump_weight_epoch()
+            _lib.set_gemm_mode("fp32")
+    la, lb = out["fp32"][0], out["fp32x3p"][0]
+    assert la[0] != la[2], "the parameters did not move"
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 2e-6 * max(1.0, abs(a)), (la, lb)
+    for k, p in out["fp32"][1].items():
+        assert float((p - out["fp32x3p"][1][k]).abs().max()) <= 1e-4, k

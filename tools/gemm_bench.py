@@ -13,7 +13,7 @@ from get_amd._lib import call, ptr, stream  # noqa: E402
 
 def bench(m, k, n, reps=20, mode="fwd"):
     dev = "cuda:0"
-    if os.environ.get("GEMM_MODE") in ("bf16", "fp32x3"):
+    if os.environ.get("GEMM_MODE") in ("bf16", "fp32x3", "fp32x3p"):
         _lib.set_gemm_mode(os.environ["GEMM_MODE"])
     x = torch.randn(m, k, device=dev)
     w = torch.randn(n, k, device=dev) / k ** 0.5
