@@ -786,6 +786,22 @@ def main():
                                          "device graph build for the node count, 4-byte m_real read-back; prepared one batch ahead "
                                          "on a side stream while the previous step runs (8 distinct host batches rotated)"}
             del wl["streamed"]
+        if default_side and args.gemm_mode == "fp32":
+            # opt-in arithmetic mode, same step otherwise: fp32 storage and results, the products of the activation-sized NT
+            # GEMMs formed on the bf16 MFMA from 3-way bf16 splits with the weight pieces pre-split once per update
+            # (error against fp64 equals the exact mode's, results are not bit-identical to it)
+            _lib.set_gemm_mode("fp32x3p")
+            ops.bump_weight_epoch()
+            try:
+                mx = measure(args, wl, trainer, 1, device, dist, args.steps, 4, profile=False, min_seconds=1.0)
+                sx = summarize_blocks(mx, args.steps, mx["block_pairs"])
+                extra["fp32x3p"] = {"pairs_per_s": sx["value"], "ms_per_step": sx["ms_per_step"],
+                                    "what": "gh_set_gemm_mode(3): fp32-equivalent products from pre-split bf16 weight pieces on "
+                                            "v_mfma_f32_16x16x32_bf16 in the big-tile NT launches; weight-gradient GEMMs and all "
+                                            "small GEMMs stay on the fp32 MFMA; NOT the headline (not bit-identical to fp32 MFMA)"}
+            finally:
+                ops.bump_weight_epoch()
+                _lib.set_gemm_mode("fp32")
         out["other_regimes"] = extra
     if rank == 0:
         if world == 1 and not args.no_series and not args.forward_only and args.evd_dist == "fixed" and headline:
