@@ -210,6 +210,7 @@ struct X3Hash {
 struct X3Ent { unsigned char* img; int pitch; long long epoch; };
 static std::mutex g_x3_mu;
 static std::unordered_map<X3Key, X3Ent, X3Hash> g_x3;
+static std::unordered_multimap<size_t, unsigned char*> g_x3_pool;      // buffers of cleared images, by size (hipMalloc / hipFree are slow)
 static long long g_x3_epoch = 0;
 
 static void x3p_split(const X3Item* items, int n, hipStream_t s) {
@@ -242,10 +243,14 @@ static bool x3p_substitute(Launch& L, hipStream_t s) {
       const X3Key key{g.B, g.ldb, g.K, q.N};
       auto f = g_x3.find(key);
       if (f == g_x3.end()) {
+        if (g_x3.size() >= 512) return false;      // views keep changing address (caller never clears): stop growing, in-register split instead
         X3Ent e;
         e.pitch = ((g.K + 15) / 16) * 96;
         e.epoch = -1;
-        if (hipMalloc((void**)&e.img, (size_t)q.N * e.pitch + 256) != hipSuccess) { (void)hipGetLastError(); return false; }
+        const size_t bytes = (size_t)q.N * e.pitch + 256;
+        auto pf = g_x3_pool.find(bytes);
+        if (pf != g_x3_pool.end()) { e.img = pf->second; g_x3_pool.erase(pf); }
+        else if (hipMalloc((void**)&e.img, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
         f = g_x3.emplace(key, e).first;
       }
       if (f->second.epoch != g_x3_epoch) {
@@ -1173,8 +1178,14 @@ extern "C" int gh_fp32x3_refresh(gh_stream_t stream) {
 
 extern "C" int gh_fp32x3_clear(void) {
   std::lock_guard<std::mutex> lk(g_x3_mu);
-  for (auto& kv : g_x3) (void)hipFree(kv.second.img);
+  if (g_x3.empty()) return 0;
+  GH_CHECK_HIP(hipDeviceSynchronize());      // a launch on any stream may still read an image; the buffers go back to the pool
+  for (auto& kv : g_x3) g_x3_pool.emplace((size_t)kv.first.N * kv.second.pitch + 256, kv.second.img);
   g_x3.clear();
+  if (g_x3_pool.size() > 2048) {
+    for (auto& kv : g_x3_pool) (void)hipFree(kv.second);
+    g_x3_pool.clear();
+  }
   return 0;
 }
 

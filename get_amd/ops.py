@@ -152,10 +152,18 @@ def transposed(w: torch.Tensor) -> torch.Tensor:
         if ref() is w and dptr == w.data_ptr() and ver == w._version and epoch == _WEIGHT_EPOCH:
             return wt
     wc = _f32(w.detach())
-    wt = torch.empty((wc.shape[1], wc.shape[0]), device=w.device, dtype=torch.float32)
-    call("gh_transpose", ptr(wc), ptr(wt), wc.shape[0], wc.shape[1], stream())
-    if _lib.gemm_mode() == "fp32x3p":       # a new k-major copy, possibly at a recycled address: no image of it may survive
+    if _lib.gemm_mode() == "fp32x3p":
+        # the library keys its pre-split images by operand address: keep the k-major copy in the parameter's persistent
+        # buffer (as refresh_transposes does) so that the address stays, and mark the images stale
+        hit_p = _WT_PERSIST.get(key)
+        if hit_p is None or hit_p[0]() is not w or hit_p[1].shape != (wc.shape[1], wc.shape[0]) or hit_p[1].device != w.device:
+            hit_p = (weakref.ref(w), torch.empty((wc.shape[1], wc.shape[0]), device=w.device, dtype=torch.float32))
+            _WT_PERSIST[key] = hit_p
+        wt = hit_p[1]
         call("gh_weights_changed")
+    else:
+        wt = torch.empty((wc.shape[1], wc.shape[0]), device=w.device, dtype=torch.float32)
+    call("gh_transpose", ptr(wc), ptr(wt), wc.shape[0], wc.shape[1], stream())
     if len(_WT_CACHE) > 512:
         for k in [k for k, v in _WT_CACHE.items() if v[0]() is None]:
             del _WT_CACHE[k]

@@ -977,7 +977,7 @@ def test_fp32x3p_training_steps_track_fp32(monkeypatch):
                 trainer.zero_grad()
                 loss = ops.cross_entropy(model(wl["query"], wl["document"], **wl["kargs"]), wl["labels"])
                 loss.backward()
-                losses.append(float(loss))
+                losses.append(float(loss.detach()))
                 trainer.step()
             out[mode] = (losses, {k: p.detach().clone() for k, p in model.named_parameters()})
         finally:
@@ -989,3 +989,33 @@ def test_fp32x3p_training_steps_track_fp32(monkeypatch):
         assert abs(a - b) <= 2e-6 * max(1.0, abs(a)), (la, lb)
     for k, p in out["fp32"][1].items():
         assert float((p - out["fp32x3p"][1][k]).abs().max()) <= 1e-4, k
+
+
+def test_fp32x3p_follows_a_plain_torch_optimizer():
+    """No FlatTrainer: torch.optim.SGD rewrites the parameters in place, which the library cannot see.  The forward's
+    guard (ops.fp32x3p_guard: parameter versions) and the transposed-copy cache must mark the pre-split images stale, so
+    three steps track the exact-fp32 run (losses within 2e-6 relative; a stale image shows as ~1e-2 at this step size)."""
+    from bench import build_workload
+    from get_amd import _lib, ops
+    out = {}
+    for mode in ("fp32", "fp32x3p"):
+        _lib.set_gemm_mode(mode)
+        try:
+            wl = build_workload(batch=10, n_evd=30, seed=78, device=DEV)
+            model = wl["model"].train(False)
+            ops.bump_weight_epoch()
+            opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.05)
+            losses = []
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                loss = torch.nn.functional.cross_entropy(model(wl["query"], wl["document"], **wl["kargs"]), wl["labels"])
+                loss.backward()
+                losses.append(float(loss.detach()))
+                opt.step()
+            out[mode] = losses
+        finally:
+            ops.bump_weight_epoch()
+            _lib.set_gemm_mode("fp32")
+    assert abs(out["fp32"][0] - out["fp32"][2]) > 1e-4 * abs(out["fp32"][0]), "the parameters did not move"
+    for a, b in zip(out["fp32"], out["fp32x3p"]):
+        assert abs(a - b) <= 2e-6 * max(1.0, abs(a)), out
