@@ -23,6 +23,9 @@ timeout 600 python bench.py --len-right 200 --n-evd 10 --batch 64 --no-cpu-basel
 C4="--hidden 768 --word-heads 8 --window 5 --gsl-rate 0.8 --batch 32 --no-cpu-baseline --no-series"
 timeout 600 python bench.py $C4 --gemm-mode fp32 > $O/cfg4_fp32_bench_line.json 2>> $O/bench_err.log
 timeout 600 python bench.py $C4 --gemm-mode bf16 > $O/cfg4_bf16_bench_line.json 2>> $O/bench_err.log
+# opt-in fp32x3 with pre-split weights: bench line with its kernel table, and the isolated GEMM rates of the three arithmetic modes
+timeout 600 python bench.py --gemm-mode fp32x3p --no-cpu-baseline --no-series --no-side-modes > $O/bench_fp32x3p.json 2>> $O/bench_err.log
+for m in fp32 fp32x3 fp32x3p; do echo "== GEMM_MODE=$m"; GEMM_MODE=$m timeout 200 python tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids; done > $O/gemm_bench_modes.txt
 # N > 1 code path on the 1-GPU box: bench.py spawns its own 2 ranks (gloo, ranks share the device)
 GET_AMD_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 > $O/bench_2rank_gloo.json 2> $O/bench_2rank.err
 GET_AMD_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 --global-batch 64 --evd-dist snopes > $O/bench_2rank_gloo_gb64_snopes.json 2>> $O/bench_2rank.err

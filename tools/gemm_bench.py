@@ -15,6 +15,8 @@ def bench(m, k, n, reps=20, mode="fwd"):
     dev = "cuda:0"
     if os.environ.get("GEMM_MODE") in ("bf16", "fp32x3", "fp32x3p"):
         _lib.set_gemm_mode(os.environ["GEMM_MODE"])
+    if os.environ.get("GEMM_MODE") == "fp32x3p":      # fresh operands below, possibly at recycled addresses: no pre-split image survives
+        call("gh_weights_changed")
     x = torch.randn(m, k, device=dev)
     w = torch.randn(n, k, device=dev) / k ** 0.5
     wt = w.t().contiguous()
