@@ -586,6 +586,10 @@ gemm_nt_kernel(const Launch L_byval) {
         return;
       }
     }
+    // streaming (nontemporal) stores: an epilogue output is ~75 MB that the next launch reads from the start; keeping its
+    // tail in L2 only evicts the weight panels the K loops are re-reading (A/B on the bench step: +0.4 %; nontemporal LOADS
+    // of the epilogue inputs: no change)
+    if (!(dbg_bits & 16)) { __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p + o)); return; }
     *reinterpret_cast<float4*>(p + o) = v;
   };
   auto epilogue_pass = [&](auto MIT) __attribute__((always_inline)) {

@@ -380,11 +380,17 @@ spmm_wave_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
 // workgroup scan of the popcounts), and every thread owns CPT float4 columns of one row, so the inner loop per
 // neighbour is one 8-byte list read, one address mad and CPT x (ds_read_b128 + 4 FMA).  Graphs whose edge count
 // exceeds the list capacity (dense hand-overs) fall back to the bit walk inside the same kernel.
+#ifdef GH_MEASURE
+__device__ unsigned g_spmm_phase[8192 * 8];     // tool build: s_memtime ticks (10 ns) per phase and workgroup (thread 0)
+#define SPMM_T(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x < 8192) g_spmm_phase[blockIdx.x * 8 + i] = (unsigned)(t_ - tprev_); tprev_ = t_; } } while (0)
+#else
+#define SPMM_T(i) do { } while (0)
+#endif
 template <bool BF, int CPT>
 __global__ void __launch_bounds__(256)
 spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
                  const uint64_t* __restrict__ keep, const int32_t* __restrict__ goff, const float* __restrict__ x,
-                 float* __restrict__ y, int R, int H, int slab, int cap, int transpose, int accumulate) {
+                 float* __restrict__ y, int R, int H, int slab, int cap, int transpose, int accumulate, int n, int nslab, int split, int seq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   const int W = (R + 63) / 64;
   float4* xs = reinterpret_cast<float4*>(dsm);                                                // [R][slab] fp32 rows ...
@@ -393,14 +399,36 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
   unsigned long long* rb = reinterpret_cast<unsigned long long*>(ent);                        // [R][W] refined bit rows (fallback only; cap >= R*W)
   int* st = reinterpret_cast<int*>(ent + cap);                                                // [R + 1] row starts
   float* dv = reinterpret_cast<float*>(st + R + 1);                                           // [R]
+  uint2* itm = reinterpret_cast<uint2*>(dv + R + 1);                                          // [R] work items ((2R + 1) floats behind ent: + 1 for 8-byte alignment)
   __shared__ int wsum[4];
-  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c0 = blockIdx.y * slab;
+  __shared__ int wsum2[4];                                                                    // groups of hub rows | of mid rows << 16
+  __shared__ int ctr[2];                                                                      // extra items, scratch slots
+  // XCD-aware work decode (nslab > 0: 1-D grid).  Workgroups go round-robin over the 8 XCDs, each with its own L2: the
+  // slabs of one graph sit next to each other in ONE XCD's queue, so the 128-byte lines that straddle a slab boundary
+  // and the graph's bit rows / dinv / keep words are fetched from HBM once and hit that L2 for the sibling slabs.
+  // seq > 0: ONE workgroup per graph walks the graph's `seq` slabs one after the other -- bit rows, scan and edge list are
+  // paid once per graph instead of once per slab (measured per workgroup: ~8 us of set-up latency chain against ~5 us of
+  // data movement per slab), and 4 resident workgroups per CU hold a whole 960-graph launch in one round.
+  int g = blockIdx.x, sl = blockIdx.y;
+  if (seq > 0) {
+    if (g >= n) return;
+    sl = 0;
+  } else if (nslab > 0) {
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    sl = j % nslab;
+    g = (j / nslab) * 8 + xcd;
+    if (g >= n) return;
+  }
+#ifdef GH_MEASURE
+  unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int c0 = sl * slab;
   // exact n / d for n, d < 2^16 by one multiply-high (a runtime integer division costs ~20 VALU instructions)
   auto magic_of = [](int d) { return (unsigned)(0xFFFFFFFFu / (unsigned)d) + 1u; };
   auto fdiv = [](int n, unsigned magic) { return (int)__umulhi((unsigned)n, magic); };
   const int H4 = H / 4;
-  const int ncol = min(slab, H4 - c0);
+  int ncol = min(slab, H4 - c0);
   const int row0 = goff ? goff[g] : g * R;
   const int NR = goff ? goff[g + 1] - row0 : R;
   if (NR <= 0) return;
@@ -417,15 +445,15 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
     }
   const float dvv = vals ? 0.f : dinv[(size_t)g * R + trow];
   __builtin_amdgcn_sched_barrier(0);
-  {
-    // LDS-DMA (buffer_load_dwordx4 ... lds): the LDS image is linear in (row, column), so a wave's 64 lanes land in 1 KB of
-    // consecutive LDS; no staging registers, no ds_write.  fp32: one 16-byte chunk = one float4 column.  BF: the image
-    // stays bf16 (half the LDS, twice the slab), one chunk = two columns (the launcher keeps slabs even).
+  // LDS-DMA (buffer_load_dwordx4 ... lds): the LDS image is linear in (row, column), so a wave's 64 lanes land in 1 KB of
+  // consecutive LDS; no staging registers, no ds_write.  fp32: one 16-byte chunk = one float4 column.  BF: the image
+  // stays bf16 (half the LDS, twice the slab), one chunk = two columns (the launcher keeps slabs even).
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const char*>(x) + (size_t)row0 * H * (BF ? 2 : 4)), 0, 0x7fffffff, 0x00020000);
+  auto dma_slab = [&]() __attribute__((always_inline)) {
     const int cpr = BF ? ncol / 2 : ncol;                 // chunks per row
     const int chunks = NR * cpr;
     const unsigned mg_cpr = magic_of(cpr);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(reinterpret_cast<const char*>(x) + (size_t)row0 * H * (BF ? 2 : 4)), 0, 0x7fffffff, 0x00020000);
     for (int base = 0; base < chunks; base += 256) {
       const int it = base + tid;
       if (it < chunks) {
@@ -434,8 +462,10 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + base + wave * 64), 16, off, 0, 0, 0);
       }
     }
-  }
+  };
+  dma_slab();
   __builtin_amdgcn_sched_barrier(0);
+  SPMM_T(0);        // loads issued
   // this thread's row (tid < NR): refined words, degree
   int deg = 0;
   {
@@ -455,15 +485,21 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
     }
   }
   if (tid < R) dv[tid] = dvv;
-  // exclusive scan of deg over the 256 threads
-  int inc = deg;
+  // exclusive scan of deg over the 256 threads (and, alongside, the totals of the 8-edge groups of hub / mid-degree rows)
+  constexpr int GS = 8;
+  const int grp = (deg + GS - 1) / GS;
+  const bool hub = deg > 4 * GS, mid = deg > 2 * GS && !hub;
+  int inc = deg, inc2 = hub ? grp : (mid ? grp << 16 : 0);
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(inc, o);
-    if (lane >= o) inc += v;
+    const int v = __shfl_up(inc, o), v2 = __shfl_up(inc2, o);
+    if (lane >= o) { inc += v; inc2 += v2; }
   }
-  if (lane == 63) wsum[wave] = inc;
+  if (lane == 63) { wsum[wave] = inc; wsum2[wave] = inc2; }
+  if (tid < 2) ctr[tid] = 0;
+  SPMM_T(1);        // row words arrived, scan
   __syncthreads();
+  SPMM_T(2);        // barrier 1
   int base = 0;
 #pragma unroll
   for (int w = 0; w < 4; ++w) if (w < wave) base += wsum[w];
@@ -472,8 +508,29 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
   const bool listed = nnz <= cap;                 // workgroup-uniform
   if (tid <= R) st[tid] = (tid < NR) ? start : nnz;
   if (R >= 256 && tid == 0) st[R] = nnz;
+  // Work items.  A word graph has a few hub nodes (frequent words: degree up to ~R/2 against a mean of ~6); with one thread per
+  // (row, column group) the hub's threads run 8x longer than the rest and the workgroup waits for them.
+  // NUMERICS (every row, split or not, every layout): a row's edges are summed in groups of GS = 8 -- each group from zero
+  // in edge order, the group sums then added in group order.  SCHEDULING: a row with more than two groups may hand each
+  // group to an item of its own; the group sums then travel through scratch slots in the part of the slab image that the
+  // graph's R - NR absent rows leave unused and are added by a short second pass.  Which rows split (hubs first, then the
+  // mid-degree rows, as far as the slots reach) never changes a result bit.
+  const int spare = split ? (BF ? (R - NR) / 2 : (R - NR)) : 0;
+  const int hm = wsum2[0] + wsum2[1] + wsum2[2] + wsum2[3];
+  const bool split_hub = listed && (hm & 0xffff) > 0 && (hm & 0xffff) <= spare;
+  const bool split_mid = listed && (hm >> 16) > 0 && (hm & 0xffff) + (hm >> 16) <= spare;
   if (tid < NR) {
     if (listed) {
+      // item tid = the row itself (or its first group); a split row's further groups are appended behind the NR rows
+      const bool sp = (hub && split_hub) || (mid && split_mid);
+      const int pcs = sp ? grp : 1;
+      int k0 = 0, s0 = 0;
+      if (sp) { k0 = NR + atomicAdd(&ctr[0], pcs - 1) - 1; s0 = atomicAdd(&ctr[1], pcs); }
+      for (int p = 0; p < pcs; ++p) {
+        const int eb = start + p * GS, ee = sp ? min(start + deg, eb + GS) : start + deg;
+        itm[p == 0 ? tid : k0 + p] = make_uint2((unsigned)tid | ((unsigned)p << 8) | ((unsigned)pcs << 14) | ((unsigned)s0 << 20),
+                                                (unsigned)eb | ((unsigned)ee << 16));
+      }
       const float di = dvv;
       int e = start;
 #pragma unroll
@@ -493,55 +550,24 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
       for (int w = 0; w < 4; ++w) if (w < W) rb[tid * W + w] = mrow[w];
     }
   }
+  SPMM_T(3);          // list build (thread 0's own row)
+  const int nsl = seq > 0 ? seq : 1;
+  for (int s_ = 0; s_ < nsl; ++s_) {
+  if (s_ > 0) {                // next slab of this graph: every thread is done with the previous image and its scratch slots
+    __syncthreads();
+    c0 = s_ * slab;
+    ncol = min(slab, H4 - c0);
+    dma_slab();
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the slab has landed (LDS-DMA is tracked by vmcnt)
+  SPMM_T(4);          // slab wait
   __syncthreads();
-  // ---- aggregate: thread = (row i, column group q); columns q, q + TPR, ...
+  SPMM_T(5);          // barrier 2 (the slowest list builder / DMA)
+  // ---- aggregate: thread = (item, column group q); columns q, q + TPR, ...
   const int TPR = (ncol + CPT - 1) / CPT;
-  const int nit = NR * TPR;
   const unsigned mg_tpr = magic_of(TPR);
   const float* vg = vals ? vals + (size_t)g * R * R : nullptr;
-  for (int it = tid; it < nit; it += 256) {
-    const int i = fdiv(it, mg_tpr), q = it - i * TPR;
-    int cc[CPT];
-    float4 acc[CPT];
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) { cc[k] = min(q + k * TPR, ncol - 1); acc[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    if (listed) {
-      const int e1 = st[i + 1];
-      for (int e = st[i]; e < e1; e += 2) {
-        const uint2 ea = ent[e];
-        const bool two = e + 1 < e1;
-        const uint2 eb = ent[two ? e + 1 : e];
-        const float wa = __builtin_bit_cast(float, ea.y);
-        const float wb = two ? __builtin_bit_cast(float, eb.y) : 0.f;
-        float4 xa[CPT], xb[CPT];
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-          if (BF) { xa[k] = bf4_to_f4(xs16[ea.x * ncol + cc[k]]); xb[k] = bf4_to_f4(xs16[eb.x * ncol + cc[k]]); }
-          else { xa[k] = xs[ea.x * ncol + cc[k]]; xb[k] = xs[eb.x * ncol + cc[k]]; }
-        }
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-          acc[k].x += wa * xa[k].x; acc[k].y += wa * xa[k].y; acc[k].z += wa * xa[k].z; acc[k].w += wa * xa[k].w;
-          acc[k].x += wb * xb[k].x; acc[k].y += wb * xb[k].y; acc[k].z += wb * xb[k].z; acc[k].w += wb * xb[k].w;
-        }
-      }
-    } else {
-      const float di = vals ? 0.f : dv[i];
-      for (int w = 0; w < W; ++w) {
-        unsigned long long m = rb[i * W + w];
-        while (m) {
-          const int j = (w << 6) + __builtin_ctzll(m);
-          m &= m - 1;
-          const float wt = vg ? (transpose ? vg[(size_t)j * R + i] : vg[(size_t)i * R + j]) : di * dv[j];
-#pragma unroll
-          for (int k = 0; k < CPT; ++k) {
-            const float4 xv = BF ? bf4_to_f4(xs16[j * ncol + cc[k]]) : xs[j * ncol + cc[k]];
-            acc[k].x += wt * xv.x; acc[k].y += wt * xv.y; acc[k].z += wt * xv.z; acc[k].w += wt * xv.w;
-          }
-        }
-      }
-    }
+  auto store_row = [&](int i, int q, const int* cc, const float4* acc) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
       if (q + k * TPR >= ncol) break;
@@ -556,8 +582,116 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
         *o = a;
       }
     }
+  };
+  if (listed) {
+    float4* scr = reinterpret_cast<float4*>(dsm + (size_t)NR * ncol * (BF ? 8 : 16));      // [slot][ncol] fp32 partial rows
+    const int nitems = NR + ctr[0];
+    const bool any_split = ctr[1] > 0;            // workgroup-uniform
+    const int nit = nitems * TPR;
+    for (int it = tid; it < nit; it += 256) {
+      const int kk = fdiv(it, mg_tpr), q = it - kk * TPR;
+      const uint2 im = itm[kk];
+      const int i = im.x & 255, pcs = (im.x >> 14) & 63;
+      int cc[CPT];
+      float4 acc[CPT];
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) { cc[k] = min(q + k * TPR, ncol - 1); acc[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      const int e1 = im.y >> 16, e00 = im.y & 0xffff;
+      const int slot0 = (int)(im.x >> 20) + (int)((im.x >> 8) & 63);
+      float4 part[CPT];
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) part[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int e = e00; e < e1; e += 2) {
+        const uint2 ea = ent[e];
+        const bool two = e + 1 < e1;
+        const uint2 eb = ent[two ? e + 1 : e];
+        const float wa = __builtin_bit_cast(float, ea.y);
+        const float wb = two ? __builtin_bit_cast(float, eb.y) : 0.f;
+        float4 xa[CPT], xb[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+          if (BF) { xa[k] = bf4_to_f4(xs16[ea.x * ncol + cc[k]]); xb[k] = bf4_to_f4(xs16[eb.x * ncol + cc[k]]); }
+          else { xa[k] = xs[ea.x * ncol + cc[k]]; xb[k] = xs[eb.x * ncol + cc[k]]; }
+        }
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+          part[k].x += wa * xa[k].x; part[k].y += wa * xa[k].y; part[k].z += wa * xa[k].z; part[k].w += wa * xa[k].w;
+          part[k].x += wb * xb[k].x; part[k].y += wb * xb[k].y; part[k].z += wb * xb[k].z; part[k].w += wb * xb[k].w;
+        }
+        if ((((e - e00) & (GS - 2)) == GS - 2) || e + 2 >= e1) {        // the group's last pair: fold the group sum into the row sum
+#pragma unroll
+          for (int k = 0; k < CPT; ++k) {
+            acc[k].x += part[k].x; acc[k].y += part[k].y; acc[k].z += part[k].z; acc[k].w += part[k].w;
+            part[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      }
+      if (pcs == 1) {
+        store_row(i, q, cc, acc);
+      } else {                     // a split row's item holds exactly one group: acc = 0 + part
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+          if (q + k * TPR < ncol) scr[slot0 * ncol + cc[k]] = acc[k];
+      }
+    }
+    if (any_split) {
+      __syncthreads();
+      for (int it = tid; it < nit; it += 256) {
+        const int kk = fdiv(it, mg_tpr), q = it - kk * TPR;
+        const uint2 im = itm[kk];
+        const int pcs = (im.x >> 14) & 63;
+        if (pcs == 1 || ((im.x >> 8) & 63) != 0) continue;
+        const int i = im.x & 255, s0 = (int)(im.x >> 20);
+        int cc[CPT];
+        float4 acc[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) { cc[k] = min(q + k * TPR, ncol - 1); acc[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int p = 0; p < pcs; ++p) {
+#pragma unroll
+          for (int k = 0; k < CPT; ++k) {
+            const float4 v = scr[(s0 + p) * ncol + cc[k]];
+            acc[k].x += v.x; acc[k].y += v.y; acc[k].z += v.z; acc[k].w += v.w;
+          }
+        }
+        store_row(i, q, cc, acc);
+      }
+    }
+  } else {
+    const int nit = NR * TPR;
+    for (int it = tid; it < nit; it += 256) {
+      const int i = fdiv(it, mg_tpr), q = it - i * TPR;
+      int cc[CPT];
+      float4 acc[CPT];
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) { cc[k] = min(q + k * TPR, ncol - 1); acc[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      const float di = vals ? 0.f : dv[i];
+      for (int w = 0; w < W; ++w) {
+        unsigned long long m = rb[i * W + w];
+        while (m) {
+          const int j = (w << 6) + __builtin_ctzll(m);
+          m &= m - 1;
+          const float wt = vg ? (transpose ? vg[(size_t)j * R + i] : vg[(size_t)i * R + j]) : di * dv[j];
+#pragma unroll
+          for (int k = 0; k < CPT; ++k) {
+            const float4 xv = BF ? bf4_to_f4(xs16[j * ncol + cc[k]]) : xs[j * ncol + cc[k]];
+            acc[k].x += wt * xv.x; acc[k].y += wt * xv.y; acc[k].z += wt * xv.z; acc[k].w += wt * xv.w;
+          }
+        }
+      }
+      store_row(i, q, cc, acc);
+    }
   }
+  }     // slabs
+  SPMM_T(6);          // aggregate + stores issued (thread 0)
 }
+
+#ifdef GH_MEASURE
+extern "C" int gh_debug_spmm_phases(unsigned* out, int reset) {     // out: [8192][8]
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spmm_phase), 8192 * 8 * sizeof(unsigned)) != hipSuccess) return 1;
+  if (reset) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_spmm_phase)) != hipSuccess || hipMemset(p, 0, 8192 * 8 * sizeof(unsigned)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
 
 int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const int32_t* goff,
                 int m_real, const float* x, float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s, int bf16) {
@@ -594,7 +728,7 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   prof_begin(s, ptag);
   if (v4 && variant >= 3 && r <= 256 && (!bf16 || hv % 2 == 0)) {
     // edge-list kernel; variant 3: one column per thread, 4 (default): two, 5: three.  LDS pitch = slab columns.
-    const int cap = 11 * r;                        // edges per graph the list holds (a window-5 word graph has <= 9 R)
+    const int cap = 10 * r;                        // edges per graph the list holds (a window-5 word graph has <= 9 R)
     int lslab = slab;
     dim3 lgrid = grid;
     if (bf16) {                                    // bf16 LDS image: 8 B per column -> twice the columns per slab, kept even
@@ -605,7 +739,7 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
       lslab = (((hv + ns - 1) / ns) + 1) & ~1;
       lgrid = dim3(n, (hv + lslab - 1) / lslab);
     }
-    const size_t llds = (size_t)r * lslab * (bf16 ? 8 : 16) + (size_t)cap * 8 + (size_t)(r + 1) * 4 + (size_t)r * 4;
+    const size_t llds = (size_t)r * lslab * (bf16 ? 8 : 16) + (size_t)cap * 8 + (size_t)(r + 1) * 4 + (size_t)r * 4 + 4 + (size_t)r * 8;   // + item table
     const void* fn;
     const int lv = variant > 5 ? 5 : variant;
     if (bf16) fn = lv == 3 ? (const void*)spmm_list_kernel<true, 1> : lv == 5 ? (const void*)spmm_list_kernel<true, 3> : (const void*)spmm_list_kernel<true, 2>;
@@ -613,8 +747,17 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
     static bool attrl[6] = {false, false, false, false, false, false};
     const int ai = (bf16 ? 3 : 0) + (lv - 3);
     if (!attrl[ai] && llds > 64 * 1024) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrl[ai] = true; }
+    static int xcd_map = -1;
+    if (xcd_map < 0) xcd_map = measure_env("GH_SPMM_XCD", 1);
+    int ns_arg = 0;
+    if (xcd_map && lgrid.y > 1) { ns_arg = (int)lgrid.y; lgrid = dim3(((n + 7) / 8) * 8 * ns_arg, 1); }
+    static int split = -1, seq_on = -1;
+    if (split < 0) split = measure_env("GH_SPMM_SPLIT", 1);
+    if (seq_on < 0) seq_on = measure_env("GH_SPMM_SEQ", 1);
+    int seq = 0;
+    if (seq_on && lgrid.y == 1 && ns_arg > 1 && n >= 768) { seq = ns_arg; ns_arg = 0; lgrid = dim3(n, 1); }   // enough graphs to fill 256 CUs x 4
     void* args[] = {(void*)&bits, (void*)&dinv, (void*)&vals, (void*)&keep, (void*)&goff, (void*)&x, (void*)&y, (void*)&r, (void*)&h,
-                    (void*)&lslab, (void*)&cap, (void*)&transpose, (void*)&accumulate};
+                    (void*)&lslab, (void*)&cap, (void*)&transpose, (void*)&accumulate, (void*)&n, (void*)&ns_arg, (void*)&split, (void*)&seq};
     (void)hipLaunchKernel(fn, lgrid, dim3(256), args, llds, s);
   } else if (bf16) {
     static bool attrb = false;

@@ -34,10 +34,40 @@ y = torch.empty_like(x)
 for name, toks in (("zipf", make_tokens(rng, n, r, 20000, r, r)[0]),
                    ("distinct", (np.arange(n * r).reshape(n, r) % 19000 + 2).astype(np.int32))):
     lens = np.full((n,), r, np.int32)
-    adj, _, _ = ops.graph_build(torch.from_numpy(toks).to(dev), torch.from_numpy(lens).to(dev), 3)
+    adj, _, n_nodes = ops.graph_build(torch.from_numpy(toks).to(dev), torch.from_numpy(lens).to(dev), 3)
     nnz = float(torch.count_nonzero(adj.to_dense())) / n
     deg = adj.to_dense().ne(0).sum(-1).max().item()
     ms = timeit(lambda: _lib.call("gh_spmm", *adj._args(), None, 0, x.data_ptr(), y.data_ptr(), n, r, h, 0, 0, _lib.stream()))
     print(f"{name:9s} nnz/graph {nnz:7.1f} max degree {deg:3d}: {ms*1e3:7.1f} us  {2*n*r*h*4/ms/1e6:7.1f} GB/s")
+    # node-compact layout (what the training step runs): the real nodes of all graphs back to back
+    goff = torch.zeros(n + 1, device=dev, dtype=torch.int32)
+    goff[1:] = torch.cumsum(n_nodes, 0).to(torch.int32)
+    m_real = int(goff[-1])
+    real = (torch.arange(r, device=dev)[None, :] < n_nodes[:, None])
+    xc = x[real].contiguous()
+    yc = torch.empty_like(xc)
+    msc = timeit(lambda: _lib.call("gh_spmm", *adj._args(), goff.data_ptr(), m_real, xc.data_ptr(), yc.data_ptr(), n, r, h, 0, 0, _lib.stream()))
+    # reference: the padded launch on an input whose padding rows are zero
+    xz = torch.where(real[..., None], x, torch.zeros_like(x))
+    _lib.call("gh_spmm", *adj._args(), None, 0, xz.data_ptr(), y.data_ptr(), n, r, h, 0, 0, _lib.stream())
+    err = float((y[real] - yc).abs().max())
+    dense = (adj.to_dense().double() @ xz.double())[real]
+    err64 = float((dense - yc.double()).abs().max())
+    print(f"{name:9s} compact m_real {m_real} ({m_real / n:.1f} rows/graph): {msc*1e3:7.1f} us  {2*m_real*h*4/msc/1e6:7.1f} GB/s  "
+          f"|compact - padded| {err:.2e}  |compact - dense f64| {err64:.2e}")
+try:      # tool build: per-phase ticks of the list kernel (thread 0 of every workgroup)
+    import ctypes
+    L = _lib.load()
+    L.gh_debug_spmm_phases.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    buf = (ctypes.c_uint * (8192 * 8))()
+    L.gh_debug_spmm_phases(None, 1)
+    _lib.call("gh_spmm", *adj._args(), goff.data_ptr(), m_real, xc.data_ptr(), yc.data_ptr(), n, r, h, 0, 0, _lib.stream())
+    torch.cuda.synchronize()
+    L.gh_debug_spmm_phases(buf, 1)
+    a = np.frombuffer(buf, dtype=np.uint32).reshape(8192, 8)[:n * 4, :7].astype(np.float64) * 0.01
+    names = ["issue", "rowwords+scan", "barrier1", "listbuild", "slabwait", "barrier2", "aggregate"]
+    print("phases, thread 0 of each workgroup, us (mean / p90): " + ", ".join(f"{nm} {a[:, i].mean():.2f}/{np.percentile(a[:, i], 90):.2f}" for i, nm in enumerate(names)) + f"  total {a.sum(1).mean():.2f}")
+except Exception as e:
+    print("no phase instrumentation:", e)
 ms = timeit(lambda: y.copy_(x))
 print(f"copy      {ms*1e3:7.1f} us  {2*n*r*h*4/ms/1e6:7.1f} GB/s")
