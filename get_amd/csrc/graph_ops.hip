@@ -403,20 +403,17 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
   __shared__ int wsum[4];
   __shared__ int wsum2[4];                                                                    // groups of hub rows | of mid rows << 16
   __shared__ int ctr[2];                                                                      // extra items, scratch slots
-  // XCD-aware work decode (nslab > 0: 1-D grid).  Workgroups go round-robin over the 8 XCDs, each with its own L2: the
-  // slabs of one graph sit next to each other in ONE XCD's queue, so the 128-byte lines that straddle a slab boundary
-  // and the graph's bit rows / dinv / keep words are fetched from HBM once and hit that L2 for the sibling slabs.
-  // seq > 0: ONE workgroup per graph walks the graph's `seq` slabs one after the other -- bit rows, scan and edge list are
-  // paid once per graph instead of once per slab (measured per workgroup: ~8 us of set-up latency chain against ~5 us of
-  // data movement per slab), and 4 resident workgroups per CU hold a whole 960-graph launch in one round.
-  int g = blockIdx.x, sl = blockIdx.y;
-  if (seq > 0) {
-    if (g >= n) return;
-    sl = 0;
-  } else if (nslab > 0) {
+  // Work decode (1-D grid).  A workgroup owns `seq` consecutive slabs of one graph and walks them one after the other: bit
+  // rows, scan and edge list are paid once per workgroup (measured: ~8 us of set-up latency chain against ~5 us of data
+  // movement per fp32 slab at h = 300).  Workgroups go round-robin over the 8 XCDs, each with its own L2: the chunks of
+  // one graph sit next to each other in ONE XCD's queue, so the 128-byte lines that straddle a slab boundary and the
+  // graph's bit rows / dinv / keep words are fetched from HBM once and hit that L2 for the sibling workgroups.
+  int g, sl;
+  {
+    const int nchunk = (nslab + seq - 1) / seq;
     const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-    sl = j % nslab;
-    g = (j / nslab) * 8 + xcd;
+    sl = (j % nchunk) * seq;
+    g = (j / nchunk) * 8 + xcd;
     if (g >= n) return;
   }
 #ifdef GH_MEASURE
@@ -551,9 +548,9 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
     }
   }
   SPMM_T(3);          // list build (thread 0's own row)
-  const int nsl = seq > 0 ? seq : 1;
-  for (int s_ = 0; s_ < nsl; ++s_) {
-  if (s_ > 0) {                // next slab of this graph: every thread is done with the previous image and its scratch slots
+  const int sl_end = min(nslab, sl + seq);
+  for (int s_ = sl; s_ < sl_end; ++s_) {
+  if (s_ > sl) {                // next slab of this graph: every thread is done with the previous image and its scratch slots
     __syncthreads();
     c0 = s_ * slab;
     ncol = min(slab, H4 - c0);
@@ -747,15 +744,17 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
     static bool attrl[6] = {false, false, false, false, false, false};
     const int ai = (bf16 ? 3 : 0) + (lv - 3);
     if (!attrl[ai] && llds > 64 * 1024) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrl[ai] = true; }
-    static int xcd_map = -1;
-    if (xcd_map < 0) xcd_map = measure_env("GH_SPMM_XCD", 1);
-    int ns_arg = 0;
-    if (xcd_map && lgrid.y > 1) { ns_arg = (int)lgrid.y; lgrid = dim3(((n + 7) / 8) * 8 * ns_arg, 1); }
-    static int split = -1, seq_on = -1;
+    // slabs per workgroup, measured inside the bench step (ms of aggregation per step at 1 / 2 / all slabs per workgroup):
+    //   960 graphs, R = 100, h = 300 fp32 (4 slabs): 0.302 / 0.282 / 0.262;   640 graphs, R = 200 (8 slabs): 0.536 / 0.467 / 0.426;
+    //   960 graphs, h = 768 bf16 image, window 5 (5 slabs): 0.634 / 0.620 / 0.698 -- long per-slab work: the whole graph in one
+    //   workgroup leaves one thinly balanced round.  Few-graph launches (claim side) keep one slab per workgroup: latency.
+    static int split = -1, spw_env = -1;
     if (split < 0) split = measure_env("GH_SPMM_SPLIT", 1);
-    if (seq_on < 0) seq_on = measure_env("GH_SPMM_SEQ", 1);
-    int seq = 0;
-    if (seq_on && lgrid.y == 1 && ns_arg > 1 && n >= 768) { seq = ns_arg; ns_arg = 0; lgrid = dim3(n, 1); }   // enough graphs to fill 256 CUs x 4
+    if (spw_env < 0) spw_env = measure_env("GH_SPMM_SPW", 0);
+    int ns_arg = (int)lgrid.y;
+    int seq = spw_env > 0 ? spw_env : (n < 256 ? 1 : (bf16 ? 2 : ns_arg));
+    if (seq > ns_arg) seq = ns_arg;
+    lgrid = dim3(((n + 7) / 8) * 8 * ((ns_arg + seq - 1) / seq), 1);
     void* args[] = {(void*)&bits, (void*)&dinv, (void*)&vals, (void*)&keep, (void*)&goff, (void*)&x, (void*)&y, (void*)&r, (void*)&h,
                     (void*)&lslab, (void*)&cap, (void*)&transpose, (void*)&accumulate, (void*)&n, (void*)&ns_arg, (void*)&split, (void*)&seq};
     (void)hipLaunchKernel(fn, lgrid, dim3(256), args, llds, s);
