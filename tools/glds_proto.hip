@@ -67,6 +67,21 @@ glds_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int
     if ((int)blockIdx.x < 768) for (int d = 0; d < cls * STAG_UNITS; ++d) __builtin_amdgcn_s_sleep(127);
   }
 #endif
+  auto calc_avo = [&](int tile_) __attribute__((always_inline)) {
+    const int m0_ = tile_ * BM;
+#pragma unroll
+    for (int j = 0; j < SA; ++j) {
+      const int ia = wave + NW * j;
+      const int gm = m0_ + 16 * ia + drow;
+      a_vo[j] = ((NW * (j + 1) <= NAI || ia < NAI) && gm < M) ? ((unsigned)gm * (unsigned)lda * 4u + (unsigned)dkq * 16u) : OOB;
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < SB; ++j) {
+    const int ib = wave + NW * j;
+    const int n = 16 * ib + drow;
+    b_vo[j] = ((NW * (j + 1) <= NBI || ib < NBI) && n < N) ? ((unsigned)n * (unsigned)ldb * 4u + (unsigned)dkq * 16u) : OOB;
+  }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   const int m0 = tile * BM;
 #ifdef MIXK
@@ -80,19 +95,12 @@ glds_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int
 #else
   const int T = (Kt + BK - 1) / BK;
 #endif
+#ifdef XPF
+  if (tile == (int)blockIdx.x) calc_avo(tile);      // later tiles: offsets + first K tile were issued during the previous epilogue
+#else
   if (tile != (int)blockIdx.x) __syncthreads();     // previous tile's epilogue no longer reads the stage memory
-#pragma unroll
-  for (int j = 0; j < SA; ++j) {
-    const int ia = wave + NW * j;
-    const int gm = m0 + 16 * ia + drow;
-    a_vo[j] = ((NW * (j + 1) <= NAI || ia < NAI) && gm < M) ? ((unsigned)gm * (unsigned)lda * 4u + (unsigned)dkq * 16u) : OOB;
-  }
-#pragma unroll
-  for (int j = 0; j < SB; ++j) {
-    const int ib = wave + NW * j;
-    const int n = 16 * ib + drow;
-    b_vo[j] = ((NW * (j + 1) <= NBI || ib < NBI) && n < N) ? ((unsigned)n * (unsigned)ldb * 4u + (unsigned)dkq * 16u) : OOB;
-  }
+  calc_avo(tile);
+#endif
   const rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
   const rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
 
@@ -149,7 +157,11 @@ glds_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int
   };
 
 #if STAGES == 2
+#ifdef XPF
+  if (tile == (int)blockIdx.x) dma_tile(0, 0);
+#else
   dma_tile(0, 0);
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #ifdef NOPIPE
@@ -260,8 +272,16 @@ glds_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int
 #else
   {
     constexpr int PITCH = BN + 4;                 // floats; rows 16 B aligned, 8 consecutive rows cover all 32 banks
+#ifdef XPF
+    // cross-tile prefetch: both stages are free after the K loop; the NEXT tile's first K tile goes to stage 0 now and
+    // lands underneath this epilogue, which stages its rows in stage 1
+    static_assert(16 * WM * PITCH * 4 <= STAGE, "epilogue pass fits ONE stage");
+    float* ep = reinterpret_cast<float*>(smem + STAGE);
+    if (tile + (int)gridDim.x < ntiles) { calc_avo(tile + gridDim.x); dma_tile(0, 0); }
+#else
     static_assert(16 * WM * PITCH * 4 <= STAGES * STAGE, "epilogue tile fits the stage memory");
     float* ep = reinterpret_cast<float*>(smem);
+#endif
     const int N4 = N / 4;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -304,7 +324,13 @@ glds_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int
 #ifndef PNI
 #define PNI 10
 #endif
-constexpr int P_WM = 2, P_WN = 2, P_NI = PNI, P_MI = 2;
+#ifndef PWM
+#define PWM 2
+#endif
+#ifndef PWN
+#define PWN 2
+#endif
+constexpr int P_WM = PWM, P_WN = PWN, P_NI = PNI, P_MI = 2;
 
 static float *g_in0, *g_in1, *g_out1;
 static void launch_k(int grid, const float* dA, const float* dB, float* dC, int M, int N, int K) {
@@ -388,6 +414,14 @@ int main(int argc, char** argv) {
   if (argc > 3) { run(atoi(argv[2]), atoi(argv[3]), 600, atoi(argv[1]), false); return 0; }
   if (argc > 2) { run(atoi(argv[2]), 300, 600, atoi(argv[1]), false); return 0; }
   if (argc > 1) { run(96000, 300, 600, atoi(argv[1]), false); return 0; }     // long loop for power / clock sampling
+#ifdef KSWEEP
+  run(1000, 300, 300, 2, true);
+  run(62128, 300, 300, 30, true);
+  run(62128, 300, 600, 30, true);
+  run(96000, 300, 300, 30, false);
+  run(14208, 300, 600, 30, false);
+  return 0;
+#endif
   run(1000, 300, 300, 2, true);           // ragged M, K tail
   run(96000, 300, 300, 20, true);
   run(96000, 300, 600, 20, false);
