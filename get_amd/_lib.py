@@ -19,7 +19,7 @@ _I = ctypes.c_int
 _F = ctypes.c_float
 _L = ctypes.c_int64
 _U = ctypes.c_uint32
-ABI_VERSION = 5          # GH_ABI_VERSION of include/get_hip.h
+ABI_VERSION = 6          # GH_ABI_VERSION of include/get_hip.h
 
 # name -> argtypes (mirrors include/get_hip.h; tests/test_abi.py checks the two agree)
 SIGNATURES = {
@@ -68,6 +68,13 @@ SIGNATURES = {
     "gh_cross_entropy": [_P, _P, _I, _I, _P, _P, _P],
     "gh_get_prepare": [_P, _P, _I, _I, _P, _P, _I, _I, _I] + [_P] * 8 + [_I] + [_P] * 5 + [_P, _P, _P],
     "gh_get_struct_sizes": [_P],
+    # library-owned RCCL communicator (csrc/comm_ops.hip; librccl is dlopen'ed on first use)
+    "gh_comm_unique_id": [_P],
+    "gh_comm_init": [_P, _I, _I, _P],
+    "gh_comm_destroy": [_P],
+    "gh_comm_info": [_P, _P, _P],
+    "gh_flat_allreduce": [_P, _P, _L, _P],
+    "gh_flat_broadcast": [_P, _P, _L, _I, _P],
 }
 
 PROFILE_ROWS = ["gemm_big", "gemm_big_tn", "gemm_small", "gemm_small_tn", "spmm", "scorer_gsl",
@@ -130,6 +137,7 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.gh_abi_version.restype = _I
     lib.gh_last_error.restype = ctypes.c_char_p
+    lib.gh_comm_library.restype = ctypes.c_char_p
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = args

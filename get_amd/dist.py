@@ -67,14 +67,104 @@ def shard_claims(n_claims: int, rank: int, world: int, evd_counts=None):
     return [int(i) for i in np.sort(mine)]          # ascending: keeps the claim-major order of the batch tensors
 
 
+class _StreamWork:
+    """Work handle of a collective that was ENQUEUED on a HIP stream (library-owned communicator): ``wait()`` orders the
+    caller's current stream behind it, as the work object of an asynchronous torch.distributed collective does."""
+
+    def __init__(self, event):
+        self._event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self._event)
+        return True
+
+
+class LibComm:
+    """RCCL communicator owned by libget_hip.so (``gh_comm_*`` / ``gh_flat_allreduce``, include/get_hip.h): what a
+    non-Python host binds for the path's one exchange step.  Collectives are enqueued on the
+    CURRENT torch stream of the communicator's device and are in place.
+
+    The 128-byte id that rank 0 creates has to reach every rank by some channel; ``from_process_group`` uses an existing
+    torch.distributed group of any backend (gloo is enough) for that one hand-over, ``single`` builds a 1-rank
+    communicator (RCCL loaded, communicator on the device, device all-reduce = identity) for single-GPU boxes."""
+
+    def __init__(self, id_bytes: bytes, rank: int, world: int, device=None):
+        import ctypes
+        from . import _lib
+        assert len(id_bytes) == 128
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.device, self.rank, self.world = dev, int(rank), int(world)
+        buf = ctypes.create_string_buffer(bytes(id_bytes), 128)
+        out = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.call("gh_comm_init", ctypes.cast(buf, ctypes.c_void_p), self.rank, self.world, ctypes.addressof(out))
+        self._comm = out.value
+        self.library = (_lib.load().gh_comm_library() or b"").decode()
+
+    @staticmethod
+    def new_id() -> bytes:
+        import ctypes
+        from . import _lib
+        buf = ctypes.create_string_buffer(128)
+        _lib.call("gh_comm_unique_id", ctypes.cast(buf, ctypes.c_void_p))
+        return buf.raw
+
+    @classmethod
+    def single(cls, device=None) -> "LibComm":
+        return cls(cls.new_id(), 0, 1, device)
+
+    @classmethod
+    def from_process_group(cls, group=None, device=None) -> "LibComm":
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.new_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(box[0], rank, world, device)
+
+    def info(self):
+        import ctypes
+        from . import _lib
+        r, w = ctypes.c_int(-1), ctypes.c_int(-1)
+        _lib.call("gh_comm_info", self._comm, ctypes.addressof(r), ctypes.addressof(w))
+        return r.value, w.value
+
+    def _check(self, t: torch.Tensor):
+        if self._comm is None:
+            raise RuntimeError("get_amd: LibComm used after close()")
+        if not (t.is_cuda and t.device == self.device and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("get_amd: LibComm collectives take contiguous fp32 tensors on the communicator's device")
+
+    def all_reduce(self, t: torch.Tensor):
+        """In-place sum over the ranks, enqueued on the current stream."""
+        from . import _lib
+        self._check(t)
+        with torch.cuda.device(self.device):
+            _lib.call("gh_flat_allreduce", self._comm, t.data_ptr(), t.numel(), _lib.stream())
+
+    def broadcast(self, t: torch.Tensor, root: int = 0):
+        from . import _lib
+        self._check(t)
+        with torch.cuda.device(self.device):
+            _lib.call("gh_flat_broadcast", self._comm, t.data_ptr(), t.numel(), int(root), _lib.stream())
+
+    def close(self):
+        from . import _lib
+        if self._comm is not None:
+            torch.cuda.synchronize(self.device)
+            _lib.call("gh_comm_destroy", self._comm)
+            self._comm = None
+
+
 class FlatTrainer:
     """Owns flat parameter / gradient / Adam-moment buffers; ``param.data`` and ``param.grad`` of every
     live parameter are views into them, so autograd accumulates straight into the all-reduce bucket."""
 
     def __init__(self, model: torch.nn.Module, lr=1e-4, weight_decay=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  process_group=None, late_prefixes: Sequence[str] = LATE_PREFIXES, check_overlap: bool = False,
-                 always_reduce: bool = False):
+                 always_reduce: bool = False, comm: "LibComm" = None):
         self.model = model
+        # comm: a library-owned RCCL communicator (LibComm) carries the collectives instead of torch.distributed -- the same
+        # calls a C / C++ host of the library would make (gh_flat_allreduce on the caller's stream, stream-ordered)
+        self.comm = comm
         # always_reduce: issue the collectives even in a 1-rank group (a world_size-1 RCCL group on a single-GPU box then
         # exercises communicator set-up, the device all-reduce and the asynchronous early range; tests/test_gpu_dist.py)
         self._always_reduce = bool(always_reduce)
@@ -138,14 +228,24 @@ class FlatTrainer:
 
     @property
     def world(self) -> int:
+        if self.comm is not None:
+            return self.comm.world
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def _reducing(self) -> bool:
-        return self.world > 1 or (self._always_reduce and dist.is_available() and dist.is_initialized())
+        return self.world > 1 or (self._always_reduce and (self.comm is not None or (dist.is_available() and dist.is_initialized())))
 
     def _all_reduce(self, t: torch.Tensor, async_op: bool = False):
         self.comm_bytes += t.numel() * t.element_size()
         self.comm_calls += 1
+        if self.comm is not None:
+            # enqueued on the current stream; "asynchronous" = the caller later orders its own stream behind this one
+            self.comm.all_reduce(t)
+            if not async_op:
+                return None
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(t.device))
+            return _StreamWork(ev)
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def broadcast_parameters(self, src: int = 0):
@@ -153,16 +253,17 @@ class FlatTrainer:
         one packed buffer of everything outside it that the forward reads (the never-trained GSL scorer, frozen
         embedding tables, the dead-but-present LSTM / trans parameters a checkpoint carries).  The per-tensor loop this
         replaces issued ~90 broadcasts."""
-        if not (dist.is_available() and dist.is_initialized()):
+        if self.comm is None and not (dist.is_available() and dist.is_initialized()):
             return
         from . import ops
-        dist.broadcast(self.flat_p, src=src, group=self.group)
+        bcast = (lambda t: self.comm.broadcast(t, src)) if self.comm is not None else (lambda t: dist.broadcast(t, src=src, group=self.group))
+        bcast(self.flat_p)
         live = {id(p) for p in self.params}
         rest = [p for p in self.model.parameters() if id(p) not in live]
         rest += [b for b in self.model.buffers() if b.is_floating_point()]
         if rest:
             pack = torch.cat([t.detach().reshape(-1).float() for t in rest])
-            dist.broadcast(pack, src=src, group=self.group)
+            bcast(pack)
             off = 0
             with torch.no_grad():
                 for t in rest:
@@ -227,7 +328,10 @@ class FlatTrainer:
                     # every rank contributed its snapshot, so the reduced range must equal the sum of the snapshots:
                     # reduce the snapshots again and compare (a gradient that landed after the milestone shows up here)
                     ref = self._early_snapshot
-                    dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.group)
+                    if self.comm is not None:
+                        self.comm.all_reduce(ref)
+                    else:
+                        dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.group)
                     bad = float((ref - self.flat_g[:self.n_early]).abs().max())
                     self._early_snapshot = None
                     if bad != 0.0:

@@ -56,7 +56,7 @@ extern "C" {
 
 typedef void* gh_stream_t;
 
-#define GH_ABI_VERSION 5
+#define GH_ABI_VERSION 6
 
 int gh_abi_version(void);
 /* Thread-local message of the last failing call on this thread (never NULL). */
@@ -288,6 +288,23 @@ int gh_masked_mean_bwd(const float* g, const int32_t* ids, const float* lens, fl
  *      on one flat fp32 bucket (the same bucket the RCCL gradient all-reduce uses) ---- */
 int gh_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, float grad_scale, gh_stream_t stream);
+
+/* ---- (e) the path's one exchange step: all-reduce(sum) of the flat fp32 gradient bucket over RCCL / xGMI with a
+ *      communicator this library owns (SURVEY 8(b) `flat_allreduce`).  The reference has no distributed code -- its
+ *      optimiser is single-process (Fitting/FittingFC/declare_fitter.py:58-61) -- so these calls mirror no reference
+ *      interface; they exist so that a non-Python host can run data-parallel steps without
+ *      torch.distributed:   rank 0: gh_comm_unique_id -> ship the 128 bytes to every rank by any channel ->
+ *      every rank: hipSetDevice, gh_comm_init -> per step: gh_get_backward ..., gh_flat_allreduce(bucket),
+ *      gh_adam_step(..., grad_scale = 1 / world).  librccl is dlopen'ed on first use (a copy the process already holds,
+ *      e.g. torch's, is reused; $GET_AMD_RCCL overrides the search); nothing else in the library depends on it.
+ *      Collectives are enqueued on `stream` and are in place; buffers are device pointers. ---- */
+int gh_comm_unique_id(void* id128);                                  /* out: 128 bytes (ncclUniqueId) */
+int gh_comm_init(const void* id128, int rank, int world, void** comm);   /* binds to the calling thread's current device */
+int gh_comm_destroy(void* comm);
+int gh_comm_info(void* comm, int* rank, int* world);                 /* either output may be NULL */
+const char* gh_comm_library(void);                                   /* the librccl that was loaded; NULL + gh_last_error() if none */
+int gh_flat_allreduce(void* comm, float* buf, int64_t count, gh_stream_t stream);
+int gh_flat_broadcast(void* comm, float* buf, int64_t count, int root, gh_stream_t stream);
 
 /* ==== a7  the whole model in two calls: Graph_basedSemantiStructure.forward (graph_based_semantic_structure.py:76-125) ====
  * gh_get_forward / gh_get_backward chain every kernel of the path -- claim cell + masked mean (:144-155), evidence cells

@@ -181,3 +181,73 @@ def test_rccl_world_size_one_runs_the_overlapped_allreduce_on_the_device():
     assert calls == 6 and nbytes == 3 * numel * 4           # early + late range per step = the whole bucket once
     assert calls0 == 0 and early0 == 0
     assert np.array_equal(p_rccl, p_plain), "three steps through RCCL differ from three steps without a collective"
+
+
+def _worker_libcomm_single(port, q, use_comm):
+    """One rank on cuda:0 with the LIBRARY's communicator (gh_comm_init / gh_flat_allreduce, include/get_hip.h) instead of
+    torch.distributed's: the 128-byte id travels through a world_size-1 gloo group (LibComm.from_process_group), the
+    broadcast and both all-reduce ranges run as RCCL calls enqueued by libget_hip.so on the trainer's own streams."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from get_amd.dist import FlatTrainer, LibComm
+    torch.cuda.set_device(0)
+    comm = None
+    if use_comm:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        comm = LibComm.from_process_group(device="cuda:0")
+    try:
+        cfg, seed = _cfg(), 5
+        model, nb = _make(cfg, seed, "cuda:0", None, True)
+        tr = FlatTrainer(model, check_overlap=use_comm, always_reduce=use_comm, comm=comm)
+        if use_comm:
+            tr.broadcast_parameters(0)
+        tr.attach_overlap()
+        early_seen = 0
+        for step in range(3):
+            tr.zero_grad()
+            q_, d_, k_ = nb.inputs()
+            loss = torch.nn.functional.cross_entropy(model(q_, d_, **k_), nb.labels)
+            loss.backward()
+            early_seen += int(tr._early_work is not None)
+            tr.step()
+        torch.cuda.synchronize()
+        extra = None
+        if use_comm:
+            # the collective itself: sum over one rank is the identity, on a buffer the trainer does not own
+            t = torch.arange(1 << 20, device="cuda:0", dtype=torch.float32)
+            ref = t.clone()
+            comm.all_reduce(t)
+            comm.broadcast(t, 0)
+            torch.cuda.synchronize()
+            extra = (bool(torch.equal(t, ref)), comm.info(), comm.library, tr.world)
+            comm.close()
+        q.put((use_comm, tr.flat_p.cpu().numpy(), tr.comm_calls, tr.comm_bytes, early_seen, tr.numel, extra))
+    finally:
+        if use_comm:
+            dist.destroy_process_group()
+
+
+def test_library_owned_rccl_communicator_world_size_one():
+    """SURVEY 8(b) `flat_allreduce` as a C-ABI export: three overlapped FlatTrainer steps whose collectives are
+    gh_flat_allreduce / gh_flat_broadcast calls on a communicator built by gh_comm_init must leave the parameters
+    BIT-identical to the same steps without any collective, and the loaded librccl is reported."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    res = {}
+    for use_comm in (True, False):
+        q = ctx.Queue()
+        p = ctx.Process(target=_worker_libcomm_single, args=(_free_port(), q, use_comm))
+        p.start()
+        got = q.get(timeout=600)
+        p.join(300)
+        assert p.exitcode == 0
+        res[use_comm] = got
+    _, p_lib, calls, nbytes, early_seen, numel, extra = res[True]
+    _, p_plain, calls0, nbytes0, early0, _, _ = res[False]
+    ident, (rank, world), library, tr_world = extra
+    assert ident and (rank, world) == (0, 1) and tr_world == 1
+    assert "rccl" in library
+    assert early_seen == 3, "the milestone hook did not start the early all-reduce on the library's communicator"
+    assert calls == 6 and nbytes == 3 * numel * 4
+    assert calls0 == 0 and early0 == 0
+    assert np.array_equal(p_lib, p_plain), "three steps through gh_flat_allreduce differ from three steps without a collective"

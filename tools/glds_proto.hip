@@ -330,7 +330,10 @@ glds_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int
 #ifndef PWN
 #define PWN 2
 #endif
-constexpr int P_WM = PWM, P_WN = PWN, P_NI = PNI, P_MI = 2;
+#ifndef PMI
+#define PMI 2
+#endif
+constexpr int P_WM = PWM, P_WN = PWN, P_NI = PNI, P_MI = PMI;
 
 static float *g_in0, *g_in1, *g_out1;
 static void launch_k(int grid, const float* dA, const float* dB, float* dC, int M, int N, int K) {
@@ -420,6 +423,8 @@ int main(int argc, char** argv) {
   run(62128, 300, 600, 30, true);
   run(96000, 300, 300, 30, false);
   run(14208, 300, 600, 30, false);
+  run(14208, 300, 300, 30, true);
+  run(14208, 300, 900, 30, false);
   return 0;
 #endif
   run(1000, 300, 300, 2, true);           // ragged M, K tail
