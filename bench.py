@@ -549,6 +549,10 @@ def main():
     ap.add_argument("--streamed", action="store_true",
                     help="ALSO time a fresh NativeBatch per step (H2D of the ids + m_real read-back, one batch ahead on a side stream)")
     ap.add_argument("--no-side-modes", action="store_true", help="skip the --reference-api / --streamed legs the headline run adds by default")
+    ap.add_argument("--collective", choices=["torch", "library"], default="torch",
+                    help="who carries the gradient all-reduce: torch.distributed (default; backend nccl = RCCL) or the library's own "
+                         "RCCL communicator (gh_comm_init / gh_flat_allreduce, include/get_hip.h); with --gpus 1 the library route "
+                         "runs a world-size-1 communicator so that the collective is issued and timed on the device")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-series", action="store_true", help="skip the realistic evidence-count series")
@@ -620,9 +624,18 @@ def main():
     wl = build_workload(seed=SEED + (0 if shard else rank), device=device, cfg=cfg_in, compact=False if args.padded else None,
                         n_batches=args.batches, evd_dist=args.evd_dist, model_seed=SEED, claim_shard=shard)
     model, cfg = wl["model"], wl["cfg"]
-    trainer = FlatTrainer(model, lr=1e-4, weight_decay=1e-3)
+    lib_comm = None
+    if args.collective == "library":
+        from get_amd.dist import LibComm
+        lib_comm = LibComm.from_process_group(device=device) if world > 1 else LibComm.single(device)
+        backend = f"library-owned RCCL communicator ({lib_comm.library}); rendezvous over torch.distributed {backend}" if world > 1 \
+            else f"library-owned RCCL communicator ({lib_comm.library}), world size 1"
+    trainer = FlatTrainer(model, lr=1e-4, weight_decay=1e-3, comm=lib_comm, always_reduce=lib_comm is not None)
     from get_amd import ops
     ops.bump_weight_epoch()            # parameters were (re)written through .data: drop cached transposes
+    if lib_comm is not None and world == 1:
+        trainer.broadcast_parameters(0)
+        trainer.attach_overlap()
     if world > 1:
         trainer.broadcast_parameters(0)      # two collectives (flat bucket + everything outside it), not one per tensor
         trainer.attach_overlap()             # 76 % of the gradient all-reduce runs underneath the first cell's backward
@@ -671,7 +684,7 @@ def main():
             "data": "synthetic",
             "claims_per_s": total_claims_block * value / max(float(np.median(world_pairs)), 1.0),
             "timed": summ["timed"],
-            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "rccl_ranks": (lib_comm.info()[1] if lib_comm is not None else (dist.get_world_size() if world > 1 else 1)),
             "collective": {"backend": backend, "allreduce_bytes_per_step_per_rank": comm_bytes_step,
                            "allreduce_ms_per_step": (split or {}).get("allreduce_ms"),
                            "calls_per_step": trainer.comm_calls / max(1, (args.warmup + args.steps * len(m["blocks_s"]))),
@@ -835,6 +848,8 @@ def main():
             out["metric"] = "MEASUREMENT BUILD (not a product number): " + out["metric"]
             out["measurement_switches"] = {k: os.environ[k] for k in leaked}
         print(json.dumps(out))
+    if lib_comm is not None:
+        lib_comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
