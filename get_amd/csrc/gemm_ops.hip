@@ -431,6 +431,7 @@ nt_finish_kernel(const FinishArgs F) {
 
 // Collects problems that share their row space, splits wide outputs into column blocks the tile
 // can hold, and launches them GH_MAX_PROBLEMS at a time.
+constexpr int NARROW_DEFAULT = 14;     // call-site mask of the 64 x 160 tile (see Batch::narrow): cell forward h gate (2), cell backward da / d(r xp) pair (3) and da / dxp accumulation pair (4).  A/B on the bench step: 153.3 K -> 155.2 K pairs/s; the single-problem K = 300 sites (5, 6, 7) and the z / r pair (1) measured -0.1 .. +0.1 %
 struct Batch {
   Launch L;
   bool tn, big;
@@ -447,10 +448,18 @@ struct Batch {
 
   float* g_ws = nullptr;
   size_t g_ws_bytes = 0;
+  // 64 x 160 fp32 tile (launch_cfg<2, 2, 5>): half the accumulators -> <= 128 VGPRs -> FOUR workgroups per CU instead of three,
+  // two column blocks per 300-wide problem.  More resident workgroups run more of the neighbours' epilogue streams underneath
+  // the K loops: launches with stream-heavy epilogues gain, plain-store launches lose (prototype, tools/glds_proto.hip NHALF:
+  // h-gate-like epilogue K = 300: 62.6 -> 68.2 TF, K = 600: 87.7 -> 90.5; plain store: 92.4 -> 88.7).  Chosen per call site.
+  bool narrow = false;
   bool wide = false;      // 128 x 256 bf16 tile (launch_cfg<2, 2, 8, 4>)
   bool wide256 = false;   // 256 x 256 bf16 tile, 8 waves (launch_cfg<4, 2, 8, 4>)
   // wide_bf16: every problem of this batch is a bf16-storage NT problem whose widths are multiples of 256 (h = 768)
-  Batch(bool tn_, int rows_hint, hipStream_t s_, bool wide_bf16 = false) : tn(tn_), s(s_) {
+  // site: 0 = never narrow; 1.. = call site id, narrow when the site's bit is set in the mask (tool build: GH_NT_NARROW)
+  // n_hint: output width of the site's problems -- widths that 160-column blocks cover with less padding than 320-column
+  // blocks (h = 768: 800 against 960 computed columns) take the narrow tile at every site (configs[4] in fp32: 26.1 -> 28.4 K pairs/s)
+  Batch(bool tn_, int rows_hint, hipStream_t s_, bool wide_bf16 = false, int site = 0, int n_hint = 0) : tn(tn_), s(s_) {
     const Workspace w = workspace_for(s_);
     g_ws = w.p; g_ws_bytes = w.bytes;
     static int force_small = -1;
@@ -467,6 +476,10 @@ struct Batch {
     static int tile256 = -1;
     if (tile256 < 0) tile256 = measure_env("GH_BF16_TILE", 0) == 256 ? 1 : 0;
     if (wide && tile256 && rows_hint >= 32768) { wide256 = true; bm = 256; }
+    static int narrow_mask = -1;
+    if (narrow_mask < 0) narrow_mask = measure_env("GH_NT_NARROW", NARROW_DEFAULT);
+    const bool less_pad = n_hint > 0 && (n_hint + 159) / 160 * 160 < (n_hint + 319) / 320 * 320;
+    if (site > 0 && big && !tn_ && !wide && g_gemm_mode == 0 && (((narrow_mask >> (site - 1)) & 1) || (less_pad && narrow_mask != 0))) { narrow = true; bn = 160; }
     reset();
   }
   void reset() {
@@ -580,6 +593,7 @@ struct Batch {
   }
 
   hipError_t launch_any() {
+    if (narrow && !tn && L.ksplit == 1 && !L.p[0].elt) return launch_cfg<2, 2, 5>(L, tn, s);
     if (big && !tn && L.ksplit == 1 && !L.p[0].elt) {
       // Occupancy-aware tile choice.  The chip holds 768 workgroups of either configuration (3 per CU); a grid of 64-row
       // tiles that ends in a thinly filled last round (e.g. 976 workgroups = 1.27 rounds, the node-compact single-problem
@@ -707,7 +721,7 @@ int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* d
   GH_REQUIRE(score_drop_p >= 0.f && score_drop_p < 1.f, "ggnn_cell_fwd: scorer dropout p=%f not in [0,1)", score_drop_p);
   const bool wide = bf && h % 256 == 0;      // 128 x 256 bf16 tiles cover the width exactly (h = 768)
   {  // xp = dropout(x) Wp^T   (wrapper.py:189-191); embedding rows gathered by the loader, the dropout mask applied to the fragments
-    Batch b(false, M, s, wide);
+    Batch b(false, M, s, wide, 7, h);
     Problem p = gemm_problem(M, h, EPI_STORE, xp, h, x, din, w_p, din, din, ids, bf);
     p.io = bf ? 1 : 0;
     set_dropout(p, 1, din, drop_p, drop_seed);
@@ -734,7 +748,7 @@ int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* d
     GH_CHECK_HIP(hipMemsetAsync((char*)a + (size_t)m_real * h * (bf ? 2 : 4), 0, (size_t)(bf ? 2 : 4) * (size_t)(zend - m_real) * h, s));
   }
   {  // z, r gates (:194-200): [a | xp] . [W?0 | W?1]^T as two K segments
-    Batch b(false, M, s, wide);
+    Batch b(false, M, s, wide, 1, h);
     Problem pz = gemm_problem(M, h, EPI_SIGMOID_Z, z, h, a, h, w_z0, h, h, nullptr, bf);
     pz.io = bf ? 1 : 0;
     add_seg(pz, xp, h, w_z1, h, h);
@@ -749,7 +763,7 @@ int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* d
     GH_CHECK_HIP(b.err);
   }
   {  // h gate and the convex update (:202-206); optionally the GSL word scorer's projection of the result (:167)
-    Batch b(false, M, s, wide && !score_w);
+    Batch b(false, M, s, wide && !score_w, score_w ? 0 : 2, h);      // (the fused scorer projection needs whole rows)
     Problem ph = gemm_problem(M, h, EPI_TANH_H, hh, h, a, h, w_h0, h, h, nullptr, bf);
     ph.io = bf ? 15 : 0; ph.c32 = bf ? out32 : nullptr;
     add_seg(ph, rx, h, w_h1, h, h);
@@ -840,7 +854,7 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
     if (int e = launch_gate_bwd_pre(g, z, hh, xp, dhp, dzp, dxp, (size_t)M * h, s, bf)) return e;
   const bool wide = bf && h % 256 == 0;
   {  // hp = a Wh0^T + (r xp) Wh1^T:  da = dhp Wh0 ; d(r xp) = dhp Wh1 -> drp, dxp += .
-    Batch b(false, M, s, wide);
+    Batch b(false, M, s, wide, 3, h);
     Problem p0 = gemm_problem(M, h, EPI_STORE, da, h, dhp, h, wt_h0, h, h, nullptr, bf);
     Problem p1 = gemm_problem(M, h, EPI_BWD_DRX, drp, h, dhp, h, wt_h1, h, h, nullptr, bf);
     p1.out1 = dxp; p1.in0 = xp; p1.in1 = rr;
@@ -870,7 +884,7 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
     }
   }
   {  // da += dzp Wz0 + drp Wr0 ; dxp += dzp Wz1 + drp Wr1
-    Batch b(false, M, s, wide);
+    Batch b(false, M, s, wide, 4, h);
     Problem p0 = gemm_problem(M, h, EPI_STORE, da, h, dzp, h, wt_z0, h, h, nullptr, bf);
     add_seg(p0, drp, h, wt_r0, h, h);
     p0.accumulate = 1;
@@ -889,7 +903,7 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
   }
   if (dx || next) {  // dx = (dxp Wp) . mask/(1-p)
     GH_REQUIRE(!next || (!bf && din % 4 == 0), "ggnn_cell_bwd: the fused gate head needs the fp32 pipeline and float4-shaped rows");
-    Batch b(false, M, s, wide && din % 256 == 0);
+    Batch b(false, M, s, wide && din % 256 == 0, 5, din);
     Problem p = gemm_problem(M, din, next ? EPI_GATE_PRE : EPI_STORE, next ? next->dhp : dx, din, dxp, h, wt_p, h, h, nullptr, bf);      // dx itself is fp32
     if (next) {      // dx IS the gradient w.r.t. the previous cell's output: write that cell's dhp / dzp / dxp instead of dx
       p.in0 = next->z; p.in1 = next->hh; p.in2 = next->xp; p.out1 = next->dzp; p.out2 = next->dxp;
@@ -1063,7 +1077,7 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
   if (claim_offsets && xl > 0)
     if (int e = gh_seg_sum(du, claim_offsets, du_c, nl, ha, (gh_stream_t)s)) return e;
   if (M > 0 && next) {  // dright (= the gradient of the cell that produced `right`) is consumed by that cell's gate head only:
-    Batch bt(false, M, s);      // g = softmax part (in dright) + dpre W1[:, xl:] goes straight into dhp / dzp / dxp
+    Batch bt(false, M, s, false, 6, dr);      // g = softmax part (in dright) + dpre W1[:, xl:] goes straight into dhp / dzp / dxp
     Problem p = gemm_problem(M, dr, EPI_GATE_PRE, next->dhp, dr, dpre, ha, w1t + (size_t)xl * ha, ha, ha);
     p.gin = dright; p.in0 = next->z; p.in1 = next->hh; p.in2 = next->xp; p.out1 = next->dzp; p.out2 = next->dxp;
     bt.add(p);

@@ -417,6 +417,13 @@ int main(int argc, char** argv) {
   if (argc > 3) { run(atoi(argv[2]), atoi(argv[3]), 600, atoi(argv[1]), false); return 0; }
   if (argc > 2) { run(atoi(argv[2]), 300, 600, atoi(argv[1]), false); return 0; }
   if (argc > 1) { run(96000, 300, 600, atoi(argv[1]), false); return 0; }     // long loop for power / clock sampling
+#ifdef NHALF
+  run(124256, 160, 300, 30, true);
+  run(124256, 160, 600, 30, false);
+  run(192000, 160, 300, 30, false);
+  run(192000, 160, 600, 30, false);
+  return 0;
+#endif
 #ifdef KSWEEP
   run(1000, 300, 300, 2, true);
   run(62128, 300, 300, 30, true);
