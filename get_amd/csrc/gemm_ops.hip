@@ -479,7 +479,10 @@ struct Batch {
     static int narrow_mask = -1;
     if (narrow_mask < 0) narrow_mask = measure_env("GH_NT_NARROW", NARROW_DEFAULT);
     const bool less_pad = n_hint > 0 && (n_hint + 159) / 160 * 160 < (n_hint + 319) / 320 * 320;
-    if (site > 0 && big && !tn_ && !wide && g_gemm_mode == 0 && (((narrow_mask >> (site - 1)) & 1) || (less_pad && narrow_mask != 0))) { narrow = true; bn = 160; }
+    // launches whose 64 x 320 grid would not fill one round of 768 workgroup slots (realistic evidence counts: 14 208 rows = 222
+    // row tiles) get twice the workgroups on 1024 slots: 99.0 -> 102.0 K pairs/s on the Snopes-histogram step at B = 32
+    const bool thin = rows_hint <= 24576;
+    if (site > 0 && big && !tn_ && !wide && g_gemm_mode == 0 && narrow_mask != 0 && (((narrow_mask >> (site - 1)) & 1) || less_pad || thin)) { narrow = true; bn = 160; }
     reset();
   }
   void reset() {
