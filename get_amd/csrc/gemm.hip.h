@@ -71,6 +71,9 @@ struct Problem {
   // elements); io bits say which epilogue streams are bf16: 1 = C, 2 = out1, 4 = in0, 8 = in1; c32 (EPI_TANH_H): also
   // write the fp32 value of out1 there (the cell output the fp32 consumers read)
   int elt; int io; float* c32;
+  // EPI_TANH_H with the fused scorer projection on a COLUMN BLOCK of the row (narrow tile): this block's partial dot product is
+  // ADDED to e[row] (zeroed by the caller; two blocks -> two addends -> the sum does not depend on their order)
+  int e_atomic;
   // EPI_GATE_PRE: optional addend of g (same shape as C), third input stream, third output stream
   const float* gin; const float* in2; float* out2;
 };

@@ -672,7 +672,7 @@ gemm_nt_kernel(const Launch L_byval) {
             if (c32) *reinterpret_cast<float4*>(c32 + o) = y;
             if (scorer) {    // the word scorer sees dropout(out) (its own input dropout, wrapper.py:189-190)
               if (drop_mode == 2)
-                y = drop4(y, drop_seed, (unsigned)row * (unsigned)drop_ld + (unsigned)col, drop_thresh, drop_scale);
+                y = drop4(y, drop_seed, (unsigned)row * (unsigned)drop_ld + (unsigned)(P.drop_col0 + col), drop_thresh, drop_scale);
               *reinterpret_cast<float4*>(sp) = y;
             }
           } else if (E == EPI_BWD_DRX) {
@@ -855,7 +855,10 @@ gemm_nt_kernel(const Launch L_byval) {
         if (row < M) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (4 * q + r < nred) P.e[(size_t)row * nred + 4 * q + r] = sum[r];
+            if (4 * q + r < nred) {
+              if (P.e_atomic) atomicAdd(&P.e[(size_t)row * nred + 4 * q + r], sum[r]);
+              else P.e[(size_t)row * nred + 4 * q + r] = sum[r];
+            }
         }
       }
     }

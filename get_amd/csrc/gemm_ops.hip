@@ -494,7 +494,9 @@ struct Batch {
   }
 
   void add(const Problem& p) {
-    if ((p.epi == EPI_ATT || (p.epi == EPI_TANH_H && p.w2)) && p.N > bn) { err = hipErrorInvalidValue; return; }   // row reductions need whole rows
+    // row reductions need whole rows -- except the scorer's single dot product, which two column blocks may add up (e_atomic)
+    const bool scorer_blocks = p.epi == EPI_TANH_H && p.w2 && p.N > bn && narrow && p.N <= 2 * bn;
+    if ((p.epi == EPI_ATT || (p.epi == EPI_TANH_H && p.w2)) && p.N > bn && !scorer_blocks) { err = hipErrorInvalidValue; return; }
     for (int n0 = 0; n0 < p.N; n0 += bn) {
       Problem q = p;
       q.N = (p.N - n0 < bn) ? p.N - n0 : bn;
@@ -519,6 +521,7 @@ struct Batch {
       if (q.gin) q.gin += n0;
       if (q.in2) q.in2 += n0;
       if (q.out2) q.out2 += n0;
+      if (scorer_blocks) { q.w2 += n0; q.e_atomic = 1; }
       if (L.nprob == GH_MAX_PROBLEMS) flush();
       L.p[L.nprob++] = q;
       const int mt = (q.M + bm - 1) / bm;
@@ -766,7 +769,11 @@ int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* d
     GH_CHECK_HIP(b.err);
   }
   {  // h gate and the convex update (:202-206); optionally the GSL word scorer's projection of the result (:167)
-    Batch b(false, M, s, wide && !score_w, score_w ? 0 : 2, h);      // (the fused scorer projection needs whole rows)
+    Batch b(false, M, s, wide && !score_w, 2, h);
+    if (score_w && b.narrow) {
+      if (h > 2 * b.bn) { b.narrow = false; b.bn = 320; }      // more than two column blocks: whole rows on the 320-wide tile
+      else if (h > b.bn) GH_CHECK_HIP(hipMemsetAsync(score_x, 0, sizeof(float) * (size_t)M, s));   // two blocks add their partial dot products
+    }
     Problem ph = gemm_problem(M, h, EPI_TANH_H, hh, h, a, h, w_h0, h, h, nullptr, bf);
     ph.io = bf ? 15 : 0; ph.c32 = bf ? out32 : nullptr;
     add_seg(ph, rx, h, w_h1, h, h);

@@ -2,7 +2,7 @@
 # Evidence run behind profiles/r03_*: bench line, rocprofv3 kernel stats, the separate --pmc passes, the other BASELINE
 # configs, the step timeline, the 2-rank rehearsal (GPU box, repo root).  usage: tools/collect_r03.sh
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03; mkdir -p $O
+O=gpurun_out/r03; rm -rf $O; mkdir -p $O
 [ -f tools/_commit.txt ] && cp tools/_commit.txt $O/commit.txt
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench_err.log
 tail -c 300 $O/bench_line.json
