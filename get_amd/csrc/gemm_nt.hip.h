@@ -60,7 +60,7 @@ __device__ __forceinline__ unsigned nt_pack_bf16(float a, float b) {
 //         opt-in and experimental.  Upper bound with the weight pieces pre-split once per optimiser step (measured by feeding the
 //         raw fragment bits as "pieces", results invalid): 130.8 / 151.0 / 184.3 TF at K = 300 / 600 / 1200.
 template <int WM, int WN, int NI, int MI = 2, int MODE = 0>
-__global__ void __launch_bounds__(WM * WN * 64, (MI == 4 || MODE == 3 || MODE == 4) ? 2 : (WM == 2 && WN == 2 && NI == 5 && MODE == 0) ? 4 : 3)
+__global__ void __launch_bounds__(WM * WN * 64, (MI == 4 && NI == 4) ? 3 : (MI == 4 || MODE == 3 || MODE == 4) ? 2 : (WM == 2 && WN == 2 && NI == 5 && MODE == 0) ? 4 : 3)
 gemm_nt_kernel(const Launch L_byval) {
   (void)L_byval;
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -112,6 +112,13 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
       if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 2, 8, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); attr = true; }
       hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 8, 4, 2>), dim3(grid), dim3(256), kLds, s, L);
       launched = true;
+    } else if constexpr (WM == 2 && WN == 2 && NI == 4 && MI == 4) {      // 128 x 128 tile, three workgroups per CU (NT only)
+      if (tn) return hipErrorInvalidValue;
+      constexpr int kLds = 3 * (128 + 128) * 64;
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 2, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); attr = true; }
+      hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 4, 4, 2>), dim3(grid), dim3(256), kLds, s, L);
+      launched = true;
     } else if constexpr (WM == 4 && WN == 2 && NI == 8 && MI == 4) {      // 256 x 256 tile, 8 waves (NT only)
       if (tn) return hipErrorInvalidValue;
       constexpr int kLds = 4 * (256 + 256) * 64;          // four K-loop stages
@@ -455,6 +462,7 @@ struct Batch {
   bool narrow = false;
   bool wide = false;      // 128 x 256 bf16 tile (launch_cfg<2, 2, 8, 4>)
   bool wide256 = false;   // 256 x 256 bf16 tile, 8 waves (launch_cfg<4, 2, 8, 4>)
+  bool wide128 = false;   // 128 x 128 bf16 tile, three workgroups per CU (launch_cfg<2, 2, 4, 4>; tool build: GH_BF16_TILE=128)
   // wide_bf16: every problem of this batch is a bf16-storage NT problem whose widths are multiples of 256 (h = 768)
   // site: 0 = never narrow; 1.. = call site id, narrow when the site's bit is set in the mask (tool build: GH_NT_NARROW)
   // n_hint: output width of the site's problems -- widths that 160-column blocks cover with less padding than 320-column
@@ -476,6 +484,9 @@ struct Batch {
     static int tile256 = -1;
     if (tile256 < 0) tile256 = measure_env("GH_BF16_TILE", 0) == 256 ? 1 : 0;
     if (wide && tile256 && rows_hint >= 32768) { wide256 = true; bm = 256; }
+    static int tile128 = -1;
+    if (tile128 < 0) tile128 = measure_env("GH_BF16_TILE", 0) == 128 ? 1 : 0;
+    if (wide && tile128) { wide128 = true; bn = 128; }
     static int narrow_mask = -1;
     if (narrow_mask < 0) narrow_mask = measure_env("GH_NT_NARROW", NARROW_DEFAULT);
     const bool less_pad = n_hint > 0 && (n_hint + 159) / 160 * 160 < (n_hint + 319) / 320 * 320;
@@ -616,6 +627,7 @@ struct Batch {
       }
     }
     if (wide256) return launch_cfg<4, 2, 8, 4>(L, tn, s);
+    if (wide128) return launch_cfg<2, 2, 4, 4>(L, tn, s);
     if (wide) return launch_cfg<2, 2, 8, 4>(L, tn, s);
     return big ? launch_cfg<2, 2, 10>(L, tn, s) : launch_cfg<1, 4, 5>(L, tn, s);
   }
