@@ -26,6 +26,10 @@ timeout 600 python bench.py $C4 --gemm-mode bf16 > $O/cfg4_bf16_bench_line.json 
 # opt-in fp32x3 with pre-split weights: bench line with its kernel table, and the isolated GEMM rates of the three arithmetic modes
 timeout 600 python bench.py --gemm-mode fp32x3p --no-cpu-baseline --no-series --no-side-modes > $O/bench_fp32x3p.json 2>> $O/bench_err.log
 for m in fp32 fp32x3 fp32x3p; do echo "== GEMM_MODE=$m"; GEMM_MODE=$m timeout 200 python tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids; done > $O/gemm_bench_modes.txt
+# gradient all-reduce through the library's own RCCL communicator (world size 1 here), and the aggregation micro-benchmark with
+# its per-phase timing (tool build)
+timeout 600 python bench.py --collective library --no-cpu-baseline --no-series --no-side-modes 2>> $O/bench_err.log | grep '^{' > $O/bench_collective_library.json
+[ -f get_amd/lib/libget_hip_measure.so ] && GET_AMD_LIB=$GRAFT_REPO_ROOT/get_amd/lib/libget_hip_measure.so timeout 300 python tools/spmm_bench.py 2>&1 | grep -v amdgpu.ids > $O/spmm_bench.txt
 # N > 1 code path on the 1-GPU box: bench.py spawns its own 2 ranks (gloo, ranks share the device)
 GET_AMD_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 > $O/bench_2rank_gloo.json 2> $O/bench_2rank.err
 GET_AMD_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 --global-batch 64 --evd-dist snopes > $O/bench_2rank_gloo_gb64_snopes.json 2>> $O/bench_2rank.err
