@@ -181,7 +181,8 @@ class StreamedBatches:
         from get_amd.batch import NativeBatch
         raw = self.raws[self.i % len(self.raws)]
         self.i += 1
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        # (no wait on the caller's stream: the next batch depends on nothing the step computes -- ordering the loader stream
+        #  behind the step made the 4-byte read-back below wait for the WHOLE step, so the host could never run ahead)
         with torch.cuda.stream(self.stream):
             nb = NativeBatch(raw["claim_tokens"], raw["claim_len"], raw["evd_tokens"], raw["evd_len"], raw["evd_counts"],
                              raw["doc_sources"], raw["query_sources"], raw["labels"], window=self.cfg.window,

@@ -173,3 +173,11 @@ def test_composite_descriptor_mirrors_and_buffer_plan(lib_path):
     # arena size classes: at most 1/8 above the request for large sizes
     f = fused._arena_floats
     assert f(1000) == 1000 and all(n <= f(n) <= n * 1.125 + 1 for n in (10 ** 8, 4 * 10 ** 8, 3 * 10 ** 9))
+
+
+def test_driver_build_entry_point_runs(lib_path):
+    """__graft_entry__.build() is what the driver calls every round: it must agree with the library's ABI version (it once
+    hard-coded the previous one and failed after a bump)."""
+    import importlib
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
