@@ -1,10 +1,11 @@
 #!/bin/bash
 # configs[3]'s global batch on ONE GPU (the N = 1 point of the strong-scaling curve) and a per-GPU batch sweep.
+# (12 warm-up steps: at these sizes the first steps of a fresh process include allocator growth; with the default 5 the first timed block was up to 20x slow)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03; mkdir -p $O
 for args in "--global-batch 256" "--global-batch 256 --evd-dist snopes" "--batch 64" "--batch 128" "--batch 64 --evd-dist snopes" "--batch 256 --evd-dist snopes"; do
   n=$(echo $args | tr -d ' -' )
-  timeout 900 python bench.py $args --no-cpu-baseline --no-series --no-side-modes --no-profile > $O/sweep_$n.json 2> $O/sweep_$n.err
+  timeout 900 python bench.py $args --steps 10 --warmup 12 --no-cpu-baseline --no-series --no-side-modes --no-profile > $O/sweep_$n.json 2> $O/sweep_$n.err
   python - <<P
 import json
 try:
