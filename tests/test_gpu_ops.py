@@ -507,6 +507,44 @@ def test_compact_spmm_equals_padded(h):
         assert torch.equal(yc, plan.from_padded(yp, plan.m_real))           # same neighbours, same order: bit-exact
 
 
+@pytest.mark.parametrize("n_graphs", [9, 300])
+def test_spmm_hub_rows_split_over_work_items_match_dense_fp64(n_graphs):
+    """Word graphs with a hub node (a token at every third position: degree ~2/3 of the nodes).  In the node-compact layout
+    the aggregation kernel cuts such rows into 8-edge groups handled by separate work items whose partial sums meet in the
+    slab image's free rows (csrc/graph_ops.hip); the result must match a dense float64 product, the padded layout (which
+    never splits) bit for bit, and the backward (transposed, accumulating launch) through autograd.  300 graphs: the
+    one-workgroup-per-graph launch mode; 9: one slab per workgroup."""
+    from get_amd import ops
+    rng = np.random.default_rng(77)
+    n, r, h = n_graphs, 100, 300
+    toks = rng.integers(100, 5000, size=(n, r)).astype(np.int32)
+    for g in range(n):
+        toks[g, ::3] = 7 + (g % 3)                       # the hub token
+        if g % 4 == 1:
+            toks[g, 1::6] = 50                           # a second, mid-degree hub
+    lens = np.full((n,), r, np.int32)
+    lens[0] = 40                                         # a short text: few nodes, many free rows
+    padj, node_ids, n_nodes = ops.graph_build(T(toks), T(lens), 3)
+    nn = n_nodes.cpu().numpy()
+    dense = padj.to_dense()
+    deg = (dense != 0).sum(-1).max(-1).values.cpu().numpy()
+    assert deg.max() >= 40 and nn.max() < r, "fixture: hub rows and free rows are both present"
+    plan = ops.RaggedPlan(n_nodes, node_ids, int(nn.sum()))
+    x = T(rng.standard_normal((n, r, h)).astype(np.float32))
+    keep = ops.gsl_topk(T(rng.standard_normal((n, r)).astype(np.float32)), 60)
+    for a in (padj, padj.with_keep(keep)):
+        xc = plan.from_padded(x, plan.m_real).requires_grad_(True)
+        yc = ops.spmm(a, xc, plan)
+        yp = ops.spmm(a, x)
+        assert torch.equal(yc.detach(), plan.from_padded(yp, plan.m_real))          # same groups, same order: bit-exact
+        ref = torch.matmul(a.to_dense().double(), x.double())
+        assert float((plan.from_padded(ref, plan.m_real) - yc.detach().double()).abs().max()) <= 2e-5
+        gy = T(rng.standard_normal(tuple(yc.shape)).astype(np.float32))
+        yc.backward(gy)
+        gref = torch.matmul(a.to_dense().double().transpose(1, 2), plan.to_padded(gy).double())
+        assert float((plan.from_padded(gref, plan.m_real) - xc.grad.double()).abs().max()) <= 2e-5
+
+
 def test_compact_cell_with_dropout_vs_oracle():
     """Cell on the node-compact layout, training-mode dropout on: forward over ALL rows (padding rows included),
     backward over the real rows; the stateless mask is indexed by the compact row."""
