@@ -16,7 +16,7 @@ dev = "cuda:0"
 rng = np.random.default_rng(0)
 toks, lens = make_tokens(rng, 960, 100, 20000, 100, 100)
 adj, ids, _ = ops.graph_build(torch.from_numpy(toks).to(dev), torch.from_numpy(lens).to(dev), 3)
-cell = modules.GGNN(300, 300, dropout=0.0).to(dev)
+cell = modules.GGNN(300, 300, dropout=float(os.environ.get("CELL_DROPOUT", "0.0"))).to(dev)
 x = torch.randn(960, 100, 300, device=dev, requires_grad=True)
 g = torch.randn(960, 100, 300, device=dev)
 for _ in range(2):
