@@ -381,7 +381,7 @@ spmm_wave_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
 // neighbour is one 8-byte list read, one address mad and CPT x (ds_read_b128 + 4 FMA).  Graphs whose edge count
 // exceeds the list capacity (dense hand-overs) fall back to the bit walk inside the same kernel.
 #ifdef GH_MEASURE
-__device__ unsigned g_spmm_phase[8192 * 8];     // tool build: s_memtime ticks (10 ns) per phase and workgroup (thread 0)
+__device__ unsigned g_spmm_phase[8192 * 8];     // tool build: s_memtime ticks per phase and workgroup (thread 0); ~0.5 ns per tick on the box (calibrated on the kernel time)
 #define SPMM_T(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x < 8192) g_spmm_phase[blockIdx.x * 8 + i] = (unsigned)(t_ - tprev_); tprev_ = t_; } } while (0)
 #else
 #define SPMM_T(i) do { } while (0)

@@ -64,9 +64,10 @@ try:      # tool build: per-phase ticks of the list kernel (thread 0 of every wo
     _lib.call("gh_spmm", *adj._args(), goff.data_ptr(), m_real, xc.data_ptr(), yc.data_ptr(), n, r, h, 0, 0, _lib.stream())
     torch.cuda.synchronize()
     L.gh_debug_spmm_phases(buf, 1)
-    a = np.frombuffer(buf, dtype=np.uint32).reshape(8192, 8)[:n * 4, :7].astype(np.float64) * 0.01
+    a = np.frombuffer(buf, dtype=np.uint32).reshape(8192, 8)[:, :7].astype(np.float64)
+    a = a[a.sum(1) > 0]                     # workgroups that ran (one per graph, or one per slab with GH_SPMM_SPW=1)
     names = ["issue", "rowwords+scan", "barrier1", "listbuild", "slabwait", "barrier2", "aggregate"]
-    print("phases, thread 0 of each workgroup, us (mean / p90): " + ", ".join(f"{nm} {a[:, i].mean():.2f}/{np.percentile(a[:, i], 90):.2f}" for i, nm in enumerate(names)) + f"  total {a.sum(1).mean():.2f}")
+    print(f"phases, thread 0 of each of {a.shape[0]} workgroups, s_memtime ticks (~0.5 ns; with several slabs per workgroup the slab phases hold the LAST slab), mean / p90: " + ", ".join(f"{nm} {a[:, i].mean():.2f}/{np.percentile(a[:, i], 90):.2f}" for i, nm in enumerate(names)) + f"  total {a.sum(1).mean():.2f}")
 except Exception as e:
     print("no phase instrumentation:", e)
 ms = timeit(lambda: y.copy_(x))
