@@ -627,6 +627,10 @@ def main():
     model, cfg = wl["model"], wl["cfg"]
     lib_comm = None
     if args.collective == "library":
+        if world > 1 and torch.cuda.device_count() < world:
+            sys.stderr.write(f"bench.py: --collective library builds an RCCL communicator with one device per rank; {world} ranks "
+                             f"on {torch.cuda.device_count()} visible GPU(s) cannot (RCCL rejects duplicate devices)\n")
+            sys.exit(3)
         from get_amd.dist import LibComm
         lib_comm = LibComm.from_process_group(device=device) if world > 1 else LibComm.single(device)
         backend = f"library-owned RCCL communicator ({lib_comm.library}); rendezvous over torch.distributed {backend}" if world > 1 \
