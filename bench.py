@@ -319,6 +319,10 @@ def cpu_baseline_probe(wl, budget_s=8.0, claims=2):
 
 MIN_TIMED_SECONDS = 2.0        # the K-step block is repeated until the timed region is at least this long
 MAX_TIMED_BLOCKS = 64
+MIN_TIMED_BLOCKS = 5           # a median over fewer blocks is a mean in disguise
+SETTLE_REL = 0.02              # untimed settle blocks until two consecutive ones agree within this ...
+MAX_SETTLE_BLOCKS = 8          # ... or this many have run
+UNSTABLE_SPREAD = 0.10         # a leg whose timed blocks spread more than this is flagged, not trusted
 
 
 def make_step(args, wl, trainer, source="resident"):
@@ -362,10 +366,14 @@ def make_step(args, wl, trainer, source="resident"):
 
 def measure(args, wl, trainer, world, device, dist, steps, warmup, profile=True, source="resident",
             min_seconds=MIN_TIMED_SECONDS):
-    """W warm-up steps, then blocks of EXACTLY K timed steps, each block bracketed by barrier + synchronize on both sides
-    and reduced with MAX over the ranks; the block is repeated until the timed region covers `min_seconds` (the number
-    of repeats is fixed from the first block's duration, identically on every rank).  Returns a dict: the per-block
-    seconds, the pairs this rank processed per block, the last loss, the dominant-kernel profile row and the step fn."""
+    """W warm-up steps, then UNTIMED settle blocks of K steps until two consecutive blocks agree within SETTLE_REL (at most
+    MAX_SETTLE_BLOCKS: a fresh model / batch source still pays allocator, workspace and pinned-buffer warm-up in its first
+    blocks, and a cold block averaged into two or three warm ones is what made round 3's side legs print 91 K beside a
+    6.17 ms step), then blocks of EXACTLY K timed steps, each bracketed by barrier + synchronize on both sides and reduced
+    with MAX over the ranks.  The number of timed blocks comes from the LAST (warm) settle block, identically on every rank
+    (its duration is already the MAX over ranks): enough for `min_seconds`, never fewer than MIN_TIMED_BLOCKS.
+    Returns a dict: the per-block seconds, the pairs this rank processed per block, the settle blocks, the last loss, the
+    dominant-kernel profile row and the step fn."""
     from get_amd import _lib
     step, pairs_fn = make_step(args, wl, trainer, source)
 
@@ -381,9 +389,28 @@ def measure(args, wl, trainer, world, device, dist, steps, warmup, profile=True,
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def block(hook=None):
+        barrier()
+        t0 = time.perf_counter()
+        out = None
+        for i in range(steps):
+            if hook is not None:
+                hook(i)
+            out = step()
+        barrier()
+        return rank_max(time.perf_counter() - t0), out
+
     for _ in range(warmup):
         step()
+    settle = []
+    while len(settle) < MAX_SETTLE_BLOCKS:
+        dt, _ = block()
+        settle.append(dt)
+        if len(settle) >= 2 and abs(settle[-1] - settle[-2]) <= SETTLE_REL * min(settle[-1], settle[-2]):
+            break
     pairs_fn()
+    warm_dt = min(settle[-2:]) if len(settle) >= 2 else settle[-1]
+    n_blocks = int(min(MAX_TIMED_BLOCKS, max(MIN_TIMED_BLOCKS, np.ceil(min_seconds / max(warm_dt, 1e-6)))))
     prof_dom = None
     # live roofline of the dominant kernel: HIP events around each of its launches in the FIRST `prof_steps` timed steps
     # of the first block (an event pair between two kernels costs ~10 us of dispatch overlap: 0.4 % of those steps)
@@ -392,28 +419,19 @@ def measure(args, wl, trainer, world, device, dist, steps, warmup, profile=True,
         _lib.profile_enable(True, only=[DOMINANT])
         _lib.profile_collect()
     blocks, block_pairs = [], []
-    n_blocks = 1
     loss = None
-    b = 0
-    while b < n_blocks:
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            if profile and b == 0 and i == prof_steps:
-                _lib.profile_enable(False)       # host-side switch, no device work
-            loss = step()
-        barrier()
-        dt = rank_max(time.perf_counter() - t0)
+    for b in range(n_blocks):
+        hook = None
+        if profile and b == 0:
+            hook = lambda i: _lib.profile_enable(False) if i == prof_steps else None      # host-side switch, no device work
+        dt, loss = block(hook)
         blocks.append(dt)
         block_pairs.append(pairs_fn())
-        if b == 0:
-            if profile:
-                prof_dom = _lib.profile_collect()[DOMINANT]
-                prof_dom["steps"] = prof_steps
-                _lib.profile_enable(False)
-            n_blocks = int(min(MAX_TIMED_BLOCKS, max(1, np.ceil(min_seconds / max(dt, 1e-6)))))
-        b += 1
-    return {"blocks_s": blocks, "block_pairs": block_pairs, "loss": loss, "prof_dom": prof_dom, "step": step}
+        if b == 0 and profile:
+            prof_dom = _lib.profile_collect()[DOMINANT]
+            prof_dom["steps"] = prof_steps
+            _lib.profile_enable(False)
+    return {"blocks_s": blocks, "block_pairs": block_pairs, "settle_s": settle, "loss": loss, "prof_dom": prof_dom, "step": step}
 
 
 def phase_split(wl, trainer, steps=5):
@@ -474,6 +492,7 @@ def parity_check(wl, k=4):
 
 
 DOMINANT = "gemm_big"
+STRONG_GLOBAL_BATCH = 256         # BASELINE configs[3]
 PROFILE_TIMED_STEPS = 5           # timed steps whose dominant-kernel launches carry HIP events
 
 
@@ -505,17 +524,33 @@ def spawn_ranks(n_gpus: int) -> int:
 
 
 def summarize_blocks(m, steps, world_pairs_per_block):
-    """Median block -> value / ms_per_step; spread over the blocks."""
+    """value = median over the blocks of (pairs / seconds); ms_per_step = median block seconds / steps; spread over the
+    blocks; `unstable` when the blocks spread more than UNSTABLE_SPREAD (such a leg is a warm-up artefact, not a rate)."""
     secs = np.asarray(m["blocks_s"], dtype=np.float64)
     rates = np.asarray(world_pairs_per_block, dtype=np.float64) / secs
     med = float(np.median(rates))
-    k = int(np.argmin(np.abs(rates - med)))
-    return {"value": med, "ms_per_step": 1e3 * float(secs[k]) / steps,
-            "timed": {"blocks": int(len(secs)), "steps_per_block": int(steps), "seconds_total": float(secs.sum()),
-                      "pairs_per_s_min": float(rates.min()), "pairs_per_s_median": med, "pairs_per_s_max": float(rates.max()),
-                      "spread_rel": float((rates.max() - rates.min()) / med) if med > 0 else None,
-                      "note": f"the {steps}-step block (barrier + synchronize on both sides, MAX over ranks) is repeated "
-                              f"until >= {MIN_TIMED_SECONDS:g} s are timed; value = median block"}}
+    spread = float((rates.max() - rates.min()) / med) if med > 0 else None
+    timed = {"blocks": int(len(secs)), "steps_per_block": int(steps), "seconds_total": float(secs.sum()),
+             "pairs_per_s_min": float(rates.min()), "pairs_per_s_median": med, "pairs_per_s_max": float(rates.max()),
+             "spread_rel": spread, "settle_blocks_untimed": int(len(m.get("settle_s", []))),
+             "settle_block_ms_per_step": [round(1e3 * float(x) / steps, 4) for x in m.get("settle_s", [])],
+             "note": f"after the warm-up steps, untimed {steps}-step settle blocks run until two consecutive ones agree within "
+                     f"{SETTLE_REL:.0%} (<= {MAX_SETTLE_BLOCKS}); then the {steps}-step block (barrier + synchronize on both sides, "
+                     f"MAX over ranks) is timed >= {MIN_TIMED_BLOCKS} times and until >= {MIN_TIMED_SECONDS:g} s; value = median block"}
+    if spread is not None and spread > UNSTABLE_SPREAD:
+        timed["unstable"] = True
+    return {"value": med, "ms_per_step": 1e3 * float(np.median(secs)) / steps, "timed": timed}
+
+
+def leg_summary(s):
+    """The fields every side leg prints: rate, step time, and the block statistics behind them."""
+    t = s["timed"]
+    out = {"pairs_per_s": s["value"], "ms_per_step": s["ms_per_step"],
+           "timed": {k: t[k] for k in ("blocks", "steps_per_block", "seconds_total", "pairs_per_s_min", "pairs_per_s_median",
+                                       "pairs_per_s_max", "spread_rel", "settle_blocks_untimed", "settle_block_ms_per_step")}}
+    if t.get("unstable"):
+        out["unstable"] = True
+    return out
 
 
 def main():
@@ -554,6 +589,8 @@ def main():
                     help="who carries the gradient all-reduce: torch.distributed (default; backend nccl = RCCL) or the library's own "
                          "RCCL communicator (gh_comm_init / gh_flat_allreduce, include/get_hip.h); with --gpus 1 the library route "
                          "runs a world-size-1 communicator so that the collective is issued and timed on the device")
+    ap.add_argument("--no-strong", dest="strong_too", action="store_false",
+                    help="skip the strong-scaling leg (configs[3]: global batch 256 split over the ranks) printed beside the weak line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-series", action="store_true", help="skip the realistic evidence-count series")
@@ -667,6 +704,37 @@ def main():
     world_pairs = [float(x) for x in bp[:-1].tolist()]
     total_claims_block = float(bp[-1].item())
 
+    # configs[3] in the same launch: ONE global batch of STRONG_GLOBAL_BATCH claims dealt over the ranks by sort-then-stripe
+    # (256 / N claims per GPU), its own model replica and trainer, same step.  Every rank takes part (the
+    # gradient all-reduce and the block barriers are collectives); the weak-scaling figure above stays `value`.
+    strong = None
+    if (args.strong_too and not args.no_side_modes and args.global_batch <= 0 and not args.forward_only and args.gemm_mode == "fp32" and
+            STRONG_GLOBAL_BATCH % world == 0):
+        gshard = (lambda counts: shard_claims(STRONG_GLOBAL_BATCH, rank, world, counts))
+        cfg_s = SynthConfig(**{**cfg_in.__dict__, "batch": STRONG_GLOBAL_BATCH})
+        wls = build_workload(seed=SEED, device=device, cfg=cfg_s, compact=False if args.padded else None, n_batches=2,
+                             evd_dist=args.evd_dist, model_seed=SEED, claim_shard=gshard)
+        tr_s = FlatTrainer(wls["model"], lr=1e-4, weight_decay=1e-3, comm=lib_comm, always_reduce=lib_comm is not None)
+        ops.bump_weight_epoch()
+        if world > 1:
+            tr_s.broadcast_parameters(0)
+            tr_s.attach_overlap()
+        wls["model"].train(not args.eval_mode)
+        k_s = max(2, args.steps // (4 if world == 1 else 2))
+        m_s = measure(args, wls, tr_s, world, device, dist, k_s, 2, profile=False, min_seconds=1.0)
+        bps = torch.tensor(m_s["block_pairs"], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(bps, op=dist.ReduceOp.SUM)
+        s_s = summarize_blocks(m_s, k_s, [float(x) for x in bps.tolist()])
+        strong = {**leg_summary(s_s), "scaling": "strong", "global_batch_claims": STRONG_GLOBAL_BATCH, "n_gpus": world,
+                  "claims_per_gpu": wls["cfg"].batch, "pairs_this_rank": wls["b1"],
+                  "sharding": "sort-then-stripe by evidence count (dist.shard_claims)",
+                  "what": f"BASELINE configs[3]: the SAME global batch of {STRONG_GLOBAL_BATCH} claims at every N, "
+                          f"{STRONG_GLOBAL_BATCH}/N claims per GPU, gradients averaged over the ranks (pairs_per_s is whole-job)"}
+        del wls, tr_s, m_s
+        ops.bump_weight_epoch()
+        torch.cuda.empty_cache()
+
     headline_run = (args.len_right, args.hidden, args.word_heads, args.window, args.gsl_rate, args.n_evd, args.evd_dist) == \
                    (100, 300, 5, 3, 0.6, 30, "fixed") and per_rank == 32 and args.gemm_mode == "fp32" and not args.padded \
                    and not args.eval_mode and not args.forward_only
@@ -769,6 +837,8 @@ def main():
             out["kernels"] = kernels
         if split is not None:
             out["step_split_ms"] = split
+        if strong is not None:
+            out["strong_scaling"] = strong
         if not args.no_profile and world == 1:
             out["box_reference"] = box_reference(device)
     default_side = (world == 1 and headline_run and not args.no_side_modes and not args.no_series)
@@ -786,7 +856,7 @@ def main():
                          min_seconds=1.0)
             sr = summarize_blocks(mr, max(4, args.steps // 2), mr["block_pairs"])
             hb = wl["ref_batches"][0].bytes_handed_over
-            extra["reference_api"] = {"pairs_per_s": sr["value"], "ms_per_step": sr["ms_per_step"],
+            extra["reference_api"] = {**leg_summary(sr),
                                       "bytes_handed_over_per_step": hb,
                                       "pairs_per_s_if_shipped_over_pcie_63GBps": wl["ref_batches"][0].b1 / (sr["ms_per_step"] * 1e-3 + hb / 63e9),
                                       "what": "dense float64 (B,n,R,R) adjacency + padded ids resident in HBM -> kargs_from_reference_tensors "
@@ -799,7 +869,7 @@ def main():
             wl["streamed"] = StreamedBatches(raws8, cfg, device, wl["compact"])
             ms_ = measure(args, wl, trainer, 1, device, dist, args.steps, 3, profile=False, source="streamed", min_seconds=1.0)
             ss = summarize_blocks(ms_, args.steps, ms_["block_pairs"])
-            extra["streamed"] = {"pairs_per_s": ss["value"], "ms_per_step": ss["ms_per_step"],
+            extra["streamed"] = {**leg_summary(ss),
                                  "what": "a NEW NativeBatch per step from host numpy arrays: one pinned staging buffer -> one H2D copy, "
                                          "device graph build for the node count, 4-byte m_real read-back; prepared one batch ahead "
                                          "on a side stream while the previous step runs (8 distinct host batches rotated)"}
@@ -813,7 +883,7 @@ def main():
             try:
                 mx = measure(args, wl, trainer, 1, device, dist, args.steps, 4, profile=False, min_seconds=1.0)
                 sx = summarize_blocks(mx, args.steps, mx["block_pairs"])
-                extra["fp32x3p"] = {"pairs_per_s": sx["value"], "ms_per_step": sx["ms_per_step"],
+                extra["fp32x3p"] = {**leg_summary(sx),
                                     "what": "gh_set_gemm_mode(3): fp32-equivalent products from pre-split bf16 weight pieces on "
                                             "v_mfma_f32_16x16x32_bf16 in the big-tile NT launches; weight-gradient GEMMs and all "
                                             "small GEMMs stay on the fp32 MFMA; NOT the headline (not bit-identical to fp32 MFMA)"}
@@ -835,9 +905,8 @@ def main():
                 S_W, S_K = 8, 32        # (3 + 10 steps were too few for a fresh model: allocator / workspace warm-up leaked in)
                 m2 = measure(args, w2, t2, 1, device, dist, S_K, S_W, profile=False, min_seconds=1.0)
                 s2 = summarize_blocks(m2, S_K, m2["block_pairs"])
-                series.append({"claims": bsz, "pairs_per_step": w2["b1"], "pairs_per_s": s2["value"],
-                               "claims_per_s": s2["value"] * bsz / w2["b1"], "ms_per_step": s2["ms_per_step"],
-                               "blocks": s2["timed"]["blocks"], "spread_rel": s2["timed"]["spread_rel"]})
+                series.append({"claims": bsz, "pairs_per_step": w2["b1"], **leg_summary(s2),
+                               "claims_per_s": s2["value"] * bsz / w2["b1"]})
                 del w2, t2
             ops.bump_weight_epoch()
             out["realistic_series"] = {"evidence_counts": "empirical Snopes histogram (get_amd.synth.SNOPES_EVD_HIST, mean 6.9, max 26)",

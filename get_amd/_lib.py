@@ -19,7 +19,7 @@ _I = ctypes.c_int
 _F = ctypes.c_float
 _L = ctypes.c_int64
 _U = ctypes.c_uint32
-ABI_VERSION = 6          # GH_ABI_VERSION of include/get_hip.h
+ABI_VERSION = 7          # GH_ABI_VERSION of include/get_hip.h
 
 # name -> argtypes (mirrors include/get_hip.h; tests/test_abi.py checks the two agree)
 SIGNATURES = {
@@ -63,8 +63,8 @@ SIGNATURES = {
     "gh_fp32x3_clear": [],
     # composite entry points (get_amd/fused.py holds the ctypes mirrors of the descriptor structs)
     "gh_get_plan_buffers": [_P, _P, _P],
-    "gh_get_forward": [_P, _P, _P, _P, _P],
-    "gh_get_backward": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
+    "gh_get_forward": [_P, _P, _P, _P, _P, _P],
+    "gh_get_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
     "gh_cross_entropy": [_P, _P, _I, _I, _P, _P, _P],
     "gh_get_prepare": [_P, _P, _I, _I, _P, _P, _I, _I, _I] + [_P] * 8 + [_I] + [_P] * 5 + [_P, _P, _P],
     "gh_get_struct_sizes": [_P],

@@ -34,7 +34,9 @@ class NativeBatch:
         self.window, self.n_max, self.device = int(window), int(n_max), dev
         self._counts_host = counts_host
         self.b, self.b1 = int(counts_host.shape[0]), int(counts_host.sum())
-        assert counts_host.max(initial=0) <= self.n_max
+        if counts_host.min(initial=0) < 0 or counts_host.max(initial=0) > self.n_max:
+            raise ValueError(f"NativeBatch: evidence counts must lie in [0, n_max={self.n_max}], got "
+                             f"[{int(counts_host.min(initial=0))}, {int(counts_host.max(initial=0))}]")
         # slot of every pair inside the (B, n_max, R) padded evidence tensor -- host arithmetic, done once
         offs = np.concatenate([[0], np.cumsum(counts_host)])[:-1]
         p2c = np.repeat(np.arange(self.b), counts_host)
@@ -72,7 +74,9 @@ class NativeBatch:
             self.doc_sources, self.query_sources, self.labels = t(doc_sources), t(query_sources), t(labels)
             self._slot = t(slot)
         assert self.evd_tokens.shape[0] == self.b1, "evd_tokens must hold sum(evd_counts) rows"
-        self.counts._gh_fit = True        # every count <= n_max (asserted above): the backward needs no zero fill of unmapped rows
+        # every count <= n_max (checked above): the backward needs no zero fill of unmapped rows.  The promise is tied to the
+        # tensor's version counter: an in-place edit of `counts` afterwards voids it (fused._prepare compares)
+        self.counts._gh_fit = self.counts._version
         # node-compact layout (ops.RaggedPlan): the host has to know the total number of real evidence nodes, i.e.
         # the unique tokens per evidence -- what convert_text returns as `length_` (interactions.py:351) at load time
         if compact is None:

@@ -26,6 +26,7 @@ struct FwdBuf {
   int64_t uw, tw, ew, ww, avg, new_left;
   int64_t right_e, mask_e, ue, te, ee, we, att_e, y0, phi;
   int64_t total;
+  int64_t obs_total;      // phi, ww, we, score, keep are offsets into the SEPARATE observables buffer (gh_get_plan::obs_floats)
 };
 struct BwdBuf {
   int64_t d_y0, d_new_left, d_att_e, de_e, dpre_e, du_e, dright_e, d_avg;
@@ -76,12 +77,17 @@ static int layout(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d, FwdBu
   f.offsets = b.take(d.B + 1); f.pair2claim = b.take(d.B1); f.has = b.take(d.B); f.lens_eff = b.take(d.B);
   f.rowc = b.take(d.Mr);
   f.maskf_p = d.compact ? -1 : b.take(d.Mt);
-  // observables first (small), then the activations
-  f.phi = b.take((int64_t)d.B * d.C);
-  f.ww = b.take((int64_t)d.Mr * d.hw);
-  f.we = b.take((int64_t)d.B * d.n * d.he);
-  f.score = b.take((int64_t)d.B1 * d.R);
-  f.keep = b.take((int64_t)d.B1 * d.W * 2);
+  // observables (small; what the caller keeps after the step) live in their own buffer, so that holding on to the logits,
+  // attention weights, scores or keep-sets does not pin the multi-GB activation arena
+  {
+    Bump o;
+    f.phi = o.take((int64_t)d.B * d.C);
+    f.ww = o.take((int64_t)d.Mr * d.hw);
+    f.we = o.take((int64_t)d.B * d.n * d.he);
+    f.score = o.take((int64_t)d.B1 * d.R);
+    f.keep = o.take((int64_t)d.B1 * d.W * 2);
+    f.obs_total = o.off;
+  }
   cell_buf(b, f.q, d.Mq, d.H);
   f.q_repr = b.take((int64_t)d.B * d.H);
   cell_buf(b, f.c1, d.M1, d.H);
@@ -167,10 +173,11 @@ rows_prep_kernel(const int32_t* __restrict__ pair2claim, const int32_t* __restri
 template <typename TS>
 __global__ void __launch_bounds__(256)
 left_assemble_fwd_kernel(const float* __restrict__ table, const TS* __restrict__ src, const float* __restrict__ q_repr,
-                         const float* __restrict__ has, float* __restrict__ new_left, int cs, int H) {
+                         const float* __restrict__ has, float* __restrict__ new_left, int cs, int H, int rows) {
   const int b = blockIdx.x;
   const float hb = has[b];
-  const float* tp = table + (size_t)(long long)src[b] * cs;
+  const long long sb = (long long)src[b];
+  const float* tp = table + (size_t)(sb < 0 ? 0 : (sb >= rows ? rows - 1 : sb)) * cs;
   float* o = new_left + (size_t)b * (cs + H);
   for (int i = threadIdx.x; i < cs; i += blockDim.x) o[i] = tp[i] * hb;
   for (int i = threadIdx.x; i < H; i += blockDim.x) o[cs + i] = q_repr[(size_t)b * H + i];
@@ -180,15 +187,17 @@ left_assemble_fwd_kernel(const float* __restrict__ table, const TS* __restrict__
 template <typename TS>
 __global__ void __launch_bounds__(256)
 left_assemble_bwd_kernel(const float* __restrict__ d_new_left, const TS* __restrict__ src, const float* __restrict__ has,
-                         float* __restrict__ d_q, float* __restrict__ d_table, int B, int cs, int H) {
+                         float* __restrict__ d_q, float* __restrict__ d_table, int B, int cs, int H, int rows) {
   for (int i = threadIdx.x; i < B * H; i += blockDim.x) {
     const int b = i / H, c = i - b * H;
     d_q[i] = d_new_left[(size_t)b * (cs + H) + cs + c];
   }
   if (!d_table) return;
   for (int c = threadIdx.x; c < cs; c += blockDim.x)
-    for (int b = 0; b < B; ++b)
-      d_table[(size_t)(long long)src[b] * cs + c] += d_new_left[(size_t)b * (cs + H) + c] * has[b];
+    for (int b = 0; b < B; ++b) {
+      const long long sb = (long long)src[b];
+      d_table[(size_t)(sb < 0 ? 0 : (sb >= rows ? rows - 1 : sb)) * cs + c] += d_new_left[(size_t)b * (cs + H) + c] * has[b];
+    }
 }
 
 // losses.py:29-32: mean CE and its gradient in one pass.  One workgroup; claims strided over the threads; the loss is
@@ -206,7 +215,8 @@ cross_entropy_kernel(const float* __restrict__ phi, const int64_t* __restrict__ 
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += expf(p[c] - mx);
     const float lse = mx + logf(se);
-    const int y = (int)labels[b];
+    const long long yl = labels[b];
+    const int y = yl < 0 ? 0 : (yl >= C ? C - 1 : (int)yl);      // (no ignore_index; out-of-range labels are clamped)
     acc += lse - p[y];
     for (int c = 0; c < C; ++c) dphi[(size_t)b * C + c] = (expf(p[c] - lse) - (c == y ? 1.f : 0.f)) * invb;
   }
@@ -235,7 +245,7 @@ extern "C" int gh_get_plan_buffers(const gh_get_model* Mo, const gh_get_batch* B
   GH_REQUIRE(P, "get_plan_buffers: NULL plan");
   Dims d; FwdBuf f; BwdBuf w;
   if (int e = layout(Mo, Ba, d, f, w)) return e;
-  P->fwd_floats = f.total; P->bwd_floats = w.total;
+  P->fwd_floats = f.total; P->bwd_floats = w.total; P->obs_floats = f.obs_total;
   P->phi = f.phi; P->word_w = f.ww; P->evd_w = f.we; P->score = f.score; P->keep = f.keep;
   return 0;
 }
@@ -270,10 +280,11 @@ static int cell_bwd(const gh_cell_params& c, const CellBuf& cb, const float* A, 
                        c.db_r0, c.db_h0, c.db_z1, c.db_r1, c.db_h1, drop_p, seed, (void*)s, nullptr, nullptr, nullptr, pre_done, next);
 }
 
-extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, float* A, gh_stream_t stream, gh_stream_t side_stream) {
+extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, float* A, float* O, gh_stream_t stream, gh_stream_t side_stream) {
   Dims d; FwdBuf f; BwdBuf w;
   GH_TRY(layout(Mo, Ba, d, f, w));
   GH_REQUIRE(A && (reinterpret_cast<uintptr_t>(A) & 255) == 0, "get_forward: the arena must be 256-byte aligned");
+  GH_REQUIRE(O && (reinterpret_cast<uintptr_t>(O) & 255) == 0, "get_forward: the observables buffer must be 256-byte aligned");
   GH_REQUIRE(Ba->q_ids && Ba->q_lens && Ba->q_bits && (Ba->q_dinv || Ba->q_vals) && Ba->d_ids && Ba->d_bits && (Ba->d_dinv || Ba->d_vals) &&
              Ba->counts && Ba->document, "get_forward: a batch tensor is missing (ids, lens, packed graphs, counts, document)");
   GH_REQUIRE(Ba->q_lens_kind >= 0 && Ba->q_lens_kind <= 2, "get_forward: q_lens_kind %d not in {0,1,2}", Ba->q_lens_kind);
@@ -282,6 +293,7 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
   GH_REQUIRE(Mo->embedding && Mo->scorer_w && Mo->scorer_gate && Mo->out0_w && Mo->out1_w, "get_forward: missing model tensors");
   GH_REQUIRE((d.cs == 0) == (Mo->claim_src_table == nullptr) && (d.as == 0) == (Mo->article_src_table == nullptr),
              "get_forward: source tables and their widths must come together");
+  GH_REQUIRE(d.cs == 0 || Mo->claim_src_rows > 0, "get_forward: claim_src_rows must give the claim-source table's row count");
   GH_REQUIRE(Ba->drop_claim >= 0.f && Ba->drop_claim < 1.f && Ba->drop_gnn >= 0.f && Ba->drop_gnn < 1.f, "get_forward: dropout p not in [0,1)");
   hipStream_t s = (hipStream_t)stream, ss = side_stream ? (hipStream_t)side_stream : s;
   DevEvents ev;
@@ -304,10 +316,10 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
   if (d.cs > 0) {
     if (Ba->query_sources_i64)
       hipLaunchKernelGGL(left_assemble_fwd_kernel<int64_t>, dim3(d.B), dim3(256), 0, ss, Mo->claim_src_table, (const int64_t*)Ba->query_sources,
-                         A + f.q_repr, A + f.has, A + f.new_left, d.cs, H);
+                         A + f.q_repr, A + f.has, A + f.new_left, d.cs, H, Mo->claim_src_rows);
     else
       hipLaunchKernelGGL(left_assemble_fwd_kernel<int32_t>, dim3(d.B), dim3(256), 0, ss, Mo->claim_src_table, (const int32_t*)Ba->query_sources,
-                         A + f.q_repr, A + f.has, A + f.new_left, d.cs, H);
+                         A + f.q_repr, A + f.has, A + f.new_left, d.cs, H, Mo->claim_src_rows);
     GH_LAUNCH_CHECK();
   }
   // ---- evidence branch (:107; wrapper.py:165-172): cell -> scorer + top-k -> cell on the refined graph
@@ -315,33 +327,33 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
   const int32_t* ids1 = d.compact ? Ba->cids : Ba->d_ids;
   GH_TRY(cell_fwd(Mo->cell1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, d.M1, Mo->embedding, ids1, d.B1, d.R, d.D, H,
                   Ba->drop_gnn, Ba->seed_cell1, Mo->scorer_w, A + f.score_x, Ba->drop_gnn, Ba->seed_scorer, s));
-  uint64_t* keep = reinterpret_cast<uint64_t*>(A + f.keep);
+  uint64_t* keep = reinterpret_cast<uint64_t*>(O + f.keep);
   GH_TRY(gh_scorer_gsl(Ba->d_bits, Ba->d_dinv, Ba->d_vals, goff, (d.compact && Ba->collapsed) ? 1 : 0, nullptr, A + f.score_x, Mo->scorer_w,
-                       Mo->scorer_gate, d.B1, d.R, H, Ba->k_keep, A + f.score, keep, 0.f, 0, (void*)s));
+                       Mo->scorer_gate, d.B1, d.R, H, Ba->k_keep, O + f.score, keep, 0.f, 0, (void*)s));
   GH_TRY(cell_fwd(Mo->cell2, f.c2, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, keep, goff, d.Mr, d.Mr, A + f.c1.out, nullptr, d.B1, d.R, H, H,
                   Ba->drop_gnn, Ba->seed_cell2, nullptr, nullptr, 0.f, 0, s));
   GH_TRY(stream_after(s, ss, ev.ev[1]));
   // ---- word-level attention (:173-193): the left input is the claim vector -> ONE u row per claim
   GH_TRY(att_fwd_impl(A + f.q_repr, d.B, I32(A, f.rowc), A + f.c2.out, d.compact ? Ba->maskf : A + f.maskf_p, goff,
                       d.compact ? Ba->rowg : nullptr, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1, Mo->att_word.w2, A + f.uw, A + f.tw,
-                      A + f.ew, A + f.ww, A + f.avg, s));
+                      A + f.ew, O + f.ww, A + f.avg, s));
   // ---- evidence-level assembly + attention (:157-171, :195-221)
   GH_TRY(gh_evd_assemble_fwd(A + f.avg, I32(A, f.offsets), Mo->article_src_table, d.as > 0 ? Ba->doc_sources : nullptr, Ba->doc_sources_i64,
                              Ba->document, Ba->document_i64, d.B, d.n, d.Xa, d.as, d.R, A + f.right_e, A + f.mask_e, (void*)s));
   GH_TRY(att_fwd_impl(A + f.new_left, d.B, nullptr, A + f.right_e, A + f.mask_e, nullptr, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he,
-                      Mo->att_evd.w1, Mo->att_evd.w2, A + f.ue, A + f.te, A + f.ee, A + f.we, A + f.att_e, s));
+                      Mo->att_evd.w1, Mo->att_evd.w2, A + f.ue, A + f.te, A + f.ee, O + f.we, A + f.att_e, s));
   // ---- head (:251-267, :69-74): Linear([claim | attended evidences]) -> Linear, no activation
   GH_TRY(linear2_fwd(A + f.new_left, d.Xl, A + f.att_e, d.Dre * d.he, Mo->out0_w, Mo->out0_b, A + f.y0, d.B, H, s));
-  GH_TRY(gh_linear_fwd(A + f.y0, Mo->out1_w, Mo->out1_b, A + f.phi, d.B, H, d.C, (void*)s));
+  GH_TRY(gh_linear_fwd(A + f.y0, Mo->out1_w, Mo->out1_b, O + f.phi, d.B, H, d.C, (void*)s));
   return 0;
 }
 
-extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, const float* A, float* Wb, const float* g_phi,
+extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, const float* A, const float* O, float* Wb, const float* g_phi,
                                const float* g_word_w, const float* g_evd_w, int phase, gh_stream_t stream, gh_stream_t side_stream) {
   Dims d; FwdBuf f; BwdBuf w;
   GH_TRY(layout(Mo, Ba, d, f, w));
   GH_REQUIRE(phase >= 0 && phase <= 2, "get_backward: phase %d not in {0,1,2}", phase);
-  GH_REQUIRE(A && Wb && g_phi, "get_backward: NULL arena / gradient");
+  GH_REQUIRE(A && O && Wb && g_phi, "get_backward: NULL arena / observables / gradient");
   GH_REQUIRE(Mo->out0_wt && Mo->out1_wt && Mo->att_word.w1t && Mo->att_evd.w1t && Mo->d_out0_w && Mo->d_out0_b && Mo->d_out1_w &&
              Mo->d_out1_b && Mo->att_word.dw1 && Mo->att_word.dw2 && Mo->att_evd.dw1 && Mo->att_evd.dw2,
              "get_backward: transposes / gradient outputs of the attention layers or the head are missing");
@@ -351,7 +363,7 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
   const int H = d.H;
   const int32_t* goff = d.compact ? Ba->goff : nullptr;
   const int32_t* ids1 = d.compact ? Ba->cids : Ba->d_ids;
-  const uint64_t* keep = reinterpret_cast<const uint64_t*>(A + f.keep);
+  const uint64_t* keep = reinterpret_cast<const uint64_t*>(O + f.keep);
   // gate heads fused into the producing GEMMs' epilogues: cell scratch order is {dhp, dzp, drp, dxp, da}
   const GateFuse gf2 = {A + f.c2.z, A + f.c2.hh, A + f.c2.xp, Wb + w.sc2[0], Wb + w.sc2[1], Wb + w.sc2[3]};
   const GateFuse gf1 = {A + f.c1.z, A + f.c1.hh, A + f.c1.xp, Wb + w.sc1[0], Wb + w.sc1[1], Wb + w.sc1[3]};
@@ -365,11 +377,11 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
                        Mo->d_out0_w, Mo->d_out0_b, ss));
     // ---- evidence-level attention; its left gradient adds to the head's
     GH_TRY(att_bwd_impl(A + f.new_left, A + f.right_e, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he, Mo->att_evd.w1t, Mo->att_evd.w2, A + f.te,
-                        A + f.we, Wb + w.d_att_e, g_evd_w, Wb + w.de_e, Wb + w.dpre_e, Wb + w.du_e, Wb + w.d_new_left, Wb + w.dright_e,
+                        O + f.we, Wb + w.d_att_e, g_evd_w, Wb + w.de_e, Wb + w.dpre_e, Wb + w.du_e, Wb + w.d_new_left, Wb + w.dright_e,
                         nullptr, Mo->att_evd.dw2, nullptr, d.B, nullptr, 1, s));
     GH_TRY(stream_after(ss, s, ev.ev[3]));
     GH_TRY(att_bwd_impl(A + f.new_left, A + f.right_e, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he, Mo->att_evd.w1t, Mo->att_evd.w2, A + f.te,
-                        A + f.we, Wb + w.d_att_e, g_evd_w, Wb + w.de_e, Wb + w.dpre_e, Wb + w.du_e, nullptr, nullptr, Mo->att_evd.dw1,
+                        O + f.we, Wb + w.d_att_e, g_evd_w, Wb + w.de_e, Wb + w.dpre_e, Wb + w.du_e, nullptr, nullptr, Mo->att_evd.dw1,
                         Mo->att_evd.dw2, nullptr, d.B, nullptr, 0, ss));
     // ---- evidence-level assembly: d_avg (rows of claims with more than n_max evidences stay zero), article-source table
     if (!Ba->counts_fit) GH_CHECK_HIP(hipMemsetAsync(Wb + w.d_avg, 0, sizeof(float) * (size_t)d.B1 * d.Xa, s));
@@ -378,23 +390,23 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
     if (d.cs > 0) {
       if (Ba->query_sources_i64)
         hipLaunchKernelGGL(left_assemble_bwd_kernel<int64_t>, dim3(1), dim3(256), 0, s, Wb + w.d_new_left, (const int64_t*)Ba->query_sources,
-                           A + f.has, Wb + w.d_q, Mo->d_claim_src_table, d.B, d.cs, H);
+                           A + f.has, Wb + w.d_q, Mo->d_claim_src_table, d.B, d.cs, H, Mo->claim_src_rows);
       else
         hipLaunchKernelGGL(left_assemble_bwd_kernel<int32_t>, dim3(1), dim3(256), 0, s, Wb + w.d_new_left, (const int32_t*)Ba->query_sources,
-                           A + f.has, Wb + w.d_q, Mo->d_claim_src_table, d.B, d.cs, H);
+                           A + f.has, Wb + w.d_q, Mo->d_claim_src_table, d.B, d.cs, H, Mo->claim_src_rows);
       GH_LAUNCH_CHECK();
     }
     // ---- word-level attention: per-pair du summed per claim; d(claim vector) accumulates on top of the head / evidence part.
     //      Its dright GEMM produces the gradient of the second evidence cell's output and nothing else reads it: the GEMM's
     //      epilogue applies that cell's gate head (gf2); likewise the second cell's dX GEMM feeds the first cell's (gf1).
     GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
-                        A + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, Wb + w.g2, nullptr,
+                        O + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, Wb + w.g2, nullptr,
                         Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, s, d.compact ? Ba->rowg : nullptr, Wb + w.dw_w, &gf2));
     // ---- side stream: linear1's weight gradient of the word attention, then the claim branch's backward -- underneath
     //      the evidence cells' chain on the main stream
     GH_TRY(stream_after(ss, s, ev.ev[4]));
     GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
-                        A + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, nullptr, nullptr, Mo->att_word.dw1,
+                        O + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, nullptr, nullptr, Mo->att_word.dw1,
                         Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 0, ss));
     GH_TRY(gh_masked_mean_bwd(Wb + w.d_q, Ba->q_ids, A + f.lens_eff, Wb + w.d_qhid, d.B, d.L, H, (void*)ss));
     GH_TRY(cell_bwd(Mo->claim, f.q, A, Ba->q_bits, Ba->q_dinv, Ba->q_vals, nullptr, nullptr, 0, Mo->embedding, Ba->q_ids, d.B, d.L, d.D, H,

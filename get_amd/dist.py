@@ -78,6 +78,9 @@ class _StreamWork:
         torch.cuda.current_stream().wait_event(self._event)
         return True
 
+    def is_completed(self):
+        return self._event.query()
+
 
 class LibComm:
     """RCCL communicator owned by libget_hip.so (``gh_comm_*`` / ``gh_flat_allreduce``, include/get_hip.h): what a
@@ -93,7 +96,12 @@ class LibComm:
         from . import _lib
         assert len(id_bytes) == 128
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.type != "cuda":
+            raise ValueError(f"get_amd: LibComm needs a GPU device, got {dev}")
+        if dev.index is None:          # "cuda" without an index never equals a tensor's device ("cuda:0"): bind to the current one
+            dev = torch.device("cuda", torch.cuda.current_device())
         self.device, self.rank, self.world = dev, int(rank), int(world)
+        self._comm_stream = None       # asynchronous collectives get a stream of their own (all_reduce_async)
         buf = ctypes.create_string_buffer(bytes(id_bytes), 128)
         out = ctypes.c_void_p()
         with torch.cuda.device(dev):
@@ -139,6 +147,25 @@ class LibComm:
         self._check(t)
         with torch.cuda.device(self.device):
             _lib.call("gh_flat_allreduce", self._comm, t.data_ptr(), t.numel(), _lib.stream())
+
+    def all_reduce_async(self, t: torch.Tensor) -> "_StreamWork":
+        """In-place sum over the ranks on the communicator's OWN stream, ordered behind everything the current stream has
+        been given so far; returns a work handle whose wait() orders the then-current stream behind the collective.
+        Nothing the current stream is given afterwards waits for the collective (enqueued in the auxiliary stream itself,
+        the early all-reduce used to hold up that stream's later weight-gradient launches and, through the backward's final
+        join, the main stream)."""
+        from . import _lib
+        self._check(t)
+        with torch.cuda.device(self.device):
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=self.device)
+            cs = self._comm_stream
+            cs.wait_stream(torch.cuda.current_stream(self.device))
+            t.record_stream(cs)
+            _lib.call("gh_flat_allreduce", self._comm, t.data_ptr(), t.numel(), cs.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(cs)
+        return _StreamWork(ev)
 
     def broadcast(self, t: torch.Tensor, root: int = 0):
         from . import _lib
@@ -239,13 +266,12 @@ class FlatTrainer:
         self.comm_bytes += t.numel() * t.element_size()
         self.comm_calls += 1
         if self.comm is not None:
-            # enqueued on the current stream; "asynchronous" = the caller later orders its own stream behind this one
+            # blocking form: enqueued on the current stream; asynchronous form: on the communicator's own stream, behind
+            # the current one -- the caller later orders its stream behind the returned handle
+            if async_op:
+                return self.comm.all_reduce_async(t)
             self.comm.all_reduce(t)
-            if not async_op:
-                return None
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(t.device))
-            return _StreamWork(ev)
+            return None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def broadcast_parameters(self, src: int = 0):

@@ -37,7 +37,7 @@ class AttParams(ctypes.Structure):
 
 class GetModel(ctypes.Structure):
     _fields_ = [("d", _I), ("h", _I), ("word_heads", _I), ("evd_heads", _I), ("n_classes", _I),
-                ("claim_src_dim", _I), ("article_src_dim", _I),
+                ("claim_src_dim", _I), ("article_src_dim", _I), ("claim_src_rows", _I), ("article_src_rows", _I),
                 ("embedding", _P),
                 ("claim", CellParams), ("cell1", CellParams), ("cell2", CellParams),
                 ("scorer_w", _P), ("scorer_gate", _P),
@@ -65,7 +65,8 @@ class GetBatch(ctypes.Structure):
 
 
 class GetPlan(ctypes.Structure):
-    _fields_ = [("fwd_floats", _L), ("bwd_floats", _L), ("phi", _L), ("word_w", _L), ("evd_w", _L), ("score", _L), ("keep", _L)]
+    _fields_ = [("fwd_floats", _L), ("bwd_floats", _L), ("obs_floats", _L), ("phi", _L), ("word_w", _L), ("evd_w", _L), ("score", _L),
+                ("keep", _L)]
 
 
 def _cell_tensors(cell):
@@ -154,6 +155,8 @@ class Binding:
         S.word_heads, S.evd_heads, S.n_classes = m.num_att_heads_for_words, m.num_att_heads_for_evds, m.out[1].weight.shape[0]
         S.claim_src_dim = m.claim_emb_size if m.use_claim_source else 0
         S.article_src_dim = m.article_emb_size if m.use_article_source else 0
+        S.claim_src_rows = m.claim_source_embs.weight.shape[0] if m.use_claim_source else 0
+        S.article_src_rows = m.article_source_embs.weight.shape[0] if m.use_article_source else 0
         S.embedding = m.embedding.weight.data_ptr()
         gptr = None
         if need_grads:
@@ -244,7 +247,7 @@ def _prepare(model, query, document, kargs, q_adj: PackedAdj, d_adj: PackedAdj, 
         q_lens = q_lens.float()
     q_lens = q_lens.contiguous()
     counts = kargs[K.EvidenceCountPerQuery]
-    fit = bool(getattr(counts, "_gh_fit", False))
+    fit = getattr(counts, "_gh_fit", None) == counts._version      # NativeBatch's promise, void after any in-place edit
     if counts.dtype != torch.int64 or not counts.is_contiguous():
         counts = counts.to(torch.int64).contiguous()
     S.q_ids, S.q_lens = q_ids.data_ptr(), q_lens.data_ptr()
@@ -315,30 +318,43 @@ class _GetFused(torch.autograd.Function):
         plan = GetPlan()
         _lib.call("gh_get_plan_buffers", ctypes.addressof(M), ctypes.addressof(prep.struct), ctypes.addressof(plan))
         arena = torch.empty(_arena_floats(plan.fwd_floats), device=dev, dtype=torch.float32)
+        # the observables (logits, attention weights, scores, keep-sets: a few MB) get a buffer of their own: whoever keeps
+        # them -- the model's last_score / last_keep, batched_predict's per-chunk lists -- does not pin the activation arena
+        obs = torch.empty(int(plan.obs_floats), device=dev, dtype=torch.float32)
         main = _lib.stream()
         side_raw = side.cuda_stream if side is not None else main
         if side is not None:
             arena.record_stream(side)
-        _lib.call("gh_get_forward", ctypes.addressof(M), ctypes.addressof(prep.struct), arena.data_ptr(), main, side_raw)
+            obs.record_stream(side)
+        _lib.call("gh_get_forward", ctypes.addressof(M), ctypes.addressof(prep.struct), arena.data_ptr(), obs.data_ptr(), main, side_raw)
         B, b1, R = prep.b, prep.b1, prep.r
-        phi = arena[plan.phi:plan.phi + B * prep.c].view(B, prep.c)
-        word_w = arena[plan.word_w:plan.word_w + prep.rows * prep.hw].view(prep.rows, prep.hw)
-        evd_w = arena[plan.evd_w:plan.evd_w + B * prep.n_max * prep.he].view(B, prep.n_max, prep.he)
-        score = arena[plan.score:plan.score + b1 * R].view(b1, R)
-        keep = arena[plan.keep:plan.keep + b1 * prep.w * 2].view(torch.int64).view(b1, prep.w)
-        ctx.binding, ctx.prep, ctx.side, ctx.arena, ctx.plan_bwd = binding, prep, side, arena, int(plan.bwd_floats)
+        phi = obs[plan.phi:plan.phi + B * prep.c].view(B, prep.c)
+        word_w = obs[plan.word_w:plan.word_w + prep.rows * prep.hw].view(prep.rows, prep.hw)
+        evd_w = obs[plan.evd_w:plan.evd_w + B * prep.n_max * prep.he].view(B, prep.n_max, prep.he)
+        score = obs[plan.score:plan.score + b1 * R].view(b1, R)
+        keep = obs[plan.keep:plan.keep + b1 * prep.w * 2].view(torch.int64).view(b1, prep.w)
+        ctx.binding, ctx.prep, ctx.side, ctx.arena, ctx.obs, ctx.plan_bwd = binding, prep, side, arena, obs, int(plan.bwd_floats)
         ctx.anchor_ids = [id(a) for a in anchors]
-        ctx.mark_non_differentiable(word_w, evd_w, score, keep)
-        ctx.set_materialize_grads(False)      # no zero-filled gradient tensors for the four observables (4 fill launches per step)
+        ctx.mark_non_differentiable(score, keep)
+        ctx.set_materialize_grads(False)      # no zero-filled gradient tensors for unused outputs (fill launches per step)
         return phi, word_w, evd_w, score, keep
 
     @staticmethod
-    def backward(ctx, g_phi, *_unused):
-        binding, prep, side, arena = ctx.binding, ctx.prep, ctx.side, ctx.arena
+    def backward(ctx, g_phi, g_word_w=None, g_evd_w=None, *_unused):
+        binding, prep, side, arena, obs = ctx.binding, ctx.prep, ctx.side, ctx.arena, ctx.obs
+        if arena is None:
+            raise RuntimeError("get_amd: the fused GET backward ran twice on one forward (retain_graph / autograd.grad followed "
+                               "by backward): the activation arena is released by the first backward.  Run the forward again, or "
+                               "set GET_AMD_FUSED=0 for the module-by-module path, which supports retain_graph.")
         dev = arena.device
-        if g_phi is None:          # nothing upstream depends on phi
+        if g_phi is None and g_word_w is None and g_evd_w is None:          # nothing upstream depends on the outputs
+            ctx.arena = None
             return (None, None, None) + (None,) * len(ctx.anchor_ids)
+        if g_phi is None:
+            g_phi = torch.zeros((prep.b, prep.c), device=dev, dtype=torch.float32)
         g_phi = ops._f32(g_phi)
+        g_word_w = ops._f32(g_word_w) if g_word_w is not None else None      # loss terms on the attention weights
+        g_evd_w = ops._f32(g_evd_w) if g_evd_w is not None else None
         M, direct, gbuf, views = binding.get(True)
         main = _lib.stream()
         side_raw = side.cuda_stream if side is not None else main
@@ -348,11 +364,11 @@ class _GetFused(torch.autograd.Function):
                 _lib.ensure_workspace(dev)
         work = torch.empty(_arena_floats(ctx.plan_bwd), device=dev, dtype=torch.float32)
         if side is not None:
-            work.record_stream(side)
-            g_phi.record_stream(side)
-            if gbuf is not None:
-                gbuf.record_stream(side)
-        args = (ctypes.addressof(M), ctypes.addressof(prep.struct), arena.data_ptr(), work.data_ptr(), g_phi.data_ptr(), None, None)
+            for t in (work, g_phi, gbuf, g_word_w, g_evd_w):
+                if t is not None:
+                    t.record_stream(side)
+        args = (ctypes.addressof(M), ctypes.addressof(prep.struct), arena.data_ptr(), obs.data_ptr(), work.data_ptr(), g_phi.data_ptr(),
+                g_word_w.data_ptr() if g_word_w is not None else None, g_evd_w.data_ptr() if g_evd_w is not None else None)
         hook = binding.model.ggnn_with_gsl.grad_milestone_hook
         if hook is None:
             _lib.call("gh_get_backward", *args, 0, main, side_raw)
@@ -364,7 +380,7 @@ class _GetFused(torch.autograd.Function):
                 ops._side_pending.add(dev.index if dev.index is not None else torch.cuda.current_device())
             hook()
             _lib.call("gh_get_backward", *args, 2, main, side_raw)
-        ctx.arena = None
+        ctx.arena = None                  # (a second backward on this graph raises above)
         if direct:
             return (None, None, None) + (None,) * len(ctx.anchor_ids)
         return (None, None, None) + tuple(views.get(i) for i in ctx.anchor_ids)

@@ -56,7 +56,7 @@ extern "C" {
 
 typedef void* gh_stream_t;
 
-#define GH_ABI_VERSION 6
+#define GH_ABI_VERSION 7
 
 int gh_abi_version(void);
 /* Thread-local message of the last failing call on this thread (never NULL). */
@@ -328,6 +328,8 @@ typedef struct gh_att_params {             /* ConcatNotEqualSelfAtt, thirdparty/
 typedef struct gh_get_model {
   int d, h, word_heads, evd_heads, n_classes;       /* embedding width, hidden size, heads, output_size */
   int claim_src_dim, article_src_dim;               /* 0 = that source embedding is not used */
+  int claim_src_rows, article_src_rows;             /* rows of the two source tables: claim-source ids are clamped into
+                                                       [0, rows) (nn.Embedding raises there; a device kernel cannot) */
   const float* embedding;                           /* [vocab][d] word table (frozen) */
   gh_cell_params claim, cell1, cell2;               /* ggnn4claim_1, ggnn_with_gsl.feat_prop1 / feat_prop2 */
   const float* scorer_w;                            /* ggnn_with_gsl.word_scorer1.proj weight [h] */
@@ -358,26 +360,30 @@ typedef struct gh_get_batch {
   float drop_claim, drop_gnn;                       /* input dropout of the claim cell / of the three evidence-side cells (0 = eval) */
   uint32_t seed_claim, seed_cell1, seed_scorer, seed_cell2;
 } gh_get_batch;
-/* Buffer plan: float offsets into the two arenas for (model, batch).  fwd_floats / bwd_floats = arena sizes (in floats). */
+/* Buffer plan for (model, batch).  fwd_floats / bwd_floats = sizes (in floats) of the two activation arenas;
+ * obs_floats = size of the OBSERVABLES buffer -- a few MB holding what a caller keeps after the step (ABI 7: a buffer of
+ * its own, so that holding the logits / attention weights / keep-sets does not pin the multi-GB forward arena). */
 typedef struct gh_get_plan {
-  int64_t fwd_floats, bwd_floats;
-  int64_t phi, word_w, evd_w, score, keep;          /* offsets (floats) of the observable results inside the forward arena:
+  int64_t fwd_floats, bwd_floats, obs_floats;
+  int64_t phi, word_w, evd_w, score, keep;          /* offsets (floats) of the observable results inside the observables buffer:
                                                        phi [b][n_classes]; word_w [rows][word_heads] (rows = m_real, or b1*r padded);
                                                        evd_w [b][n_max][evd_heads]; score [b1][r]; keep [b1][W] uint64 (8-byte aligned) */
 } gh_get_plan;
 int gh_get_plan_buffers(const gh_get_model* model, const gh_get_batch* batch, gh_get_plan* plan);
 /* sizeof of {gh_get_model, gh_get_batch, gh_get_plan, gh_cell_params}: lets a binding verify its mirror of the structs. */
 int gh_get_struct_sizes(int64_t* out4_host);
-/* Forward into `arena_fwd` (plan.fwd_floats floats, 256-byte aligned, kept until the backward has run). */
-int gh_get_forward(const gh_get_model* model, const gh_get_batch* batch, float* arena_fwd, gh_stream_t stream, gh_stream_t side_stream);
+/* Forward into `arena_fwd` (plan.fwd_floats floats) and `obs` (plan.obs_floats floats); both 256-byte aligned and kept until
+ * the backward has run (evaluation: the arena may be released as soon as the call has been issued and the stream drained). */
+int gh_get_forward(const gh_get_model* model, const gh_get_batch* batch, float* arena_fwd, float* obs, gh_stream_t stream,
+                   gh_stream_t side_stream);
 /* Backward from g_phi [b][n_classes] (+ optional g_word_w / g_evd_w, shaped like the forward's weights outputs, or NULL).
  * phase 0: everything; 1: down to and including the second evidence cell -- every gradient outside the first evidence cell
  * and the claim branch is final in stream order when it returns (the data-parallel early all-reduce starts here);
  * 2: the rest (first evidence cell; joins the side stream).  Gradients are ACCUMULATED into model->d*. */
-int gh_get_backward(const gh_get_model* model, const gh_get_batch* batch, const float* arena_fwd, float* arena_bwd,
+int gh_get_backward(const gh_get_model* model, const gh_get_batch* batch, const float* arena_fwd, const float* obs, float* arena_bwd,
                     const float* g_phi, const float* g_word_w, const float* g_evd_w, int phase,
                     gh_stream_t stream, gh_stream_t side_stream);
-/* Mean cross-entropy of logits [b][c] against labels [b] (int64), fused with its gradient (losses.py:29-32 CrossEntropyLoss):
+/* Mean cross-entropy of logits [b][c] against labels [b] (int64, clamped into [0, c): no ignore_index), fused with its gradient (losses.py:29-32 CrossEntropyLoss):
  * loss[0] = mean_b(logsumexp(phi_b) - phi_b[y_b]); dphi [b][c] = (softmax(phi_b) - onehot(y_b)) / b. */
 int gh_cross_entropy(const float* phi, const int64_t* labels, int b, int c, float* loss, float* dphi, gh_stream_t stream);
 /* Batch preparation in one call (interactions.py:334-351 for both sides + basic_fc_model.py:94-121's padded document):

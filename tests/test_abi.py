@@ -45,7 +45,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     for name in _lib.SIGNATURES:
         assert name in decl, f"{name} bound in Python but not declared in get_hip.h"
     lib.gh_abi_version.restype = ctypes.c_int
-    assert lib.gh_abi_version() == 6
+    assert lib.gh_abi_version() == 7
     _lib.load()
 
 
@@ -163,7 +163,8 @@ def test_composite_descriptor_mirrors_and_buffer_plan(lib_path):
     small, big, padded = plan(4, 40, 2600), plan(32, 960, 62128), plan(32, 960, -1)
     for p in (small, big, padded):
         for off in (p.phi, p.word_w, p.evd_w, p.score, p.keep):
-            assert off % 64 == 0 and 0 <= off < p.fwd_floats
+            assert off % 64 == 0 and 0 <= off < p.obs_floats
+        assert 0 < 4 * p.obs_floats < 16e6          # observables: a few MB, never the activation arena
     assert small.fwd_floats < big.fwd_floats < padded.fwd_floats and small.bwd_floats < big.bwd_floats
     assert 1.2e9 < 4 * big.fwd_floats < 2.5e9          # ~1.5 GB of saved activations at the bench shape
     with pytest.raises(RuntimeError, match="320"):
