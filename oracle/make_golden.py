@@ -335,8 +335,68 @@ def g7_g8():
         print("G7", name, "loss", loss.item(), "none grads", len(none_grads), "live", meta["n_live"])
 
 
+def g9():
+    """G9: the **kargs the reference FITTER itself hands to net(...) -- captured, not restated.  The reference's own
+    `_get_multiple_evidences_predictions_normal` (Fitting/FittingFC/char_man_fitter_query_repr1.py:164-258, called here as
+    an unbound function on a stub `self`) runs its de-padding loop (:204-223) on the padded tensors its training loop
+    builds (:92-112) for the `small` case; the stub `net` records what arrives.  Stored: every key, and for tensor / array
+    values dtype, shape and values (tuples element-wise).  tests/test_oracle_golden.py asserts that oracle/assemble.py's
+    hand-written `reference_kargs` reproduces it."""
+    import types
+    from Fitting.FittingFC import char_man_fitter_query_repr1 as F
+    from setting_keywords import KeyWordSettings as KW
+    cfg, seed = MODEL_CASES["small"]
+    raw = make_raw_batch(cfg, seed)
+    inp = assemble_inputs(raw, cfg, ref_convert_text)
+    B, n, L, R = cfg.batch, cfg.fixed_num_evidences, cfg.len_left, cfg.len_right
+    counts = inp["evd_counts"]
+    # padded per-claim tensors, as handlers/mz_sampler.py:115-176 materialises them
+    adj = np.zeros((B, n, R, R), np.float64)
+    last = 0
+    for b in range(B):
+        c = int(counts[b])
+        adj[b, :c] = inp["doc_adj"][last:last + c]
+        last += c
+    seen = {}
+
+    def net(query, document, **kargs):
+        seen["query"], seen["document"], seen["kargs"] = query, document, kargs
+        return torch.zeros(query.size(0), 2)
+
+    stub = types.SimpleNamespace(_net=net, _use_cuda=False, _loss_func=lambda pred, labels: pred.sum() * 0.0)
+    t = torch.from_numpy
+    extra = {KW.EvidenceCountPerQuery: t(counts), KW.FCClass.QueryCharSource: t(np.zeros((B, 1, L), np.int64)),
+             KW.FCClass.DocCharSource: t(np.zeros((B, n, R), np.int64)), KW.Query_Adj: t(inp["query_adj"]),
+             KW.Evd_Docs_Adj: t(adj)}
+    F.CharManFitterQueryRepr1._get_multiple_evidences_predictions_normal(
+        stub, t(np.arange(B, dtype=np.int64)), t(inp["query"]), inp["query_lens"], t(inp["query_sources"]),
+        t(np.zeros((B, n), np.int64)), t(inp["document"]), inp["docs_lens"], t(inp["doc_sources"]), t(inp["labels"]), n, **extra)
+    store, keys = {}, []
+
+    def put(name, v):
+        if torch.is_tensor(v):
+            v = v.detach().numpy()
+        if isinstance(v, np.ndarray):
+            store[name] = v
+            return {"kind": "array", "dtype": str(v.dtype), "shape": list(v.shape)}
+        if isinstance(v, (tuple, list)):
+            return {"kind": "tuple", "items": [put(f"{name}::{i}", x) for i, x in enumerate(v)]}
+        return {"kind": "scalar", "value": v}
+
+    desc = {}
+    for k, v in seen["kargs"].items():
+        keys.append(k)
+        desc[k] = put(f"k::{k}", v)
+    store["query"], store["document"] = seen["query"].numpy(), seen["document"].numpy()
+    meta = dict(case="small", seed=seed, keys=keys, desc=desc,
+                source="Fitting/FittingFC/char_man_fitter_query_repr1.py:164-258 run on a stub self; net(**kargs) recorded")
+    store["meta"] = np.frombuffer(json.dumps(meta, default=str).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "g9_fitter_kargs_small.npz"), **store)
+    print("G9 fitter kargs:", keys)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    g1(); g2(); g3(); g4(); g5_g6(); g7_g8()
+    g1(); g2(); g3(); g4(); g5_g6(); g7_g8(); g9()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -15,3 +15,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(params=["fp32", "fp32x3p"])
+def arith_mode(request):
+    """The golden-suite tests run once per arithmetic mode of the NT GEMMs at the SAME tolerances: exact fp32 MFMA (the
+    headline and the parity claim) and the opt-in fp32x3p mode (fp32-equivalent products from pre-split bf16 pieces,
+    gh_set_gemm_mode(3)) -- the mode earns a labelled bench line only while this whole suite is green in it."""
+    from get_amd import _lib, ops
+    if request.param != "fp32":
+        _lib.set_gemm_mode(request.param)
+        ops.bump_weight_epoch()
+    yield request.param
+    if request.param != "fp32":
+        ops.bump_weight_epoch()          # frees the pre-split images while the mode is still set
+        _lib.set_gemm_mode("fp32")

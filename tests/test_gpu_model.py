@@ -67,7 +67,7 @@ def run_case(name, native_graphs=False, int32_inputs=False):
 
 @pytest.mark.parametrize("name", list(MODEL_CASES))
 @pytest.mark.parametrize("native", [False, True, "compact"])
-def test_model_vs_golden(name, native):
+def test_model_vs_golden(name, native, arith_mode):
     z, meta = load(f"g7_model_{name}.npz")
     cfg, model, inp, phi, ww, ew, loss = run_case(name, native_graphs=native)
     assert phi.shape == (cfg.batch, cfg.num_classes)
@@ -154,7 +154,7 @@ def test_model_eval_path_int32_and_predict():
         assert np.all(e[b, c:] == 0) and abs(e[b, :c].sum(0) - 1).max() <= 1e-5
 
 
-def test_model_adam_step_matches_golden():
+def test_model_adam_step_matches_golden(arith_mode):
     """G8: one Adam(lr=1e-4, weight_decay=1e-3) step through the flat bucket the DP wrapper uses."""
     from get_amd.dist import FlatTrainer
     z, meta = load("g7_model_small.npz")
@@ -401,6 +401,75 @@ def test_h768_bf16_gemm_mode_tracks_the_fp32_oracle():
         assert err <= 6e-2 * float(g32.abs().max()) + 1e-7, (k, err, float(g32.abs().max()))
 
 
+def test_h768_bf16_storage_vs_the_cpu_oracle():
+    """BASELINE configs[4], DIRECT oracle comparison: the bf16 storage pipeline at h = 768, 8 word heads,
+    window 5, rate 0.8, at a batch that takes the big-tile path, against O.model_forward (wrapper.py:188-206 arithmetic in
+    fp32 on the CPU) on the SAME batch -- not against the HIP fp32 path.  Stated bf16 bounds per quantity: logits 2e-3,
+    word / evidence attention weights 5e-3, scorer scores 1e-2, every live gradient 6e-2 of its largest entry; GSL keep
+    decisions may flip for nodes whose score sits within bf16 noise of the k-th: at most 0.5 % of the real nodes and 15 %
+    of the graphs (counts printed)."""
+    from get_amd import _lib, ops
+    from get_amd.synth import SynthConfig
+    cfg = SynthConfig(batch=6, n_evd=30, emb_dim=768, hidden=768, word_heads=8, evd_heads=2, window=5, gsl_rate=0.8, vocab=900,
+                      n_article_src=40, n_claim_src=10)
+    seed = 769
+    model = build_model(cfg, seed)
+    raw = make_raw_batch(cfg, seed)
+    inp = assemble_inputs(raw, cfg, O.convert_text)
+    kargs = to_dev(reference_kargs(inp, torch, output_ranking=True))
+    da, d_ids, d_n = ops.graph_build(torch.from_numpy(raw["evd_tokens"]).to(DEV), torch.from_numpy(raw["evd_len"]).to(DEV), cfg.window)
+    kargs["docs_adj"] = da.with_plan(ops.RaggedPlan(d_n, d_ids, int(d_n.sum().item())))
+    assert int(d_n.sum().item()) >= 8192
+    q, d = torch.from_numpy(inp["query"]).to(DEV), torch.from_numpy(inp["document"]).to(DEV)
+    labels = torch.from_numpy(inp["labels"]).to(DEV)
+    _lib.set_gemm_mode("bf16")
+    try:
+        _lib.gemm_path_counters(reset=True)
+        phi, (ww, ew) = model(q, d, **kargs)
+        score = model.ggnn_with_gsl.last_score.detach().cpu()
+        keep = model.ggnn_with_gsl.last_keep.cpu().numpy().astype(np.uint64)
+        torch.nn.functional.cross_entropy(phi, labels).backward()
+        assert _lib.gemm_path_counters()["generic_large"] == 0
+    finally:
+        _lib.set_gemm_mode("fp32")
+    # the oracle on the same batch (fp32, CPU)
+    emb, art, clm = make_embeddings(cfg, seed)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    p = {k: T(v).requires_grad_(True) for k, v in make_state_dict(cfg, seed).items()}
+    p["embedding.weight"] = T(emb)
+    p["article_source_embs.weight"] = T(art).requires_grad_(True)
+    phi_o, ww_o, ew_o, aux = O.model_forward(p, cfg.__dict__, T(inp["query"]), T(inp["document"]), T(inp["query_adj"]),
+                                             T(inp["doc_ids"]), T(inp["doc_adj"]), T(inp["query_lens"]), inp["evd_counts"],
+                                             T(inp["doc_sources"]), T(inp["query_sources"]), return_aux=True)
+    O.cross_entropy(phi_o, T(inp["labels"])).backward()
+    d_phi = float((phi.detach().cpu() - phi_o.detach()).abs().max())
+    d_ww = float((ww.detach().cpu() - ww_o.detach()).abs().max())
+    d_ew = float((ew.detach().cpu() - ew_o.detach()).abs().max())
+    d_sc = float((score - aux["score"].detach()).abs().max())
+    R = cfg.len_right
+    bits = ((keep[:, :, None] >> np.arange(64, dtype=np.uint64)[None, None, :]) & np.uint64(1)).astype(bool).reshape(keep.shape[0], -1)[:, :R]
+    real = inp["doc_ids"] > 0
+    mism = (bits != aux["keep"].numpy().astype(bool)) & real
+    graphs_off, nodes_off = int(mism.any(1).sum()), int(mism.sum())
+    worst_g, worst_k = 0.0, None
+    n_checked = 0
+    for k, prm in model.named_parameters():
+        if k in p and p[k].grad is not None and prm.grad is not None:
+            go = p[k].grad
+            rel = float((prm.grad.cpu() - go).abs().max()) / (float(go.abs().max()) + 1e-12)
+            if rel > worst_g:
+                worst_g, worst_k = rel, k
+            n_checked += 1
+    print(f"bf16 storage vs the CPU oracle: logits {d_phi:.2e}, word weights {d_ww:.2e}, evidence weights {d_ew:.2e}, scores "
+          f"{d_sc:.2e}, worst gradient {worst_g:.2e} ({worst_k}), keep decisions differ in {graphs_off} of {mism.shape[0]} graphs "
+          f"({nodes_off} of {int(real.sum())} real nodes)")
+    assert 1e-6 < d_phi <= 2e-3, d_phi
+    assert d_ww <= 5e-3 and d_ew <= 5e-3, (d_ww, d_ew)
+    assert d_sc <= 1e-2, d_sc
+    assert nodes_off <= 0.005 * real.sum() and graphs_off <= 0.15 * mism.shape[0]
+    assert n_checked >= 40 and worst_g <= 6e-2, (worst_k, worst_g)
+
+
 def test_ragged_realistic_batch_properties():
     """Evidence counts drawn U[1,30] (B1 not a multiple of any tile): weights sum to one, padded slots and
     padded nodes get exactly zero attention, gradients finite, logits equal the oracle on a slice."""
@@ -450,6 +519,75 @@ def test_batch_shim_matches_fitter_depadding():
     phi_b = model(q_ids, document, **k2)
     assert np.abs(phi_a.detach().cpu().numpy() - z["phi"]).max() <= 1e-4
     assert np.abs(phi_b.detach().cpu().numpy() - z["phi"]).max() <= 1e-4
+
+
+def test_chunked_predict_and_kept_observables_do_not_pin_the_activation_arena():
+    """the logits / attention weights / scores / keep-sets a caller keeps are views of a small
+    observables buffer of their own (ABI 7), not of the multi-GB activation arena: after a no-grad forward the arena is
+    free, the model's last_score / last_keep hold a few MB, and batched_predict in chunks keeps one chunk's observables per
+    chunk -- "chunking changes nothing but the peak memory" is true again.  A second backward through one fused forward
+    raises a clear error instead of an AttributeError."""
+    from bench import build_workload
+    from get_amd.batch import batched_predict
+    wl = build_workload(batch=16, n_evd=30, seed=91, device=DEV)
+    model, nb = wl["model"].train(False), wl["batches"][0]
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        q, d, k = nb.inputs()
+        phi = model(q, d, **k)
+    torch.cuda.synchronize()
+    held = torch.cuda.memory_allocated() - base
+    assert held < 32 << 20, f"a no-grad forward left {held / 2**20:.0f} MiB allocated: the arena is pinned by a kept view"
+    del phi
+    base = torch.cuda.memory_allocated()
+    peak0 = torch.cuda.max_memory_allocated()
+    torch.cuda.reset_peak_memory_stats()
+    phi_c, words_c, evd_c = batched_predict(model, nb, claims_per_call=4)
+    torch.cuda.synchronize()
+    kept = torch.cuda.memory_allocated() - base
+    assert kept < 64 << 20, f"chunked predict keeps {kept / 2**20:.0f} MiB: per-chunk arenas are held until the final cat"
+    peak_chunked = torch.cuda.max_memory_allocated() - base
+    torch.cuda.reset_peak_memory_stats()
+    phi_f, words_f, evd_f = batched_predict(model, nb)
+    torch.cuda.synchronize()
+    peak_full = torch.cuda.max_memory_allocated() - base
+    assert peak_chunked < 0.6 * peak_full, (peak_chunked, peak_full)
+    assert float((phi_c - phi_f).abs().max()) <= 1e-5 and float((evd_c - evd_f).abs().max()) <= 1e-6
+    # second backward through one fused forward: explicit error
+    model.train(False)
+    q, d, k = nb.inputs()
+    loss = torch.nn.functional.cross_entropy(model(q, d, **k), nb.labels)
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="ran twice"):
+        loss.backward()
+
+
+def test_attention_weight_gradients_flow_through_the_fused_path(monkeypatch):
+    """A loss term on the returned attention weights (they were marked non-differentiable, the term silently
+    got zero gradient): gh_get_backward's g_word_w / g_evd_w inputs against the module-by-module path on the `small` case."""
+    from get_amd import fused
+    grads = {}
+    for use_fused in (True, False):
+        monkeypatch.setattr(fused, "ENABLED", use_fused)
+        cfg, seed = MODEL_CASES["small"]
+        model = build_model(cfg, seed)
+        raw = make_raw_batch(cfg, seed)
+        inp = assemble_inputs(raw, cfg, O.convert_text)
+        kargs = to_dev(reference_kargs(inp, torch, output_ranking=True))
+        phi, (ww, ew) = model(torch.from_numpy(inp["query"]).to(DEV), torch.from_numpy(inp["document"]).to(DEV), **kargs)
+        gw = torch.linspace(-1, 1, ww.numel(), device=DEV).view_as(ww)
+        ge = torch.linspace(1, -1, ew.numel(), device=DEV).view_as(ew)
+        ((ww * gw).sum() + (ew * ge).sum() + 0.0 * phi.sum()).backward()
+        grads[use_fused] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    assert set(grads[True]) == set(grads[False]) and len(grads[True]) >= 30
+    moved = 0
+    for k, g in grads[False].items():
+        err = float((grads[True][k] - g).abs().max())
+        assert err <= 2e-5 * float(g.abs().max()) + 1e-7, (k, err)
+        moved += int(float(g.abs().max()) > 0)
+    assert moved >= 25, "the attention-weight loss produced no gradient"
 
 
 def test_batched_predict_equals_per_claim_predict():

@@ -185,7 +185,7 @@ def _load_cell(mod, p, prefix=""):
 
 @pytest.mark.parametrize("ci", range(len(cases.G2_CASES)))
 @pytest.mark.parametrize("mode", ["dense", "native"])
-def test_ggnn_cell_vs_golden_and_oracle(ci, mode):
+def test_ggnn_cell_vs_golden_and_oracle(ci, mode, arith_mode):
     from get_amd import modules, ops
     z, meta = load("g2_ggnn.npz")
     n, r, din, dout, window = cases.G2_CASES[ci]
@@ -263,7 +263,7 @@ def test_gsl_keep_sets_golden():
 
 # ---------------------------------------------------------------- a4 GGNN_with_GSL (G4)
 @pytest.mark.parametrize("ci", range(len(cases.G4_CASES)))
-def test_ggnn_with_gsl_vs_golden(ci):
+def test_ggnn_with_gsl_vs_golden(ci, arith_mode):
     from get_amd import modules
     z, meta = load("g4_ggnn_gsl.npz")
     m = meta[ci]
@@ -292,7 +292,7 @@ def test_ggnn_with_gsl_vs_golden(ci):
 
 # ---------------------------------------------------------------- a5/a6 attention (G5, G6)
 @pytest.mark.parametrize("ci", range(len(cases.G5_CASES)))
-def test_concat_att_vs_golden(ci):
+def test_concat_att_vs_golden(ci, arith_mode):
     from get_amd import modules
     z, meta = load("g5_concat_att.npz")
     b, l, xl, dr, ha, heads, mkind = cases.G5_CASES[ci]

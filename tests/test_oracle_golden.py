@@ -222,6 +222,47 @@ def test_state_dict_contract_fixture_lists_dead_params(golden_dir):
         assert tuple(contract[k]) == tuple(shp), k
 
 
+def test_g9_reference_kargs_reproduce_what_the_fitter_hands_over():
+    """G9: oracle/assemble.py `reference_kargs` -- the hand-written restatement of the fitter's
+    de-padding and kargs protocol (char_man_fitter_query_repr1.py:204-250) that every parity test feeds the models with --
+    against the kargs CAPTURED from the reference's own `_get_multiple_evidences_predictions_normal` (stub net, `small`
+    case).  Every key forward() consumes must match in dtype, shape and value; the captured keys reference_kargs omits
+    must be exactly the ones forward() ignores, and the drop-in's key table must cover all of them."""
+    from get_amd.keywords import KeyWordSettings as K
+    from oracle.assemble import reference_kargs
+    z, meta = load("g9_fitter_kargs_small.npz")
+    cfg, seed = MODEL_CASES[meta["case"]]
+    inp = assemble_inputs(make_raw_batch(cfg, seed), cfg, O.convert_text)
+    mine = reference_kargs(inp, torch)
+    assert np.array_equal(z["query"], inp["query"]) and np.array_equal(z["document"], inp["document"])
+    ignored = {"query_content_without_padding_evidences", "query_char_source", "doc_char_source"}
+    assert set(meta["keys"]) - set(mine) == ignored
+    assert set(mine) <= set(meta["keys"])
+
+    def same(name, d, v):
+        if d["kind"] == "scalar":
+            assert v == d["value"], name
+            return
+        if d["kind"] == "tuple":
+            assert isinstance(v, tuple) and len(v) == len(d["items"]), name
+            for i, (di, vi) in enumerate(zip(d["items"], v)):
+                if vi is not None:                      # (reference_kargs leaves the LSTM-legacy sort indices of the CLAIM side out)
+                    same(f"{name}::{i}", di, vi)
+            return
+        a = v.numpy() if torch.is_tensor(v) else np.asarray(v)
+        exp = z[name]
+        assert str(a.dtype) == d["dtype"] and list(a.shape) == d["shape"], (name, a.dtype, a.shape, d)
+        assert np.array_equal(a, exp), name
+
+    for k, v in mine.items():
+        same(f"k::{k}", meta["desc"][k], v)
+    # only the claim side's sort indices are omitted (never read: graph_based_semantic_structure.py uses doc_lens_indices[2] alone)
+    assert mine["query_lens_indices"][0] is None and all(x is not None for x in mine["doc_lens_indices"])
+    # the drop-in's vocabulary holds every key string the fitter uses
+    vocab = {v for k, v in vars(K).items() if isinstance(v, str) and not k.startswith("_")}
+    assert set(meta["keys"]) - ignored <= vocab | {"fc_labels", "query_lens_indices"}, set(meta["keys"]) - vocab
+
+
 # ------------------------------------------------------------- the pin checks itself
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference only exists in the build container")
 def test_golden_fixtures_regenerate_identically(tmp_path):
