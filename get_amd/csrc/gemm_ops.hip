@@ -358,30 +358,52 @@ struct FinishItem {
   const float* u; const float* w2; float* e; int ldu, R, heads;
   const int32_t* rowg;
 };
-struct FinishArgs { FinishItem it[GH_MAX_PROBLEMS]; int n; };
+
+// Two shapes.  split = 1 (few-row products with many partials: the head's K = 3556 product has 55): one WORKGROUP per output
+// row, the four waves each sum a quarter of the partial tiles (eight 16-byte loads in flight per lane), the quarter sums meet
+// in LDS in wave order (fixed summation order: deterministic) and wave 0 applies the epilogue -- one wave per row walked all
+// `ks` partials alone, 14 dependent memory round trips = 18 us for the head; four waves need 4.  split = 0: one wave per
+// row, four rows per workgroup (few partials, many rows).
+struct FinishArgs { FinishItem it[GH_MAX_PROBLEMS]; int n; int split; };
 
 __global__ void __launch_bounds__(256)
 nt_finish_kernel(const FinishArgs F) {
   const FinishItem& it = F.it[blockIdx.y];
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= it.M) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool split = F.split != 0;
+  const int row = split ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+  if (row >= it.M) return;           // (workgroup-uniform when split)
   const int N4 = it.N / 4;
+  __shared__ float4 part[3][64];
+  int kb = 0, ke = it.ks;
+  if (split) { const int kq = (it.ks + 3) / 4; kb = wave * kq; ke = min(it.ks, kb + kq); }
   float pe[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) pe[c] = 0.f;
-  for (int c4 = lane; c4 < N4; c4 += 64) {
+  for (int c0 = 0; c0 < N4; c0 += 64) {
+    const int c4 = c0 + lane;
     const int col = 4 * c4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* p = it.ws + (size_t)row * it.N + col;
-    for (int k0 = 0; k0 < it.ks; k0 += 8) {            // eight partial tiles in flight, added in split order
-      float4 x[8];
+    if (c4 < N4 && kb < ke) {
+      const float* p = it.ws + (size_t)row * it.N + col;
+      for (int k0 = kb; k0 < ke; k0 += 8) {            // eight partial tiles in flight, added in split order
+        float4 x[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(p + (size_t)min(k0 + u, it.ks - 1) * it.stride);
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const float4*>(p + (size_t)min(k0 + u, ke - 1) * it.stride);
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (k0 + u < it.ks) { v.x += x[u].x; v.y += x[u].y; v.z += x[u].z; v.w += x[u].w; }
+        for (int u = 0; u < 8; ++u)
+          if (k0 + u < ke) { v.x += x[u].x; v.y += x[u].y; v.z += x[u].z; v.w += x[u].w; }
+      }
     }
+    if (split) {
+      if (c0 > 0) __syncthreads();                     // wave 0 is done with the previous chunk's quarter sums
+      if (wave > 0) part[wave - 1][lane] = v;
+      __syncthreads();
+      if (wave > 0) continue;
+#pragma unroll
+      for (int w = 0; w < 3; ++w) { const float4 q = part[w][lane]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+    }
+    if (c4 >= N4) continue;
     const size_t oo = (size_t)row * it.ldc + col;
     float* o = it.C + oo;
     if (it.bias) { const float4 b4 = *reinterpret_cast<const float4*>(it.bias + col); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
@@ -426,7 +448,7 @@ nt_finish_kernel(const FinishArgs F) {
       *reinterpret_cast<float4*>(o) = v;
     }
   }
-  if (it.epi == EPI_ATT) {
+  if (it.epi == EPI_ATT && (!split || wave == 0)) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       float v = pe[c];
@@ -673,7 +695,9 @@ struct Batch {
     L.kchunk = ct * 16;
     hipError_t e = launch_any();
     if (e != hipSuccess) err = e;
-    hipLaunchKernelGGL(nt_finish_kernel, dim3((max_m + 3) / 4, F.n), dim3(256), 0, s, F);
+    // many partials over few rows: a workgroup per row (the four waves share the partials); otherwise a wave per row
+    F.split = (ks >= 6 && max_m <= 8192) ? 1 : 0;
+    hipLaunchKernelGGL(nt_finish_kernel, dim3(F.split ? max_m : (max_m + 3) / 4, F.n), dim3(256), 0, s, F);
     e = hipGetLastError();
     if (e != hipSuccess) err = e;
     reset();
@@ -1007,27 +1031,31 @@ extern "C" int gh_ggnn_cell_bwd_bf16(const uint64_t* bits, const float* dinv, co
 //   att_out / att_ld: where `attended` goes (row pitch att_ld >= dr * heads: straight into a wider concatenation buffer).
 int gh::att_fwd_impl(const float* left, int nl, const int32_t* rowu, const float* right, const float* mask, const int32_t* goff,
                  const int32_t* rowg, int m_real, int b, int l, int xl, int dr, int ha, int heads, const float* w1, const float* w2,
-                 float* u, float* t, float* e, float* weights, float* attended, hipStream_t s) {
+                 float* u, float* t, float* e, float* weights, float* attended, hipStream_t s, int u_mode) {
   GH_REQUIRE(heads >= 1 && heads <= 8, "concat_att: heads=%d not in [1,8]", heads);
   GH_REQUIRE(b > 0 && l > 0 && dr > 0 && ha > 0, "concat_att_fwd: bad sizes");
+  GH_REQUIRE(u_mode >= 0 && u_mode <= 2, "concat_att_fwd: u_mode %d not in {0,1,2}", u_mode);
   GH_REQUIRE((goff == nullptr) == (rowg == nullptr), "concat_att_fwd: goff and rowg come together");
   if (!goff) m_real = b * l;
   GH_REQUIRE(m_real >= 0 && m_real <= b * l, "concat_att_fwd: node-compact rows %d do not fit b*l=%d", m_real, b * l);
-  if (!rowu) nl = b;
+  if (!rowu && u_mode != 1) nl = b;      // (the u-only call names its row count itself)
   const int M = m_real;
   const bool one_block = ha <= Batch(false, M, s).bn;      // column block of the tile configuration this launch will use
   GH_REQUIRE(one_block || (ha % 4 == 0 && al16(t) && al16(u) && al16(w2)),
              "concat_att_fwd: attention hidden %d wider than one column block needs float4-shaped rows", ha);
   const int xl_in = (left && xl > 0) ? xl : 0;      // column offset of the right branch inside linear1.weight
-  if (left && xl > 0) {  // u = W1[:, :xl] . left -- once per pair / claim, not per token (two_branches_attention.py:137-140)
-    Batch bt(false, nl, s);
-    bt.add(gemm_problem(nl, ha, EPI_STORE, u, ha, left, xl, w1, xl + dr, xl));
-    bt.flush();
-    GH_CHECK_HIP(bt.err);
-  } else {
-    GH_CHECK_HIP(hipMemsetAsync(u, 0, sizeof(float) * (size_t)nl * ha, s));
-    xl = 0;
+  if (u_mode != 2) {
+    if (left && xl > 0) {  // u = W1[:, :xl] . left -- once per pair / claim, not per token (two_branches_attention.py:137-140)
+      Batch bt(false, nl, s);
+      bt.add(gemm_problem(nl, ha, EPI_STORE, u, ha, left, xl, w1, xl + dr, xl));
+      bt.flush();
+      GH_CHECK_HIP(bt.err);
+    } else {
+      GH_CHECK_HIP(hipMemsetAsync(u, 0, sizeof(float) * (size_t)nl * ha, s));
+    }
   }
+  if (u_mode == 1) return 0;
+  if (!(left && xl > 0)) xl = 0;
   const int32_t* urow = rowu ? rowu : rowg;
   if (M > 0) {  // t = tanh(W1[:, xl:] . right_t + u) ; e = W2 t  (:140-141)
     Batch bt(false, M, s);
@@ -1039,7 +1067,7 @@ int gh::att_fwd_impl(const float* left, int nl, const int32_t* rowu, const float
     GH_CHECK_HIP(bt.err);
     if (!one_block) {
       FinishArgs F;
-      F.n = 1;
+      F.n = 1; F.split = 0;
       F.it[0] = FinishItem{t, 0, 1, M, ha, EPI_ATT, 0, ha, t, nullptr, nullptr, nullptr, nullptr, nullptr, u, w2, e, ha, l, heads, urow};
       hipLaunchKernelGGL(nt_finish_kernel, dim3((M + 3) / 4, 1), dim3(256), 0, s, F);
       GH_LAUNCH_CHECK();
@@ -1065,7 +1093,7 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
                  const float* g_att, const float* g_w, float* de, float* dpre, float* du,
                  float* dleft, float* dright, float* dw1, float* dw2,
                  const int32_t* claim_offsets, int nl, float* du_c, int dleft_accumulate, hipStream_t s,
-                 const int32_t* rowg, float* dw_tmp, const GateFuse* next) {
+                 const int32_t* rowg, float* dw_tmp, const GateFuse* next, int dleft_late) {
   GH_REQUIRE(heads >= 1 && heads <= 8, "concat_att: heads=%d not in [1,8]", heads);
   if (!goff) m_real = b * l;
   GH_REQUIRE(m_real >= 0 && m_real <= b * l, "concat_att_bwd: node-compact rows %d do not fit b*l=%d", m_real, b * l);
@@ -1113,7 +1141,7 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }
-  if (xl > 0 && dleft) {  // dleft = du W1[:, :xl]
+  if (xl > 0 && dleft && !dleft_late) {  // dleft = du W1[:, :xl]
     Batch bt(false, nl, s);
     Problem p = gemm_problem(nl, xl, EPI_STORE, dleft, xl, dul, ha, w1t, ha, ha);
     p.accumulate = dleft_accumulate ? 1 : 0;
@@ -1127,6 +1155,14 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }
+  }
+  if (weights_only && dleft_late && xl > 0 && dleft) {  // the left gradient, deferred to this (weight-gradient stream) call
+    Batch bt(false, nl, s);
+    Problem p = gemm_problem(nl, xl, EPI_STORE, dleft, xl, dul, ha, w1t, ha, ha);
+    p.accumulate = dleft_accumulate ? 1 : 0;
+    bt.add(p);
+    bt.flush();
+    GH_CHECK_HIP(bt.err);
   }
   if (!dw1) return 0;
   if (M > 0) {

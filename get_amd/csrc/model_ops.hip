@@ -322,6 +322,13 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
                          A + f.q_repr, A + f.has, A + f.new_left, d.cs, H, Mo->claim_src_rows);
     GH_LAUNCH_CHECK();
   }
+  // the left projections of both attention layers depend on the claim branch only (two_branches_attention.py:137-140:
+  // linear1 splits into a left and a right part): they run here, underneath the evidence cells, instead of in front of the
+  // two attention GEMMs on the main stream (two split-K launches + their finish kernels, ~45 us of the critical path)
+  GH_TRY(att_fwd_impl(A + f.q_repr, d.B, nullptr, nullptr, nullptr, nullptr, nullptr, 0, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1,
+                      Mo->att_word.w2, A + f.uw, nullptr, nullptr, nullptr, nullptr, ss, 1));
+  GH_TRY(att_fwd_impl(A + f.new_left, d.B, nullptr, nullptr, nullptr, nullptr, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he, Mo->att_evd.w1,
+                      Mo->att_evd.w2, A + f.ue, nullptr, nullptr, nullptr, nullptr, ss, 1));
   // ---- evidence branch (:107; wrapper.py:165-172): cell -> scorer + top-k -> cell on the refined graph
   const int32_t* goff = d.compact ? Ba->goff : nullptr;
   const int32_t* ids1 = d.compact ? Ba->cids : Ba->d_ids;
@@ -336,12 +343,12 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
   // ---- word-level attention (:173-193): the left input is the claim vector -> ONE u row per claim
   GH_TRY(att_fwd_impl(A + f.q_repr, d.B, I32(A, f.rowc), A + f.c2.out, d.compact ? Ba->maskf : A + f.maskf_p, goff,
                       d.compact ? Ba->rowg : nullptr, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1, Mo->att_word.w2, A + f.uw, A + f.tw,
-                      A + f.ew, O + f.ww, A + f.avg, s));
+                      A + f.ew, O + f.ww, A + f.avg, s, 2));
   // ---- evidence-level assembly + attention (:157-171, :195-221)
   GH_TRY(gh_evd_assemble_fwd(A + f.avg, I32(A, f.offsets), Mo->article_src_table, d.as > 0 ? Ba->doc_sources : nullptr, Ba->doc_sources_i64,
                              Ba->document, Ba->document_i64, d.B, d.n, d.Xa, d.as, d.R, A + f.right_e, A + f.mask_e, (void*)s));
   GH_TRY(att_fwd_impl(A + f.new_left, d.B, nullptr, A + f.right_e, A + f.mask_e, nullptr, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he,
-                      Mo->att_evd.w1, Mo->att_evd.w2, A + f.ue, A + f.te, A + f.ee, O + f.we, A + f.att_e, s));
+                      Mo->att_evd.w1, Mo->att_evd.w2, A + f.ue, A + f.te, A + f.ee, O + f.we, A + f.att_e, s, 2));
   // ---- head (:251-267, :69-74): Linear([claim | attended evidences]) -> Linear, no activation
   GH_TRY(linear2_fwd(A + f.new_left, d.Xl, A + f.att_e, d.Dre * d.he, Mo->out0_w, Mo->out0_b, A + f.y0, d.B, H, s));
   GH_TRY(gh_linear_fwd(A + f.y0, Mo->out1_w, Mo->out1_b, O + f.phi, d.B, H, d.C, (void*)s));
@@ -376,38 +383,40 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
     GH_TRY(linear2_bwd(A + f.new_left, d.Xl, A + f.att_e, d.Dre * d.he, Mo->out0_wt, Wb + w.d_y0, d.B, H, nullptr, 0, nullptr,
                        Mo->d_out0_w, Mo->d_out0_b, ss));
     // ---- evidence-level attention; its left gradient adds to the head's
+    //      (the left gradients -- d_new_left here, d_q below -- feed the claim branch only: their GEMMs run with the linear1 weight
+    //       gradients on the side stream, `dleft_late`, and so does the split of d_new_left into d_q + claim-source table gradient)
     GH_TRY(att_bwd_impl(A + f.new_left, A + f.right_e, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he, Mo->att_evd.w1t, Mo->att_evd.w2, A + f.te,
                         O + f.we, Wb + w.d_att_e, g_evd_w, Wb + w.de_e, Wb + w.dpre_e, Wb + w.du_e, Wb + w.d_new_left, Wb + w.dright_e,
-                        nullptr, Mo->att_evd.dw2, nullptr, d.B, nullptr, 1, s));
+                        nullptr, Mo->att_evd.dw2, nullptr, d.B, nullptr, 1, s, nullptr, nullptr, nullptr, 1));
     GH_TRY(stream_after(ss, s, ev.ev[3]));
     GH_TRY(att_bwd_impl(A + f.new_left, A + f.right_e, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he, Mo->att_evd.w1t, Mo->att_evd.w2, A + f.te,
-                        O + f.we, Wb + w.d_att_e, g_evd_w, Wb + w.de_e, Wb + w.dpre_e, Wb + w.du_e, nullptr, nullptr, Mo->att_evd.dw1,
-                        Mo->att_evd.dw2, nullptr, d.B, nullptr, 0, ss));
+                        O + f.we, Wb + w.d_att_e, g_evd_w, Wb + w.de_e, Wb + w.dpre_e, Wb + w.du_e, Wb + w.d_new_left, nullptr, Mo->att_evd.dw1,
+                        Mo->att_evd.dw2, nullptr, d.B, nullptr, 1, ss, nullptr, nullptr, nullptr, 1));
+    if (d.cs > 0) {
+      if (Ba->query_sources_i64)
+        hipLaunchKernelGGL(left_assemble_bwd_kernel<int64_t>, dim3(1), dim3(256), 0, ss, Wb + w.d_new_left, (const int64_t*)Ba->query_sources,
+                           A + f.has, Wb + w.d_q, Mo->d_claim_src_table, d.B, d.cs, H, Mo->claim_src_rows);
+      else
+        hipLaunchKernelGGL(left_assemble_bwd_kernel<int32_t>, dim3(1), dim3(256), 0, ss, Wb + w.d_new_left, (const int32_t*)Ba->query_sources,
+                           A + f.has, Wb + w.d_q, Mo->d_claim_src_table, d.B, d.cs, H, Mo->claim_src_rows);
+      GH_LAUNCH_CHECK();
+    }
     // ---- evidence-level assembly: d_avg (rows of claims with more than n_max evidences stay zero), article-source table
     if (!Ba->counts_fit) GH_CHECK_HIP(hipMemsetAsync(Wb + w.d_avg, 0, sizeof(float) * (size_t)d.B1 * d.Xa, s));
     GH_TRY(gh_evd_assemble_bwd(Wb + w.dright_e, I32(A, f.offsets), d.as > 0 ? Ba->doc_sources : nullptr, Ba->doc_sources_i64, d.B, d.n, d.Xa,
                                d.as, Wb + w.d_avg, d.as > 0 ? Mo->d_article_src_table : nullptr, (void*)s));
-    if (d.cs > 0) {
-      if (Ba->query_sources_i64)
-        hipLaunchKernelGGL(left_assemble_bwd_kernel<int64_t>, dim3(1), dim3(256), 0, s, Wb + w.d_new_left, (const int64_t*)Ba->query_sources,
-                           A + f.has, Wb + w.d_q, Mo->d_claim_src_table, d.B, d.cs, H, Mo->claim_src_rows);
-      else
-        hipLaunchKernelGGL(left_assemble_bwd_kernel<int32_t>, dim3(1), dim3(256), 0, s, Wb + w.d_new_left, (const int32_t*)Ba->query_sources,
-                           A + f.has, Wb + w.d_q, Mo->d_claim_src_table, d.B, d.cs, H, Mo->claim_src_rows);
-      GH_LAUNCH_CHECK();
-    }
     // ---- word-level attention: per-pair du summed per claim; d(claim vector) accumulates on top of the head / evidence part.
     //      Its dright GEMM produces the gradient of the second evidence cell's output and nothing else reads it: the GEMM's
     //      epilogue applies that cell's gate head (gf2); likewise the second cell's dX GEMM feeds the first cell's (gf1).
     GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
                         O + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, Wb + w.g2, nullptr,
-                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, s, d.compact ? Ba->rowg : nullptr, Wb + w.dw_w, &gf2));
+                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, s, d.compact ? Ba->rowg : nullptr, Wb + w.dw_w, &gf2, 1));
     // ---- side stream: linear1's weight gradient of the word attention, then the claim branch's backward -- underneath
     //      the evidence cells' chain on the main stream
     GH_TRY(stream_after(ss, s, ev.ev[4]));
     GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
-                        O + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, nullptr, nullptr, Mo->att_word.dw1,
-                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 0, ss));
+                        O + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, nullptr, Mo->att_word.dw1,
+                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, ss, nullptr, nullptr, nullptr, 1));
     GH_TRY(gh_masked_mean_bwd(Wb + w.d_q, Ba->q_ids, A + f.lens_eff, Wb + w.d_qhid, d.B, d.L, H, (void*)ss));
     GH_TRY(cell_bwd(Mo->claim, f.q, A, Ba->q_bits, Ba->q_dinv, Ba->q_vals, nullptr, nullptr, 0, Mo->embedding, Ba->q_ids, d.B, d.L, d.D, H,
                     Wb + w.d_qhid, Wb, w.qs, nullptr, Ba->drop_claim, Ba->seed_claim, ss));
