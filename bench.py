@@ -598,14 +598,18 @@ def main():
     ap.add_argument("--measure-build", action="store_true",
                     help="kernel A/B tooling only: load lib/libget_hip_measure.so (make -C get_amd/csrc measure), honour the GH_* "
                          "switches, and stamp the line as NOT a product measurement")
+    ap.add_argument("--measure-lib", default="", help="kernel A/B tooling only: like --measure-build, but loads the variant build "
+                                                      "get_amd/lib/libget_hip_NAME.so (make -C get_amd/csrc variant NAME=... EXTRA=...)")
     args = ap.parse_args()
+    if args.measure_lib:
+        args.measure_build = True
 
     # measurement switches of the library (GH_*) change what the kernels compute or how they are scheduled: a bench line
     # taken with one set is not a measurement of the product.  (The shipped .so ignores them -- they only exist in the
     # -DGH_MEASURE tool build -- but a GET_AMD_LIB override could point at such a build.)
     leaked = sorted(k for k in os.environ if k.startswith("GH_"))
     if args.measure_build:
-        os.environ["GET_AMD_LIB"] = os.path.join(ROOT, "get_amd", "lib", "libget_hip_measure.so")
+        os.environ["GET_AMD_LIB"] = os.path.join(ROOT, "get_amd", "lib", f"libget_hip_{args.measure_lib or 'measure'}.so")
         from get_amd import _lib as _l
         _l.LIB_PATH = os.environ["GET_AMD_LIB"]
     elif leaked or os.environ.get("GET_AMD_LIB"):
