@@ -125,10 +125,13 @@ int att_bwd_impl(const float* left, const float* right, const int32_t* goff, int
                  int heads, const float* w1t, const float* w2, const float* t, const float* weights, const float* g_att,
                  const float* g_w, float* de, float* dpre, float* du, float* dleft, float* dright, float* dw1, float* dw2,
                  const int32_t* claim_offsets, int nl, float* du_c, int dleft_accumulate, hipStream_t s,
-                 const int32_t* rowg = nullptr, float* dw_tmp = nullptr, const GateFuse* next = nullptr, int dleft_late = 0);
+                 const int32_t* rowg = nullptr, float* dw_tmp = nullptr, const GateFuse* next = nullptr, int dleft_late = 0,
+                 float* dw2_buf = nullptr);
 // att_fwd_impl u_mode: 0 = the whole layer; 1 = ONLY the left projection u (the caller runs it early, e.g. on the claim branch's
 //   stream); 2 = u is already there.  att_bwd_impl dleft_late: the left gradient's GEMM runs in the dw1-only call (dright == NULL)
-//   instead of the first one, i.e. on the weight-gradient stream, off the critical path.
+//   instead of the first one, i.e. on the weight-gradient stream, off the critical path; with dw2_buf ([b][heads][ha] floats, the same
+//   pointer in both calls) the per-pair dW2 partials go there instead of the stream workspace and their reduction, like the
+//   per-claim sum of du, moves into the second call as well.
 int linear2_fwd(const float* x0, int k0, const float* x1, int k1, const float* w, const float* bias, float* y, int m, int n, hipStream_t s);
 int linear2_bwd(const float* x0, int k0, const float* x1, int k1, const float* wt, const float* g, int m, int n, float* dx0,
                 int dx0_accumulate, float* dx1, float* dw, float* db, hipStream_t s);

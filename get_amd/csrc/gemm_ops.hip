@@ -1093,7 +1093,7 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
                  const float* g_att, const float* g_w, float* de, float* dpre, float* du,
                  float* dleft, float* dright, float* dw1, float* dw2,
                  const int32_t* claim_offsets, int nl, float* du_c, int dleft_accumulate, hipStream_t s,
-                 const int32_t* rowg, float* dw_tmp, const GateFuse* next, int dleft_late) {
+                 const int32_t* rowg, float* dw_tmp, const GateFuse* next, int dleft_late, float* dw2_buf) {
   GH_REQUIRE(heads >= 1 && heads <= 8, "concat_att: heads=%d not in [1,8]", heads);
   if (!goff) m_real = b * l;
   GH_REQUIRE(m_real >= 0 && m_real <= b * l, "concat_att_bwd: node-compact rows %d do not fit b*l=%d", m_real, b * l);
@@ -1114,17 +1114,18 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
   // dW2 = de^T t rides along with the dpre pass (per-pair partials in the workspace, one reduce)
   const size_t dw2_bytes = (size_t)b * heads * ha * sizeof(float);
   const Workspace wsp = workspace_for(s);
-  dw2_part = (wsp.p && dw2_bytes <= wsp.bytes && ha % 4 == 0) ? wsp.p : nullptr;
+  const bool late = dleft_late && dw2_buf && ha % 4 == 0;      // partials in the caller's buffer, reduced by the second call
+  dw2_part = late ? dw2_buf : ((wsp.p && dw2_bytes <= wsp.bytes && ha % 4 == 0) ? wsp.p : nullptr);
   if (int e = launch_att_dpre(de, w2, t, goff, m_real, b, l, ha, heads, dpre, du, dw2_part, s, dw_written ? dw_tmp : nullptr,
                               dw_written ? weights : nullptr, dw_written ? de : nullptr)) return e;
-  if (dw2_part) {
+  if (dw2_part && !late) {
     ReduceArgs R;
     R.n = 1;
     R.it[0] = ReduceItem{dw2_part, dw2, heads, ha, ha, b, (long long)heads * ha};
     hipLaunchKernelGGL(reduce_partials_wave_kernel, dim3((heads * (ha / 4) + 3) / 4, 1), dim3(256), 0, s, R);
     GH_LAUNCH_CHECK();
   }
-  if (claim_offsets && xl > 0)
+  if (claim_offsets && xl > 0 && !dleft_late)
     if (int e = gh_seg_sum(du, claim_offsets, du_c, nl, ha, (gh_stream_t)s)) return e;
   if (M > 0 && next) {  // dright (= the gradient of the cell that produced `right`) is consumed by that cell's gate head only:
     Batch bt(false, M, s, false, 6, dr);      // g = softmax part (in dright) + dpre W1[:, xl:] goes straight into dhp / dzp / dxp
@@ -1155,6 +1156,17 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }
+  }
+  if (weights_only && dleft_late) {
+    if (dw2_buf && ha % 4 == 0) {      // the first call left the per-pair dW2 partials in dw2_buf
+      ReduceArgs R;
+      R.n = 1;
+      R.it[0] = ReduceItem{dw2_buf, dw2, heads, ha, ha, b, (long long)heads * ha};
+      hipLaunchKernelGGL(reduce_partials_wave_kernel, dim3((heads * (ha / 4) + 3) / 4, 1), dim3(256), 0, s, R);
+      GH_LAUNCH_CHECK();
+    }
+    if (claim_offsets && xl > 0)
+      if (int e = gh_seg_sum(du, claim_offsets, du_c, nl, ha, (gh_stream_t)s)) return e;
   }
   if (weights_only && dleft_late && xl > 0 && dleft) {  // the left gradient, deferred to this (weight-gradient stream) call
     Batch bt(false, nl, s);

@@ -30,7 +30,7 @@ struct FwdBuf {
 };
 struct BwdBuf {
   int64_t d_y0, d_new_left, d_att_e, de_e, dpre_e, du_e, dright_e, d_avg;
-  int64_t de_w, dw_w, dpre_w, du_w, du_c, d_q, g2, d_qhid, qs[5], sc2[5], sc1[5], dx2;
+  int64_t de_w, dw_w, dpre_w, du_w, du_c, d_q, g2, d_qhid, qs[5], sc2[5], sc1[5], dx2, dw2p_e, dw2p_w;
   int64_t total;
 };
 struct Bump {
@@ -117,6 +117,8 @@ static int layout(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d, FwdBu
   for (int i = 0; i < 5; ++i) w.sc2[i] = c.take((int64_t)d.Mr * d.H);
   for (int i = 0; i < 5; ++i) w.sc1[i] = c.take((int64_t)d.Mr * d.H);
   w.dx2 = c.take((int64_t)d.Mr * d.H);
+  // per-pair partials of the two attention layers' dW2 (reduced on the side stream)
+  w.dw2p_e = c.take((int64_t)d.B * d.he * d.H); w.dw2p_w = c.take((int64_t)d.B1 * d.hw * d.H);
   w.total = c.off;
   return 0;
 }
@@ -387,11 +389,11 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
     //       gradients on the side stream, `dleft_late`, and so does the split of d_new_left into d_q + claim-source table gradient)
     GH_TRY(att_bwd_impl(A + f.new_left, A + f.right_e, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he, Mo->att_evd.w1t, Mo->att_evd.w2, A + f.te,
                         O + f.we, Wb + w.d_att_e, g_evd_w, Wb + w.de_e, Wb + w.dpre_e, Wb + w.du_e, Wb + w.d_new_left, Wb + w.dright_e,
-                        nullptr, Mo->att_evd.dw2, nullptr, d.B, nullptr, 1, s, nullptr, nullptr, nullptr, 1));
+                        nullptr, Mo->att_evd.dw2, nullptr, d.B, nullptr, 1, s, nullptr, nullptr, nullptr, 1, Wb + w.dw2p_e));
     GH_TRY(stream_after(ss, s, ev.ev[3]));
     GH_TRY(att_bwd_impl(A + f.new_left, A + f.right_e, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he, Mo->att_evd.w1t, Mo->att_evd.w2, A + f.te,
                         O + f.we, Wb + w.d_att_e, g_evd_w, Wb + w.de_e, Wb + w.dpre_e, Wb + w.du_e, Wb + w.d_new_left, nullptr, Mo->att_evd.dw1,
-                        Mo->att_evd.dw2, nullptr, d.B, nullptr, 1, ss, nullptr, nullptr, nullptr, 1));
+                        Mo->att_evd.dw2, nullptr, d.B, nullptr, 1, ss, nullptr, nullptr, nullptr, 1, Wb + w.dw2p_e));
     if (d.cs > 0) {
       if (Ba->query_sources_i64)
         hipLaunchKernelGGL(left_assemble_bwd_kernel<int64_t>, dim3(1), dim3(256), 0, ss, Wb + w.d_new_left, (const int64_t*)Ba->query_sources,
@@ -410,13 +412,14 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
     //      epilogue applies that cell's gate head (gf2); likewise the second cell's dX GEMM feeds the first cell's (gf1).
     GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
                         O + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, Wb + w.g2, nullptr,
-                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, s, d.compact ? Ba->rowg : nullptr, Wb + w.dw_w, &gf2, 1));
+                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, s, d.compact ? Ba->rowg : nullptr, Wb + w.dw_w, &gf2, 1,
+                        Wb + w.dw2p_w));
     // ---- side stream: linear1's weight gradient of the word attention, then the claim branch's backward -- underneath
     //      the evidence cells' chain on the main stream
     GH_TRY(stream_after(ss, s, ev.ev[4]));
     GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
                         O + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, nullptr, Mo->att_word.dw1,
-                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, ss, nullptr, nullptr, nullptr, 1));
+                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, ss, nullptr, nullptr, nullptr, 1, Wb + w.dw2p_w));
     GH_TRY(gh_masked_mean_bwd(Wb + w.d_q, Ba->q_ids, A + f.lens_eff, Wb + w.d_qhid, d.B, d.L, H, (void*)ss));
     GH_TRY(cell_bwd(Mo->claim, f.q, A, Ba->q_bits, Ba->q_dinv, Ba->q_vals, nullptr, nullptr, 0, Mo->embedding, Ba->q_ids, d.B, d.L, d.D, H,
                     Wb + w.d_qhid, Wb, w.qs, nullptr, Ba->drop_claim, Ba->seed_claim, ss));
