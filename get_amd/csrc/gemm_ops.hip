@@ -696,7 +696,7 @@ struct Batch {
     hipError_t e = launch_any();
     if (e != hipSuccess) err = e;
     // many partials over few rows: a workgroup per row (the four waves share the partials); otherwise a wave per row
-    F.split = (ks >= 6 && max_m <= 8192) ? 1 : 0;
+    F.split = (ks >= 16 && max_m <= 8192) ? 1 : 0;      // (ks = 9, M = 960 -- the claim cell, the evidence-level attention -- measured equal or slower split)
     hipLaunchKernelGGL(nt_finish_kernel, dim3(F.split ? max_m : (max_m + 3) / 4, F.n), dim3(256), 0, s, F);
     e = hipGetLastError();
     if (e != hipSuccess) err = e;
