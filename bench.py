@@ -712,8 +712,11 @@ def main():
     # (256 / N claims per GPU), its own model replica and trainer, same step.  Every rank takes part (the
     # gradient all-reduce and the block barriers are collectives); the weak-scaling figure above stays `value`.
     strong = None
+    # (configs[3] is defined on the Snopes shape: only the headline shape carries the leg -- at h = 768 a 256-claim batch on one
+    #  GPU is 2.4 GB per activation, past what the fast kernels' buffer descriptors address)
+    strong_shape = (args.len_right, args.hidden, args.word_heads, args.window, args.n_evd) == (100, 300, 5, 3, 30)
     if (args.strong_too and not args.no_side_modes and args.global_batch <= 0 and not args.forward_only and args.gemm_mode == "fp32" and
-            STRONG_GLOBAL_BATCH % world == 0):
+            STRONG_GLOBAL_BATCH % world == 0 and strong_shape):
         gshard = (lambda counts: shard_claims(STRONG_GLOBAL_BATCH, rank, world, counts))
         cfg_s = SynthConfig(**{**cfg_in.__dict__, "batch": STRONG_GLOBAL_BATCH})
         wls = build_workload(seed=SEED, device=device, cfg=cfg_s, compact=False if args.padded else None, n_batches=2,

@@ -78,7 +78,7 @@ struct Problem {
   const float* gin; const float* in2; float* out2;
 };
 
-#define GH_MAX_PROBLEMS 8
+#define GH_MAX_PROBLEMS 12     // (sizeof(Launch) = 12 x 336 + 24 = 4056 of the 4096 kernarg bytes: the head's 3556-wide products are 12 column blocks)
 struct Launch {
   Problem p[GH_MAX_PROBLEMS];
   int nprob;
@@ -87,6 +87,7 @@ struct Launch {
   int kchunk;    // TN: rows per chunk, multiple of 16
   int dbg;       // measurement only (GH_DBG): bit 0 = skip the epilogue, bit 1 = skip the K loop
 };
+static_assert(sizeof(Launch) <= 4096, "Launch travels by value in the kernarg segment (4 KB)");
 
 __host__ __device__ __forceinline__ unsigned drop_hash(unsigned seed, unsigned idx) {
   unsigned x = idx * 0x9E3779B1u + seed;

@@ -13,34 +13,39 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 
 static bool s_lds_bad(const Problem& p) { return p.seg[0].lda % 8 || p.seg[0].ldb % 8; }
 // fast-path preconditions of gemm_nt.hip.h (NT: both operands contraction-contiguous) and gemm_tn.hip.h (TN); both LDS-DMA
+static void fast_why(int rule, int prob) {      // tool build: GH_FASTOK_DEBUG=1 names the rule that sent a launch to the generic kernel
+  static int dbg = -1;
+  if (dbg < 0) dbg = measure_env("GH_FASTOK_DEBUG", 0);
+  if (dbg) fprintf(stderr, "gemm: generic kernel (fast_ok rule %d, problem %d)\n", rule, prob);
+}
 static bool fast_ok(const Launch& L, bool tn) {
   for (int i = 0; i < L.nprob; ++i) {
     const Problem& p = L.p[i];
     const int ns = tn ? 1 : p.nseg;
     for (int j = 0; j < ns; ++j) {
       const Seg& s = p.seg[j];
-      if (!s.vecA || !s.vecB || s.gatherB || s.K < 4) return false;
-      if (tn && s.gatherA) return false;
+      if (!s.vecA || !s.vecB || s.gatherB || s.K < 4) { fast_why(1, i); return false; }
+      if (tn && s.gatherA) { fast_why(2, i); return false; }
     }
-    if (p.elt && tn && (p.M % 8 || p.N % 8 || s_lds_bad(p))) return false;
+    if (p.elt && tn && (p.M % 8 || p.N % 8 || s_lds_bad(p))) { fast_why(3, i); return false; }
     if (!tn) {  // operands are addressed through buffer descriptors: 31-bit byte offsets
       for (int j = 0; j < p.nseg; ++j) {
-        if (4.0 * (double)p.seg[j].ldb * (double)p.N >= 2147483648.0) return false;
-        if (!p.seg[j].gatherA && 4.0 * (double)p.seg[j].lda * (double)p.M >= 2147483648.0) return false;   // (gathered tables: < 2 GB by contract)
+        if (4.0 * (double)p.seg[j].ldb * (double)p.N >= 2147483648.0) { fast_why(4, i); return false; }
+        if (!p.seg[j].gatherA && 4.0 * (double)p.seg[j].lda * (double)p.M >= 2147483648.0) { fast_why(5, i); if (measure_env("GH_FASTOK_DEBUG", 0)) fprintf(stderr, "   seg %d lda %d M %d N %d K %d\n", j, p.seg[j].lda, p.M, p.N, p.seg[j].K); return false; }   // (gathered tables: < 2 GB by contract)
       }
     }
     if (tn) {
       const Seg& s = p.seg[0];
-      if (4.0 * (double)s.lda * (double)s.K >= 2147483648.0 || 4.0 * (double)s.ldb * (double)s.K >= 2147483648.0) return false;
+      if (4.0 * (double)s.lda * (double)s.K >= 2147483648.0 || 4.0 * (double)s.ldb * (double)s.K >= 2147483648.0) { fast_why(6, i); return false; }
     }
-    if (p.N % 4 || p.N < 4 || p.ldc % 4 || !al16(p.C)) return false;
-    if (tn && (p.M % 4 || p.M < 4)) return false;
+    if (p.N % 4 || p.N < 4 || p.ldc % 4 || !al16(p.C)) { fast_why(7, i); return false; }
+    if (tn && (p.M % 4 || p.M < 4)) { fast_why(8, i); return false; }
     if ((p.bias && !al16(p.bias)) || (p.bias2 && !al16(p.bias2)) || (p.out1 && !al16(p.out1)) || (p.in0 && !al16(p.in0)) || (p.in1 && !al16(p.in1)))
-      return false;
-    if (p.epi == EPI_ATT && (!al16(p.u) || p.ldu % 4 || !al16(p.w2))) return false;
-    if (p.epi == EPI_TANH_H && p.w2 && !al16(p.w2)) return false;
+      { fast_why(9, i); return false; }
+    if (p.epi == EPI_ATT && (!al16(p.u) || p.ldu % 4 || !al16(p.w2))) { fast_why(10, i); return false; }
+    if (p.epi == EPI_TANH_H && p.w2 && !al16(p.w2)) { fast_why(11, i); return false; }
     if (p.epi == EPI_GATE_PRE && (tn || !p.in0 || !p.in1 || !p.in2 || !p.out1 || !p.out2 || !al16(p.in2) || !al16(p.out2) ||
-                                  (p.gin && !al16(p.gin)) || p.elt)) return false;
+                                  (p.gin && !al16(p.gin)) || p.elt)) { fast_why(12, i); return false; }
   }
   return true;
 }
@@ -784,7 +789,9 @@ int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* d
     const uintptr_t al = (uintptr_t)a | (uintptr_t)xp | (uintptr_t)z | (uintptr_t)rr | (uintptr_t)rx | (uintptr_t)hh | (uintptr_t)out |
                          (uintptr_t)w_z0 | (uintptr_t)w_z1 | (uintptr_t)w_r0 | (uintptr_t)w_r1 | (uintptr_t)w_h0 | (uintptr_t)w_h1 |
                          (uintptr_t)b_z0 | (uintptr_t)b_z1 | (uintptr_t)b_r0 | (uintptr_t)b_r1 | (uintptr_t)b_h0 | (uintptr_t)b_h1;
-    partial_zero = ((al & 15) == 0) && (h % (bf ? 8 : 4) == 0) && h >= 4;
+    // (and only while the activations stay below the 2 GB a buffer descriptor addresses: beyond that the gate GEMMs take the
+    //  generic kernel -- fast_ok -- which reads every row)
+    partial_zero = ((al & 15) == 0) && (h % (bf ? 8 : 4) == 0) && h >= 4 && 4.0 * (double)h * (double)M < 2147483648.0;
     const int zfull = ((m_real + 127) / 128 + 1) * 128;
     const int zend = (partial_zero && zfull < m_rows) ? zfull : m_rows;
     GH_CHECK_HIP(hipMemsetAsync((char*)a + (size_t)m_real * h * (bf ? 2 : 4), 0, (size_t)(bf ? 2 : 4) * (size_t)(zend - m_real) * h, s));
