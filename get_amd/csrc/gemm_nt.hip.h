@@ -102,8 +102,12 @@ gemm_nt_kernel(const Launch L_byval) {
   const int n_inner = L.nprob * L.ksplit;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
-  const int m_tile = xcd + 8 * (slot / n_inner);
-  const int inner = slot % n_inner;
+  // (few-row launches -- fewer than 8 row tiles, e.g. the head's 32-row split-K products: the grid is m_tiles x n_inner and
+  //  consecutive workgroups, i.e. the 8 XCDs, take the (problem, K chunk) units of ONE row tile; the row-tile-per-XCD deal
+  //  would leave every workgroup of a one-row-tile launch on XCD 0)
+  const bool few = L.m_tiles < 8 && !(GH_DBG_BITS(L) & 32);
+  const int m_tile = few ? bid / n_inner : xcd + 8 * (slot / n_inner);
+  const int inner = few ? bid % n_inner : slot % n_inner;
   if (m_tile >= L.m_tiles) return;
   const int prob = inner % L.nprob;
   const int ks = inner / L.nprob;

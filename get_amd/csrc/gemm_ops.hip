@@ -76,7 +76,8 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
   }
   const int n_outer = tn ? L.ksplit : L.m_tiles;
   const int n_inner = tn ? L.m_tiles * L.nprob : L.nprob * L.ksplit;
-  const int grid = 8 * ((n_outer + 7) / 8) * n_inner;
+  const bool nt_few = !tn && L.m_tiles < 8 && fast && !(GH_DBG_BITS(L) & 32);      // gemm_nt.hip.h: linear work decode for launches of fewer than 8 row tiles
+  const int grid = nt_few ? n_outer * n_inner : 8 * ((n_outer + 7) / 8) * n_inner;
   if (grid <= 0) return hipSuccess;
   // profiler row: by the SIZE of the launch, not by the tile configuration it runs on -- the activation-sized single-problem
   // launches that the occupancy rule moves to the 32-row tile belong with the big GEMMs (booked under
@@ -579,10 +580,22 @@ struct Batch {
       const int ks_max = (k_total / 256 > 1) ? k_total / 256 : 1;
       if (ks > ks_max) ks = ks_max;
       if (ks < 1) ks = 1;
+      // The K chunks are dealt round-robin to the 8 XCDs (chunk c runs on XCD c % 8, gemm_tn.hip.h): a chunk count that is
+      // not a multiple of 8 leaves some XCDs one chunk (1 / 8 of their work at 65 chunks) more than the others.  Measured on
+      // the bench step (A/B, one box): 65 chunks 158.6 K pairs/s, 72 chunks 159.9 K, 85 chunks 156.4 K.
+      static int xcd_rule = -1;
+      if (xcd_rule < 0) xcd_rule = measure_env("GH_TN_XCD_RULE", 1);
+      const int align = L.p[0].elt ? 32 : 16;      // K tile of the kernel (bf16 storage: 32 rows)
+      if (xcd_rule && ks >= 12) ks = ((ks + 4) / 8) * 8;
       int chunk = (k_total + ks - 1) / ks;
-      chunk = ((chunk + 31) / 32) * 32;
+      chunk = ((chunk + align - 1) / align) * align;
       L.kchunk = chunk;
       L.ksplit = (k_total + chunk - 1) / chunk;
+      if (xcd_rule && L.ksplit >= 12 && L.ksplit % 8 != 0) {      // rounding the chunk up dropped a chunk or two: stretch the chunks to the multiple of 8 below
+        const int k8 = (L.ksplit / 8) * 8;
+        chunk = (((k_total + k8 - 1) / k8 + align - 1) / align) * align;
+        if ((k_total + chunk - 1) / chunk % 8 == 0) { L.kchunk = chunk; L.ksplit = (k_total + chunk - 1) / chunk; }
+      }
       // partial tiles -> workspace when it is big enough and every output is float4-shaped
       size_t need = 0;
       bool ws_ok = g_ws != nullptr && L.ksplit > 1;

@@ -701,8 +701,11 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   const int hv = h / V;
   // slab: <= 32 float4 (or 128 scalars) per row, as even as possible
   // (sized so that a workgroup's slab stays under ~32 KB of LDS: four to five workgroups per CU, also at R = 200)
-  static int cap_kb = -1;
-  if (cap_kb < 0) cap_kb = measure_env("GH_SPMM_SLAB_KB", 32);   // measured per step: 48 KB -> 0.314 ms, 32 -> 0.288, 24 -> 0.294, 16 -> 0.344 (R = 100); R = 200: 0.60 -> 0.43
+  static int cap_env = -2;
+  if (cap_env == -2) cap_env = measure_env("GH_SPMM_SLAB_KB", -1);
+  // round 4, A/B on one box: many graphs of <= 128 nodes (the bench step's 960 x 100) run 0.4 % faster per STEP on 24 KB slabs (five
+  // slabs of 15 float4 instead of four of 19), few graphs (218: the realistic step) 1 % slower
+  const int cap_kb = cap_env > 0 ? cap_env : ((n >= 512 && r <= 128 && !bf16) ? 24 : 32);   // measured per step: 48 KB -> 0.314 ms, 32 -> 0.288, 24 -> 0.294, 16 -> 0.344 (R = 100); R = 200: 0.60 -> 0.43
   const int lds_cap = (cap_kb * 1024) / (r * (v4 ? 16 : 4));
   const int slab_max = v4 ? (lds_cap < 32 ? (lds_cap < 4 ? 4 : lds_cap) : 32) : (lds_cap < 128 ? (lds_cap < 16 ? 16 : lds_cap) : 128);
   const int nslab = (hv + slab_max - 1) / slab_max;
