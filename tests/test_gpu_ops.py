@@ -336,7 +336,11 @@ def test_self_att_extend_vs_golden(ci):
 
 
 # ---------------------------------------------------------------- linear / ragged helpers / Adam
-@pytest.mark.parametrize("m,k,n", [(32, 3556, 300), (32, 300, 2), (960, 300, 300), (7, 20, 5), (2048, 64, 48)])
+# (32, 3556, 300): the head -- 55 K chunks, workgroup-per-row finish; (32, 4096, 768): the same finish over three 64-float4 column
+# passes; (40, 300, 3556): 12 column-block problems in one grouped launch (the head's backward); (3, 2000, 300): one row tile,
+# linear work decode, rows that are not a multiple of the finish kernel's four
+@pytest.mark.parametrize("m,k,n", [(32, 3556, 300), (32, 300, 2), (960, 300, 300), (7, 20, 5), (2048, 64, 48),
+                                   (32, 4096, 768), (40, 300, 3556), (3, 2000, 300)])
 def test_linear_fwd_bwd(m, k, n):
     from get_amd import ops
     rng = np.random.default_rng(m + k + n)
