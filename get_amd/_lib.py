@@ -19,12 +19,13 @@ _I = ctypes.c_int
 _F = ctypes.c_float
 _L = ctypes.c_int64
 _U = ctypes.c_uint32
-ABI_VERSION = 7          # GH_ABI_VERSION of include/get_hip.h
+ABI_VERSION = 8          # GH_ABI_VERSION of include/get_hip.h
 
 # name -> argtypes (mirrors include/get_hip.h; tests/test_abi.py checks the two agree)
 SIGNATURES = {
     "gh_graph_build": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "gh_adj_pack_f64": [_P, _I, _I, _P, _P, _P],
+    "gh_ref_depad": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "gh_adj_pack_f32": [_P, _I, _I, _P, _P, _P],
     "gh_ragged_plan": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "gh_spmm": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],

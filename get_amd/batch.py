@@ -151,13 +151,46 @@ class NativeBatch:
 
 
 def kargs_from_reference_tensors(query_lens, evd_doc_contents, evd_docs_adj, query_adj, evd_counts, doc_sources,
-                                 query_sources=None, n_max: int = 30):
+                                 query_sources=None, n_max: int = 30, fused: bool = True):
     """Compatibility shim: the tensors the reference fitter holds before its de-padding loop
     (char_man_fitter_query_repr1.py:196-223) -> forward kargs, with the per-claim ``[:evd_cnt]`` slicing
     done by ONE boolean-mask gather on the device instead of a Python loop with 2 syncs per claim.
 
-    evd_doc_contents (B,n,R) ids, evd_docs_adj (B,n,R,R) dense, query_adj (B,L,L), evd_counts (B,)."""
+    evd_doc_contents (B,n,R) ids, evd_docs_adj (B,n,R,R) dense, query_adj (B,L,L), evd_counts (B,).
+
+    Device tensors with a float64 adjacency (what handlers/mz_sampler.py:146-160 ships) take ONE library launch
+    (``gh_ref_depad``: ids narrowed, adjacency packed, node counts, layout check) and ONE 24-byte read-back; the evidence
+    adjacency then comes back already packed (``ops.PackedAdj``, with the node-compact plan attached when the graphs allow
+    it), which every ``forward`` of this package accepts in place of the dense tensor.  ``fused=False`` keeps the plain
+    tensor form (boolean-mask gathers: two syncs, three passes over the 77 MB adjacency, then packing inside the forward)."""
     b, n, r = evd_doc_contents.shape
+    if (fused and evd_docs_adj.is_cuda and evd_docs_adj.dtype == torch.float64 and evd_docs_adj.is_contiguous() and r <= 256
+            and evd_doc_contents.is_cuda and evd_doc_contents.dtype in (torch.int32, torch.int64) and b > 0):
+        from ._lib import call, ptr, stream
+        dev = evd_docs_adj.device
+        ids = evd_doc_contents.contiguous()
+        counts = evd_counts.to(device=dev, dtype=torch.int64).contiguous()
+        w = (r + 63) // 64
+        d_ids = torch.empty((b * n, r), device=dev, dtype=torch.int32)
+        bits = torch.empty((b * n, r, w), device=dev, dtype=torch.int64)
+        vals = torch.empty((b * n, r, r), device=dev, dtype=torch.float32)
+        n_nodes = torch.empty((b * n,), device=dev, dtype=torch.int32)
+        stats = torch.empty((3,), device=dev, dtype=torch.int64)
+        call("gh_ref_depad", ptr(counts), b, n, r, ptr(ids), 1 if ids.dtype == torch.int64 else 0, ptr(evd_docs_adj), ptr(d_ids),
+             ptr(bits), ptr(vals), ptr(n_nodes), ptr(stats), stream())
+        b1, m_real, bad = stats.tolist()                  # the one host sync of this path
+        e_conts = d_ids[:b1]
+        adj = ops.PackedAdj(bits[:b1], None, vals[:b1], None, int(b1), r)
+        if b1 > 0 and not bad and 0 < m_real < b1 * r and os.environ.get("GET_AMD_AUTO_COMPACT", "1") != "0":
+            adj = adj.with_plan(ops.RaggedPlan(n_nodes[:b1], e_conts, int(m_real)))
+        kargs = {
+            K.Query_lens: query_lens, K.Doc_lens: None, K.DocLensIndices: None,
+            K.DocContentNoPaddingEvidence: e_conts, K.EvidenceCountPerQuery: evd_counts,
+            K.FIXED_NUM_EVIDENCES: n_max, K.Query_Adj: query_adj, K.Evd_Docs_Adj: adj, K.DocSources: doc_sources,
+        }
+        if query_sources is not None:
+            kargs[K.QuerySources] = query_sources
+        return kargs
     valid = torch.arange(n, device=evd_counts.device)[None, :] < evd_counts[:, None]          # (B,n)
     e_conts = evd_doc_contents[valid]                                                         # (B1,R) claim-major
     e_adj = evd_docs_adj[valid]                                                               # (B1,R,R)

@@ -107,6 +107,78 @@ adj_pack_kernel(const T* __restrict__ adj, int R, uint64_t* __restrict__ bits, f
   }
 }
 
+// The reference fitter's de-padding (char_man_fitter_query_repr1.py:204-250: a Python loop over the claims slicing
+// `[:evd_count]` out of the padded (B, n_max, R) ids and (B, n_max, R, R) float64 adjacency, two host syncs per claim) plus the
+// packing of the adjacency and the node counts the node-compact plan needs, in ONE pass over the handed-over tensors:
+// workgroup (claim c, slot j) with j < counts[c] is pair p = sum(counts[:c]) + j; it narrows the ids, counts the real nodes
+// (id >= 1), packs its R x R block (as adj_pack_kernel) and checks what the node-compact layout assumes (ids prefix-shaped,
+// no edge on a padding node).  stats = {pairs, real nodes, pairs that violate the assumption}: one read-back sizes everything.
+template <typename TI>
+__global__ void __launch_bounds__(256)
+ref_depad_kernel(const int64_t* __restrict__ counts, int B, int n_max, int R, const TI* __restrict__ ids, const double* __restrict__ adj,
+                 int32_t* __restrict__ d_ids, uint64_t* __restrict__ bits, float* __restrict__ vals, int32_t* __restrict__ n_nodes,
+                 unsigned long long* __restrict__ stats) {
+  const int c = blockIdx.x / n_max, j = blockIdx.x % n_max;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int red[4];
+  __shared__ int s_real[256];
+  __shared__ int s_bad;
+  const long long cnt_c = counts[c];
+  const int cc = cnt_c < 0 ? 0 : (cnt_c > n_max ? n_max : (int)cnt_c);
+  if (j >= cc) return;
+  // pair index: clamped counts of the claims before c (B is a few hundred at most)
+  int part = 0;
+  for (int i = tid; i < c; i += 256) { const long long v = counts[i]; part += v < 0 ? 0 : (v > n_max ? n_max : (int)v); }
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+  if (lane == 0) red[wave] = part;
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  const int p = red[0] + red[1] + red[2] + red[3] + j;
+  const size_t slot = (size_t)c * n_max + j;
+  // ids -> int32, real-node flags, node count
+  int real = 0;
+  if (tid < R) {
+    const long long id = (long long)ids[slot * R + tid];
+    d_ids[(size_t)p * R + tid] = (int32_t)id;
+    real = id >= 1 ? 1 : 0;
+  }
+  s_real[tid] = real;
+  int nn = real;
+  for (int o = 32; o > 0; o >>= 1) nn += __shfl_xor(nn, o);
+  __syncthreads();                      // (red is re-used: every thread has read it)
+  if (lane == 0) red[wave] = nn;
+  __syncthreads();
+  nn = red[0] + red[1] + red[2] + red[3];
+  int bad = (tid < R && real != (tid < nn ? 1 : 0)) ? 1 : 0;
+  // adjacency block: row i per wave iteration, 64 columns per pass
+  const int W = (R + 63) / 64;
+  const double* ab = adj + slot * (size_t)R * R;
+  for (int i = wave; i < R; i += 4) {
+    bool any = false;
+    for (int w = 0; w < W; ++w) {
+      const int jj = w * 64 + lane;
+      float v = 0.f, vt = 0.f;
+      if (jj < R) {
+        v = (float)ab[(size_t)i * R + jj];
+        vals[((size_t)p * R + i) * R + jj] = v;
+        vt = (float)ab[(size_t)jj * R + i];
+      }
+      const unsigned long long m = __ballot(v != 0.f || vt != 0.f);
+      if (lane == 0) bits[((size_t)p * R + i) * W + w] = m;
+      any = any || m != 0ull;
+    }
+    if (any && !s_real[i]) bad = 1;     // a padding node with edges: the node-compact layout would drop them
+  }
+  if (bad) s_bad = 1;
+  __syncthreads();
+  if (tid == 0) {
+    n_nodes[p] = nn;
+    atomicAdd(&stats[0], 1ull);
+    atomicAdd(&stats[1], (unsigned long long)nn);
+    if (s_bad) atomicAdd(&stats[2], 1ull);
+  }
+}
+
 __global__ void __launch_bounds__(256)
 adj_unpack_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
                   const uint64_t* __restrict__ keep, int R, float* __restrict__ adj) {
@@ -973,6 +1045,22 @@ extern "C" int gh_adj_pack_f32(const float* adj, int n, int r, uint64_t* bits, f
   GH_REQUIRE(r > 0 && r <= MAX_R, "adj_pack: r=%d not in [1,%d]", r, MAX_R);
   if (n <= 0) return 0;
   hipLaunchKernelGGL(adj_pack_kernel<float>, dim3(n), dim3(256), 0, (hipStream_t)stream, adj, r, bits, vals);
+  GH_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int gh_ref_depad(const int64_t* counts, int b, int n_max, int r, const void* ids, int ids_i64, const double* adj,
+                            int32_t* d_ids, uint64_t* bits, float* vals, int32_t* n_nodes, int64_t* stats, gh_stream_t stream) {
+  GH_REQUIRE(r > 0 && r <= MAX_R, "ref_depad: r=%d not in [1,%d]", r, MAX_R);
+  GH_REQUIRE(b >= 0 && n_max > 0 && counts && ids && adj && d_ids && bits && vals && n_nodes && stats, "ref_depad: bad arguments");
+  GH_CHECK_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(int64_t), (hipStream_t)stream));
+  if (b == 0) return 0;
+  if (ids_i64)
+    hipLaunchKernelGGL(ref_depad_kernel<int64_t>, dim3(b * n_max), dim3(256), 0, (hipStream_t)stream, counts, b, n_max, r,
+                       (const int64_t*)ids, adj, d_ids, bits, vals, n_nodes, (unsigned long long*)stats);
+  else
+    hipLaunchKernelGGL(ref_depad_kernel<int32_t>, dim3(b * n_max), dim3(256), 0, (hipStream_t)stream, counts, b, n_max, r,
+                       (const int32_t*)ids, adj, d_ids, bits, vals, n_nodes, (unsigned long long*)stats);
   GH_LAUNCH_CHECK();
   return 0;
 }

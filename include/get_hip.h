@@ -56,7 +56,7 @@ extern "C" {
 
 typedef void* gh_stream_t;
 
-#define GH_ABI_VERSION 7
+#define GH_ABI_VERSION 8
 
 int gh_abi_version(void);
 /* Thread-local message of the last failing call on this thread (never NULL). */
@@ -75,6 +75,17 @@ int gh_graph_build(const int32_t* tokens, const int32_t* lengths, int n_texts, i
  * transposed aggregation of the backward pass sees every entry of an adjacency whose pattern is not symmetric. */
 int gh_adj_pack_f64(const double* adj, int n, int r, uint64_t* bits, float* vals, gh_stream_t stream);
 int gh_adj_pack_f32(const float* adj, int n, int r, uint64_t* bits, float* vals, gh_stream_t stream);
+
+/* De-padding of what the reference fitter holds before its per-claim loop
+ * (Fitting/FittingFC/char_man_fitter_query_repr1.py:196-250: `evd_doc_contents` (b, n_max, r) ids and `evd_docs_adj`
+ * (b, n_max, r, r) float64, `[:evd_count]` sliced claim by claim with two host syncs each) in one launch:
+ * pair p = sum(counts[:c]) + j for every slot j < counts[c] (counts clamped to [0, n_max]) gets its ids narrowed to int32
+ * (d_ids [b*n_max][r], rows [0, pairs) written), its adjacency packed as gh_adj_pack_f64 does (bits [b*n_max][r][W],
+ * vals [b*n_max][r][r]) and its number of real nodes (id >= 1) in n_nodes [b*n_max].
+ * stats[3] (device, int64): {pairs, real nodes over all pairs, pairs whose ids are not prefix-shaped or whose padding
+ * nodes carry edges} -- the last must be 0 for the node-compact layout (gh_ragged_plan) to apply. */
+int gh_ref_depad(const int64_t* counts, int b, int n_max, int r, const void* ids, int ids_i64, const double* adj,
+                 int32_t* d_ids, uint64_t* bits, float* vals, int32_t* n_nodes, int64_t* stats, gh_stream_t stream);
 
 /* Node-compact layout plan from the node counts of gh_graph_build (device arrays):
  *   goff[n+1] (see above); rowg[n*r] graph of every compact row; src[n*r] padded row index g*r+j of every compact

@@ -505,9 +505,32 @@ def test_batch_shim_matches_fitter_depadding():
         last += c
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
     kargs = kargs_from_reference_tensors(T(inp["query_lens"]), T(inp["document"]), T(adj_padded), T(inp["query_adj"]),
-                                         T(inp["evd_counts"]), T(inp["doc_sources"]), T(inp["query_sources"]))
+                                         T(inp["evd_counts"]), T(inp["doc_sources"]), T(inp["query_sources"]), fused=False)
     assert np.array_equal(kargs["doc_content_without_padding_evidences"].cpu().numpy(), inp["doc_ids"])
     assert np.array_equal(kargs["docs_adj"].cpu().numpy(), inp["doc_adj"])
+    # the one-launch form (gh_ref_depad): same ids, the same adjacency in packed form, the node-compact plan attached
+    from get_amd.ops import PackedAdj
+    kf = kargs_from_reference_tensors(T(inp["query_lens"]), T(inp["document"]), T(adj_padded), T(inp["query_adj"]),
+                                      T(inp["evd_counts"]), T(inp["doc_sources"]), T(inp["query_sources"]))
+    assert isinstance(kf["docs_adj"], PackedAdj) and kf["docs_adj"].plan is not None
+    assert np.array_equal(kf["doc_content_without_padding_evidences"].cpu().numpy(), inp["doc_ids"])
+    assert np.array_equal(kf["docs_adj"].to_dense().cpu().numpy(), inp["doc_adj"].astype(np.float32))
+    n_nodes = (inp["doc_ids"] >= 1).sum(1)
+    assert kf["docs_adj"].plan.m_real == int(n_nodes.sum())
+    assert np.array_equal(kf["docs_adj"].plan.goff.cpu().numpy(), np.concatenate([[0], np.cumsum(n_nodes)]))
+    # int32 ids; a claim without evidences; an edge on a padding node (-> packed, but no node-compact plan)
+    doc0, adj0, cnt0 = inp["document"].copy(), adj_padded.copy(), np.asarray(inp["evd_counts"]).copy()
+    cnt0[1] = 0
+    k0 = kargs_from_reference_tensors(T(inp["query_lens"]), T(doc0.astype(np.int32)), T(adj0), T(inp["query_adj"]), T(cnt0),
+                                      T(inp["doc_sources"]), T(inp["query_sources"]))
+    valid = np.arange(n)[None, :] < cnt0[:, None]
+    assert np.array_equal(k0["doc_content_without_padding_evidences"].cpu().numpy(), doc0[valid])
+    assert np.array_equal(k0["docs_adj"].to_dense().cpu().numpy(), adj0[valid].astype(np.float32))
+    adj0[0, 0, R - 1, 0] = 0.5      # (position R - 1 of this evidence is a padding node)
+    assert doc0[0, 0, R - 1] == 0
+    k1 = kargs_from_reference_tensors(T(inp["query_lens"]), T(doc0), T(adj0), T(inp["query_adj"]), T(cnt0),
+                                      T(inp["doc_sources"]), T(inp["query_sources"]))
+    assert k1["docs_adj"].plan is None and float(k1["docs_adj"].to_dense()[0, R - 1, 0]) == 0.5
     nb = NativeBatch(raw["claim_tokens"], raw["claim_len"], raw["evd_tokens"], raw["evd_len"], raw["evd_counts"],
                      raw["doc_sources"], raw["query_sources"], raw["labels"], window=cfg.window, device=DEV)
     q_ids, document, k2 = nb.inputs()
@@ -517,6 +540,8 @@ def test_batch_shim_matches_fitter_depadding():
     z, _ = load("g7_model_small.npz")
     phi_a = model(T(inp["query"]), T(inp["document"]), **kargs)
     phi_b = model(q_ids, document, **k2)
+    phi_f = model(T(inp["query"]), T(inp["document"]), **kf)
+    assert np.abs(phi_f.detach().cpu().numpy() - z["phi"]).max() <= 1e-4
     assert np.abs(phi_a.detach().cpu().numpy() - z["phi"]).max() <= 1e-4
     assert np.abs(phi_b.detach().cpu().numpy() - z["phi"]).max() <= 1e-4
 
