@@ -65,11 +65,15 @@ bool prof_enabled();
 void prof_begin(hipStream_t s, int tag);   // events are recorded only for tags selected by gh_profile_select
 void prof_end(int tag, double work, hipStream_t s);
 
+struct ZeroFill { float* p0; long long n0; float* p1; long long n1; };      // n in floats, multiples of 4, 16-byte aligned pointers
 // internal launchers implemented in graph_ops.hip / misc_ops.hip, used by the fused entry points
 // goff != NULL: node-compact layout (include/get_hip.h) -- graph g owns rows [goff[g], goff[g+1]); m_real = goff[n]
 int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const int32_t* goff,
                 int m_real, const float* x, float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s,
-                int bf16 = 0);      // bf16: x and y hold bf16
+                int bf16 = 0,       // bf16: x and y hold bf16
+                const ZeroFill* zf = nullptr, bool* zf_done = nullptr);
+// zf: up to two float ranges the launch zero-fills on its way (the cell forward's padding rows of `a` and the scorer's partial
+// dot products: two memset dispatches per step otherwise); *zf_done says whether the kernel variant that ran supports it
 int launch_gate_bwd_pre(const float* g, const float* z, const float* hh, const float* xp, float* dhp, float* dzp,
                         float* dxp, size_t count, hipStream_t s, int bf16 = 0);   // bf16: everything but g holds bf16
 int launch_colsum3(const float* a, const float* b, const float* c, float* oa, float* ob, float* oc, int m, int h,

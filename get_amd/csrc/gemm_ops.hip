@@ -790,9 +790,16 @@ int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* d
     GH_REQUIRE(b.err != hipErrorInvalidValue || drop_p == 0.f, "ggnn_cell_fwd: fused dropout needs float4-shaped rows (din=%d, h=%d)", din, h);
     GH_CHECK_HIP(b.err);
   }
-  if (int e = launch_spmm(bits, dinv, vals, keep, goff, m_real, xp, a, n, r, h, 0, 0, s, bf)) return e;   // a = A_hat xp (:192)
   bool partial_zero = false;
-  const long long generic_before = g_path_counts[1];
+  // zero fills of this cell -- the padding rows of `a` that a row tile can touch (below) and the scorer's partial dot products
+  // (two column blocks add into score_x) -- ride on the aggregation launch when its kernel variant takes them: two memset
+  // dispatches less per step
+  ZeroFill zf = {nullptr, 0, nullptr, 0};
+  bool zf_done = false, score_zero = false;
+  if (score_w) {
+    Batch bh(false, M, s, false, 2, h);
+    score_zero = bh.narrow && h <= 2 * bh.bn && h > bh.bn;
+  }
   if (m_rows > m_real) {
     // padding rows of the node-compact layout have no neighbours.  The fast gate GEMMs skip the aggregation segment for
     // every row tile at or beyond seg0_rows (= m_real), so only the tile that straddles m_real ever reads such rows: zero
@@ -807,8 +814,15 @@ int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* d
     partial_zero = ((al & 15) == 0) && (h % (bf ? 8 : 4) == 0) && h >= 4 && 4.0 * (double)h * (double)M < 2147483648.0;
     const int zfull = ((m_real + 127) / 128 + 1) * 128;
     const int zend = (partial_zero && zfull < m_rows) ? zfull : m_rows;
-    GH_CHECK_HIP(hipMemsetAsync((char*)a + (size_t)m_real * h * (bf ? 2 : 4), 0, (size_t)(bf ? 2 : 4) * (size_t)(zend - m_real) * h, s));
+    if (!bf) { zf.p0 = a + (size_t)m_real * h; zf.n0 = (long long)(zend - m_real) * h; }
+    if (!bf && score_zero && M % 4 == 0) { zf.p1 = score_x; zf.n1 = M; }
+    if (int e = launch_spmm(bits, dinv, vals, keep, goff, m_real, xp, a, n, r, h, 0, 0, s, bf, bf ? nullptr : &zf, &zf_done)) return e;   // a = A_hat xp (:192)
+    if (!zf_done)
+      GH_CHECK_HIP(hipMemsetAsync((char*)a + (size_t)m_real * h * (bf ? 2 : 4), 0, (size_t)(bf ? 2 : 4) * (size_t)(zend - m_real) * h, s));
+  } else {
+    if (int e = launch_spmm(bits, dinv, vals, keep, goff, m_real, xp, a, n, r, h, 0, 0, s, bf)) return e;   // a = A_hat xp (:192)
   }
+  const long long generic_before = g_path_counts[1];
   {  // z, r gates (:194-200): [a | xp] . [W?0 | W?1]^T as two K segments
     Batch b(false, M, s, wide, 1, h);
     Problem pz = gemm_problem(M, h, EPI_SIGMOID_Z, z, h, a, h, w_z0, h, h, nullptr, bf);
@@ -828,7 +842,7 @@ int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* d
     Batch b(false, M, s, wide && !score_w, 2, h);
     if (score_w && b.narrow) {
       if (h > 2 * b.bn) { b.narrow = false; b.bn = 320; }      // more than two column blocks: whole rows on the 320-wide tile
-      else if (h > b.bn) GH_CHECK_HIP(hipMemsetAsync(score_x, 0, sizeof(float) * (size_t)M, s));   // two blocks add their partial dot products
+      else if (h > b.bn && !(zf_done && zf.p1 == score_x)) GH_CHECK_HIP(hipMemsetAsync(score_x, 0, sizeof(float) * (size_t)M, s));   // two blocks add their partial dot products
     }
     Problem ph = gemm_problem(M, h, EPI_TANH_H, hh, h, a, h, w_h0, h, h, nullptr, bf);
     ph.io = bf ? 15 : 0; ph.c32 = bf ? out32 : nullptr;

@@ -462,8 +462,15 @@ template <bool BF, int CPT>
 __global__ void __launch_bounds__(256)
 spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
                  const uint64_t* __restrict__ keep, const int32_t* __restrict__ goff, const float* __restrict__ x,
-                 float* __restrict__ y, int R, int H, int slab, int cap, int transpose, int accumulate, int n, int nslab, int split, int seq) {
+                 float* __restrict__ y, int R, int H, int slab, int cap, int transpose, int accumulate, int n, int nslab, int split, int seq,
+                 const ZeroFill zf) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  // zero-fill ranges handed over by the caller (a few hundred KB: the first workgroups' threads cover them)
+  if (zf.n0 > 0 || zf.n1 > 0) {
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4, st = (long long)gridDim.x * 256 * 4;
+    for (long long i = i0; i < zf.n0; i += st) *reinterpret_cast<float4*>(zf.p0 + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long i = i0; i < zf.n1; i += st) *reinterpret_cast<float4*>(zf.p1 + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   const int W = (R + 63) / 64;
   float4* xs = reinterpret_cast<float4*>(dsm);                                                // [R][slab] fp32 rows ...
   const uint2* xs16 = reinterpret_cast<const uint2*>(dsm);                                    // ... or (BF) bf16 rows, 8 B per float4 column
@@ -763,7 +770,9 @@ extern "C" int gh_debug_spmm_phases(unsigned* out, int reset) {     // out: [819
 #endif
 
 int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const int32_t* goff,
-                int m_real, const float* x, float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s, int bf16) {
+                int m_real, const float* x, float* y, int n, int r, int h, int transpose, int accumulate, hipStream_t s, int bf16,
+                const ZeroFill* zfp, bool* zf_done) {
+  if (zf_done) *zf_done = false;
   GH_REQUIRE(r <= MAX_R, "spmm: padded graph size %d > %d", r, MAX_R);
   GH_REQUIRE(vals || dinv, "spmm: need dinv or vals");
   const int W = words_for(r);
@@ -830,8 +839,14 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
     int seq = spw_env > 0 ? spw_env : (n < 256 ? 1 : (bf16 ? 2 : ns_arg));
     if (seq > ns_arg) seq = ns_arg;
     lgrid = dim3(((n + 7) / 8) * 8 * ((ns_arg + seq - 1) / seq), 1);
+    ZeroFill zf = {nullptr, 0, nullptr, 0};
+    if (zfp && (zfp->n0 % 4 == 0) && (zfp->n1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(zfp->p0) | reinterpret_cast<uintptr_t>(zfp->p1)) & 15) == 0) {
+      zf = *zfp;
+      if (zf_done) *zf_done = true;
+    }
     void* args[] = {(void*)&bits, (void*)&dinv, (void*)&vals, (void*)&keep, (void*)&goff, (void*)&x, (void*)&y, (void*)&r, (void*)&h,
-                    (void*)&lslab, (void*)&cap, (void*)&transpose, (void*)&accumulate, (void*)&n, (void*)&ns_arg, (void*)&split, (void*)&seq};
+                    (void*)&lslab, (void*)&cap, (void*)&transpose, (void*)&accumulate, (void*)&n, (void*)&ns_arg, (void*)&split, (void*)&seq,
+                    (void*)&zf};
     (void)hipLaunchKernel(fn, lgrid, dim3(256), args, llds, s);
   } else if (bf16) {
     static bool attrb = false;

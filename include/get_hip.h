@@ -364,7 +364,7 @@ typedef struct gh_get_batch {
   const uint64_t* d_bits; const float* d_dinv; const float* d_vals;      /* evidence graphs */
   const int32_t *goff, *rowg, *cids; const float* maskf;                 /* gh_ragged_plan outputs, or all NULL (padded layout) */
   const int64_t* counts;                            /* [b] evidences per claim (sum = b1) */
-  int counts_fit;                                   /* 1: the caller guarantees counts[i] <= n_max (saves a memset in the backward) */
+  int counts_fit;                                   /* (ignored since ABI 8: the backward always zero-fills d_avg) */
   const void* doc_sources; int doc_sources_i64;     /* [b][n_max], -1 = padding slot (article source ids) */
   const void* query_sources; int query_sources_i64; /* [b] claim source ids (claim_src_dim > 0) */
   const void* document; int document_i64;           /* [b][n_max][r] padded evidence node ids (slot mask only) */
