@@ -65,6 +65,11 @@ bool prof_enabled();
 void prof_begin(hipStream_t s, int tag);   // events are recorded only for tags selected by gh_profile_select
 void prof_end(int tag, double work, hipStream_t s);
 
+int launch_ragged_plan(const int32_t* n_nodes, const int32_t* node_ids, int n, int r, int32_t* goff, int32_t* rowg, int32_t* src,
+                       int32_t* cids, float* maskf, const int64_t* slot, int32_t* document, hipStream_t s, bool* scattered);   // *scattered: the document scatter rode along
+int launch_graph_build2(const int32_t* ta, const int32_t* la, int na, int ra, int32_t* ida, int32_t* nna, uint64_t* ba, float* da,
+                        const int32_t* tb, const int32_t* lb, int nb, int rb, int32_t* idb, int32_t* nnb, uint64_t* bb, float* db,
+                        int window, hipStream_t s);
 struct ZeroFill { float* p0; long long n0; float* p1; long long n1; };      // n in floats, multiples of 4, 16-byte aligned pointers
 // internal launchers implemented in graph_ops.hip / misc_ops.hip, used by the fused entry points
 // goff != NULL: node-compact layout (include/get_hip.h) -- graph g owns rows [goff[g], goff[g+1]); m_real = goff[n]

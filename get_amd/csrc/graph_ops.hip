@@ -14,16 +14,15 @@ constexpr int MAX_W = MAX_R / 64;
 // ------------------------------------------------------------------------------------------------
 // a1  graph build (interactions.py:334-351).  One workgroup per text.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-graph_build_kernel(const int32_t* __restrict__ tokens, const int32_t* __restrict__ lengths, int R, int window,
-                   int32_t* __restrict__ node_ids, int32_t* __restrict__ n_nodes, uint64_t* __restrict__ bits,
-                   float* __restrict__ dinv) {
+__device__ __forceinline__ void graph_build_body(const int g, const int32_t* __restrict__ tokens, const int32_t* __restrict__ lengths, int R,
+                                                 int window, int32_t* __restrict__ node_ids, int32_t* __restrict__ n_nodes,
+                                                 uint64_t* __restrict__ bits, float* __restrict__ dinv) {
   __shared__ int tok[MAX_R];
   __shared__ int first[MAX_R];       // position of the first occurrence of tok[i]
   __shared__ int node_of[MAX_R];     // node index of position i
   __shared__ unsigned long long rows[MAX_R * MAX_W];
   __shared__ int total;
-  const int g = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int W = (R + 63) / 64;
   int len = lengths[g];
   len = len < 0 ? 0 : (len > R ? R : len);
@@ -78,6 +77,20 @@ graph_build_kernel(const int32_t* __restrict__ tokens, const int32_t* __restrict
     dinv[(size_t)g * R + i] = deg > 0 ? (float)(1.0 / sqrt((double)deg)) : 0.f;
   }
   if (tid == 0) n_nodes[g] = total;
+}
+__global__ void __launch_bounds__(256)
+graph_build_kernel(const int32_t* __restrict__ tokens, const int32_t* __restrict__ lengths, int R, int window,
+                   int32_t* __restrict__ node_ids, int32_t* __restrict__ n_nodes, uint64_t* __restrict__ bits,
+                   float* __restrict__ dinv) {
+  graph_build_body(blockIdx.x, tokens, lengths, R, window, node_ids, n_nodes, bits, dinv);
+}
+// both sides of a batch in one launch (gh_get_prepare): workgroups [0, na) build the claims, the rest the evidences
+struct GraphSide { const int32_t* tokens; const int32_t* lengths; int R; int32_t* node_ids; int32_t* n_nodes; uint64_t* bits; float* dinv; };
+__global__ void __launch_bounds__(256)
+graph_build2_kernel(const GraphSide a, const GraphSide b, int na, int window) {
+  const bool first = (int)blockIdx.x < na;      // workgroup-uniform
+  const GraphSide& s = first ? a : b;
+  graph_build_body(first ? blockIdx.x : blockIdx.x - na, s.tokens, s.lengths, s.R, window, s.node_ids, s.n_nodes, s.bits, s.dinv);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -917,6 +930,41 @@ ragged_fill_kernel(const int32_t* __restrict__ goff, const int32_t* __restrict__
   }
 }
 
+// The plan in ONE launch for n <= 4096 graphs: every workgroup sums the node counts in front of its graph itself (n loads of
+// 4 bytes out of L2, 960 at the bench shape) instead of waiting for a one-workgroup scan kernel; optionally it also scatters
+// its graph's node ids into the padded `document` tensor (gh_get_prepare).
+__global__ void __launch_bounds__(256)
+ragged_plan1_kernel(const int32_t* __restrict__ n_nodes, const int32_t* __restrict__ node_ids, int n, int R,
+                    int32_t* __restrict__ goff, int32_t* __restrict__ rowg, int32_t* __restrict__ src, int32_t* __restrict__ cids,
+                    float* __restrict__ maskf, const int64_t* __restrict__ slot, int32_t* __restrict__ document) {
+  __shared__ int red[2][4];
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int before = 0, all = 0;
+  for (int i = tid; i < n; i += 256) {
+    const int v = min(max(n_nodes[i], 0), R);
+    all += v;
+    if (i < g) before += v;
+  }
+  for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); all += __shfl_xor(all, o); }
+  if (lane == 0) { red[0][wave] = before; red[1][wave] = all; }
+  __syncthreads();
+  const int row0 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  const int total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const int NR = min(max(n_nodes[g], 0), R);
+  if (tid == 0) { goff[g] = row0; if (g == n - 1) goff[n] = total; }
+  const int pad0 = total + g * R - row0 - NR;
+  const size_t dst = (slot && document) ? (size_t)slot[g] * R : 0;
+  for (int j = tid; j < R; j += 256) {
+    const int row = j < NR ? row0 + j : pad0 + j;
+    rowg[row] = g;
+    src[row] = g * R + j;
+    const int id = (cids || maskf || document) ? node_ids[(size_t)g * R + j] : 0;
+    if (cids) cids[row] = id;
+    if (maskf) maskf[row] = id >= 1 ? 1.f : 0.f;
+    if (slot && document) document[dst + j] = id;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // top-k keep set from R scores held in LDS: rank by counting, ballot packs the 64-node words.
 // ------------------------------------------------------------------------------------------------
@@ -1043,8 +1091,35 @@ extern "C" int gh_ragged_plan(const int32_t* n_nodes, const int32_t* node_ids, i
   GH_REQUIRE(r > 0 && r <= MAX_R, "ragged_plan: r=%d not in [1,%d]", r, MAX_R);
   GH_REQUIRE((cids == nullptr && maskf == nullptr) || (node_ids != nullptr), "ragged_plan: cids / maskf need node_ids");
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(ragged_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_nodes, n, r, goff);
-  hipLaunchKernelGGL(ragged_fill_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, goff, node_ids, n, r, rowg, src, cids, maskf);
+  return launch_ragged_plan(n_nodes, node_ids, n, r, goff, rowg, src, cids, maskf, nullptr, nullptr, (hipStream_t)stream, nullptr);
+}
+
+// slot / document: also scatter the node ids of graph g into document[slot[g]][:] (the composite batch preparation)
+int gh::launch_ragged_plan(const int32_t* n_nodes, const int32_t* node_ids, int n, int r, int32_t* goff, int32_t* rowg, int32_t* src,
+                           int32_t* cids, float* maskf, const int64_t* slot, int32_t* document, hipStream_t s, bool* scattered) {
+  if (scattered) *scattered = false;
+  if (n <= 4096 && (node_ids || !(slot && document))) {
+    hipLaunchKernelGGL(ragged_plan1_kernel, dim3(n), dim3(256), 0, s, n_nodes, node_ids, n, r, goff, rowg, src, cids, maskf, slot, document);
+    GH_LAUNCH_CHECK();
+    if (scattered) *scattered = slot && document;
+    return 0;
+  }
+  hipLaunchKernelGGL(ragged_scan_kernel, dim3(1), dim3(1024), 0, s, n_nodes, n, r, goff);
+  hipLaunchKernelGGL(ragged_fill_kernel, dim3(n), dim3(256), 0, s, goff, node_ids, n, r, rowg, src, cids, maskf);
+  GH_LAUNCH_CHECK();
+  return 0;      // (*scattered stays false: the document scatter, if any, is still the caller's)
+}
+
+int gh::launch_graph_build2(const int32_t* ta, const int32_t* la, int na, int ra, int32_t* ida, int32_t* nna, uint64_t* ba, float* da,
+                            const int32_t* tb, const int32_t* lb, int nb, int rb, int32_t* idb, int32_t* nnb, uint64_t* bb, float* db,
+                            int window, hipStream_t s) {
+  GH_REQUIRE(ra > 0 && ra <= MAX_R && rb > 0 && rb <= MAX_R, "graph_build: fixed lengths %d / %d not in [1,%d]", ra, rb, MAX_R);
+  GH_REQUIRE(window >= 1, "graph_build: window %d < 1", window);
+  if (na + nb <= 0) return 0;
+  const GraphSide A = {ta, la, ra, ida, nna, ba, da}, B = {tb, lb, rb, idb, nnb, bb, db};
+  prof_begin(s, PROF_GRAPH_BUILD);
+  hipLaunchKernelGGL(graph_build2_kernel, dim3(na + nb), dim3(256), 0, s, A, B, na, window);
+  prof_end(PROF_GRAPH_BUILD, (double)na * (12.0 * ra + 8.0 * ra * words_for(ra) + 8.0) + (double)nb * (12.0 * rb + 8.0 * rb * words_for(rb) + 8.0), s);
   GH_LAUNCH_CHECK();
   return 0;
 }

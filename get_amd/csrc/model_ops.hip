@@ -171,6 +171,57 @@ rows_prep_kernel(const int32_t* __restrict__ pair2claim, const int32_t* __restri
   }
 }
 
+// seg_offsets_kernel + rows_prep_kernel in one launch for B <= 1024 claims: every workgroup scans the counts itself (LDS), workgroup
+// 0 writes offsets / pair2claim / has / lens_eff as the two kernels did, every thread finds its row's claim by a binary search.
+template <typename TL>
+__global__ void __launch_bounds__(256)
+seg_rows_kernel(const int64_t* __restrict__ counts, int B, int b1, const int32_t* __restrict__ rowg, int R, int Mr,
+                int32_t* __restrict__ offsets, int32_t* __restrict__ pair2claim, float* __restrict__ has, int32_t* __restrict__ rowc,
+                const int32_t* __restrict__ d_ids, float* __restrict__ maskf_p, const TL* __restrict__ q_lens, float* __restrict__ lens_eff) {
+  __shared__ int off[1025];
+  const int tid = threadIdx.x;
+  // inclusive scan of the (few) counts: thread t owns claims [4 t, 4 t + 4)
+  int c[4], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int b = 4 * tid + k; c[k] = b < B ? (int)counts[b] : 0; sum += c[k]; }
+  __shared__ int part[256];
+  part[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = part[tid] - sum;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int b = 4 * tid + k; if (b < B) off[b] = run; run += c[k]; }
+  if (tid == 255) off[B] = part[255];
+  __syncthreads();
+  const int total = off[B];
+  if (blockIdx.x == 0) {
+    for (int b = tid; b <= B; b += 256) offsets[b] = off[b];
+    for (int b = tid; b < B; b += 256) {
+      const float hb = counts[b] > 0 ? 1.f : 0.f;
+      has[b] = hb;
+      lens_eff[b] = hb > 0.f ? (float)q_lens[b] : INFINITY;
+    }
+  }
+  auto claim_of = [&](int p) {      // largest b with off[b] <= p  (pairs beyond the counts' total map to claim 0, as seg_offsets does)
+    if (p >= total) return 0;
+    int lo = 0, hi = B - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (off[mid] <= p) lo = mid; else hi = mid - 1; }
+    return lo;
+  };
+  const int i = blockIdx.x * 256 + tid;
+  if (i < b1) pair2claim[i] = claim_of(i);
+  if (i < Mr) {
+    const int pair = rowg ? rowg[i] : i / R;
+    rowc[i] = claim_of(pair);
+    if (maskf_p) maskf_p[i] = d_ids[i] >= 1 ? 1.f : 0.f;
+  }
+}
+
 // new_left[b] = [claim_src_table[src[b]] * has[b] | q_repr[b]]   (q_repr already carries has; graph_based_semantic_structure.py:113-116)
 template <typename TS>
 __global__ void __launch_bounds__(256)
@@ -302,6 +353,22 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
   GH_TRY(get_events(ev));
   const int H = d.H;
   // ---- claim -> pair map, row -> claim map, masks
+  if (d.B <= 1024) {
+    const int nthr = d.Mr > d.B1 ? d.Mr : d.B1;
+    const dim3 grid((nthr + 255) / 256);
+    const int32_t* rg = d.compact ? Ba->rowg : nullptr;
+    float* mp = d.compact ? nullptr : A + f.maskf_p;
+    if (Ba->q_lens_kind == 0)
+      hipLaunchKernelGGL(seg_rows_kernel<float>, grid, dim3(256), 0, s, Ba->counts, d.B, d.B1, rg, d.R, d.Mr, I32(A, f.offsets), I32(A, f.pair2claim),
+                         A + f.has, I32(A, f.rowc), Ba->d_ids, mp, (const float*)Ba->q_lens, A + f.lens_eff);
+    else if (Ba->q_lens_kind == 1)
+      hipLaunchKernelGGL(seg_rows_kernel<int32_t>, grid, dim3(256), 0, s, Ba->counts, d.B, d.B1, rg, d.R, d.Mr, I32(A, f.offsets), I32(A, f.pair2claim),
+                         A + f.has, I32(A, f.rowc), Ba->d_ids, mp, (const int32_t*)Ba->q_lens, A + f.lens_eff);
+    else
+      hipLaunchKernelGGL(seg_rows_kernel<int64_t>, grid, dim3(256), 0, s, Ba->counts, d.B, d.B1, rg, d.R, d.Mr, I32(A, f.offsets), I32(A, f.pair2claim),
+                         A + f.has, I32(A, f.rowc), Ba->d_ids, mp, (const int64_t*)Ba->q_lens, A + f.lens_eff);
+    GH_LAUNCH_CHECK();
+  } else {
   GH_TRY(gh_seg_offsets(Ba->counts, d.B, I32(A, f.offsets), I32(A, f.pair2claim), d.B1, A + f.has, (void*)s));
   {
     const int nthr = d.Mr > d.B ? d.Mr : d.B;
@@ -309,6 +376,7 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
                        d.Mr, I32(A, f.rowc), Ba->d_ids, d.compact ? nullptr : A + f.maskf_p, Ba->q_lens, Ba->q_lens_kind, A + f.has,
                        A + f.lens_eff, d.B);
     GH_LAUNCH_CHECK();
+  }
   }
   // ---- claim branch on the side stream (graph_based_semantic_structure.py:144-155): cell -> masked mean (x has)
   GH_TRY(stream_after(ss, s, ev.ev[0]));
@@ -452,11 +520,19 @@ extern "C" int gh_get_prepare(const int32_t* claim_tokens, const int32_t* claim_
                               int32_t* d_ids, int32_t* d_n, uint64_t* d_bits, float* d_dinv,
                               int m_real, int32_t* goff, int32_t* rowg, int32_t* src, int32_t* cids, float* maskf,
                               const int64_t* slot, int32_t* document, gh_stream_t stream) {
-  GH_TRY(gh_graph_build(claim_tokens, claim_len, b, l, window, q_ids, q_n, q_bits, q_dinv, stream));
-  GH_TRY(gh_graph_build(evd_tokens, evd_len, b1, r, window, d_ids, d_n, d_bits, d_dinv, stream));
-  if (m_real >= 0 && b1 > 0)
-    GH_TRY(gh_ragged_plan(d_n, d_ids, b1, r, goff, rowg, src, cids, maskf, stream));
-  if (slot && document && b1 > 0) {
+  // two launches: both sides' graphs, then the node-compact plan with the document scatter on its way (five launches before)
+  if (b > 0 && b1 > 0) {
+    GH_TRY(launch_graph_build2(claim_tokens, claim_len, b, l, q_ids, q_n, q_bits, q_dinv, evd_tokens, evd_len, b1, r, d_ids, d_n, d_bits,
+                               d_dinv, window, (hipStream_t)stream));
+  } else {
+    GH_TRY(gh_graph_build(claim_tokens, claim_len, b, l, window, q_ids, q_n, q_bits, q_dinv, stream));
+    GH_TRY(gh_graph_build(evd_tokens, evd_len, b1, r, window, d_ids, d_n, d_bits, d_dinv, stream));
+  }
+  bool scattered = false;
+  if (m_real >= 0 && b1 > 0) {
+    GH_TRY(launch_ragged_plan(d_n, d_ids, b1, r, goff, rowg, src, cids, maskf, slot, document, (hipStream_t)stream, &scattered));
+  }
+  if (slot && document && b1 > 0 && !scattered) {
     hipLaunchKernelGGL(document_scatter_kernel, dim3(b1), dim3(256), 0, (hipStream_t)stream, d_ids, slot, document, r);
     GH_LAUNCH_CHECK();
   }
