@@ -116,7 +116,7 @@ int cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* dinv,
                   const float* w_h1, const float* b_z0, const float* b_z1, const float* b_r0, const float* b_r1, const float* b_h0,
                   const float* b_h1, float* xp, float* a, float* z, float* rr, float* rx, float* hh, float* out, float drop_p,
                   uint32_t drop_seed, const float* score_w, float* score_x, float score_drop_p, uint32_t score_drop_seed,
-                  void* stream);
+                  void* stream, int pad_out_dead = 0);      // pad_out_dead: nobody reads `out` of the padding rows (fused scorer only)
 int cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const int32_t* goff,
                   int m_real, const float* x, const int32_t* ids, int n, int r, int din, int h, const float* wt_p,
                   const float* wt_z0, const float* wt_z1, const float* wt_r0, const float* wt_r1, const float* wt_h0,

@@ -555,6 +555,8 @@ gemm_nt_kernel(const Launch L_byval) {
   const int accumulate = P.accumulate;
   const int heads = P.heads;
   const bool scorer = (epi == EPI_TANH_H) && (P.w2 != nullptr);
+  const int pad_rows = (MODE == 2 || (dbg_bits & 64)) ? 0 : P.seg0_rows;                    // first padding row of the node-compact layout (0: none)
+  const bool out_dead = scorer && P.ldu == 1;                            // EPI_TANH_H: padding rows' outputs feed the scorer only
   const bool rowred = (epi == EPI_ATT) || scorer;
   float* ep = reinterpret_cast<float*>(smem);
   float* const ep_bias_ptr = ep + 16 * WM * EP_PITCH + NW * 64 * 4;
@@ -664,15 +666,21 @@ gemm_nt_kernel(const Launch L_byval) {
           } else if (E == EPI_SIGMOID_R) {
             const float4 x = xa[j];
             const float4 r4 = make_float4(sigmoidf_(w.x), sigmoidf_(w.y), sigmoidf_(w.z), sigmoidf_(w.w));
-            st4(C, o, r4, io & 1);
+            // padding rows of the node-compact layout (row >= seg0_rows): r is read by the backward only, and the backward
+            // never touches a padding row -- the store is dead (a third of the first cell's rows in training mode)
+            if (!(pad_rows > 0 && row >= pad_rows)) st4(C, o, r4, io & 1);
             st4(out1, o, make_float4(r4.x * x.x, r4.y * x.y, r4.z * x.z, r4.w * x.w), io & 2);
           } else if (E == EPI_TANH_H) {
             const float4 z = xa[j], x = xb[j];
             const float4 h = make_float4(tanhf_(w.x), tanhf_(w.y), tanhf_(w.z), tanhf_(w.w));
             float4 y = make_float4(h.x * z.x + x.x * (1.f - z.x), h.y * z.y + x.y * (1.f - z.y),
                                    h.z * z.z + x.z * (1.f - z.z), h.w * z.w + x.w * (1.f - z.w));
-            st4(C, o, h, io & 1);
-            st4(out1, o, y, io & 2);
+            // padding rows: h~ is backward-only (dead, as r above); the cell output of a padding row feeds the fused scorer
+            // projection below and nothing else when the caller says so (ldu = 1: the composite forward, whose second cell
+            // and attention run on the real rows only)
+            const bool pad = pad_rows > 0 && row >= pad_rows;
+            if (!pad) st4(C, o, h, io & 1);
+            if (!(pad && out_dead)) st4(out1, o, y, io & 2);
             if (c32) *reinterpret_cast<float4*>(c32 + o) = y;
             if (scorer) {    // the word scorer sees dropout(out) (its own input dropout, wrapper.py:189-190)
               if (drop_mode == 2)

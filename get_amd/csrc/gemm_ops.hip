@@ -768,7 +768,7 @@ int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* d
                                 float* xp, float* a, float* z, float* rr, float* rx, float* hh, float* out,
                                 float drop_p, uint32_t drop_seed,
                                 const float* score_w, float* score_x, float score_drop_p, uint32_t score_drop_seed,
-                                gh_stream_t stream) {
+                                gh_stream_t stream, int pad_out_dead) {
   hipStream_t s = (hipStream_t)stream;
   GH_REQUIRE(n > 0 && r > 0 && din > 0 && h > 0, "ggnn_cell_fwd: bad sizes n=%d r=%d din=%d h=%d", n, r, din, h);
   GH_REQUIRE(!bf || (din % 8 == 0 && h % 8 == 0 && out32), "ggnn_cell_fwd_bf16: needs din %% 8 == 0, h %% 8 == 0 (din=%d h=%d) and out32", din, h);
@@ -851,6 +851,7 @@ int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* d
     if (m_rows > m_real) ph.seg0_rows = (m_real > 0 ? m_real : 1);
     if (score_w) {
       ph.w2 = score_w; ph.e = score_x;
+      if (pad_out_dead && m_rows > m_real) ph.ldu = 1;
       set_dropout(ph, 2, h, score_drop_p, score_drop_seed);
     }
     b.add(ph);

@@ -317,10 +317,10 @@ static inline int32_t* I32(float* A, int64_t off) { return reinterpret_cast<int3
 static int cell_fwd(const gh_cell_params& c, const CellBuf& cb, float* A, const uint64_t* bits, const float* dinv, const float* vals,
                     const uint64_t* keep, const int32_t* goff, int m_real, int m_rows, const float* x, const int32_t* ids, int n, int r,
                     int din, int h, float drop_p, uint32_t seed, const float* score_w, float* score_x, float sdrop, uint32_t sseed,
-                    hipStream_t s) {
+                    hipStream_t s, int pad_out_dead = 0) {
   return cell_fwd_impl(0, nullptr, bits, dinv, vals, keep, goff, m_real, m_rows, x, ids, n, r, din, h, c.w_p, c.w_z0, c.w_z1, c.w_r0,
                        c.w_r1, c.w_h0, c.w_h1, c.b_z0, c.b_z1, c.b_r0, c.b_r1, c.b_h0, c.b_h1, A + cb.xp, A + cb.a, A + cb.z,
-                       A + cb.rr, A + cb.rx, A + cb.hh, A + cb.out, drop_p, seed, score_w, score_x, sdrop, sseed, (void*)s);
+                       A + cb.rr, A + cb.rx, A + cb.hh, A + cb.out, drop_p, seed, score_w, score_x, sdrop, sseed, (void*)s, pad_out_dead);
 }
 static int cell_bwd(const gh_cell_params& c, const CellBuf& cb, const float* A, const uint64_t* bits, const float* dinv,
                     const float* vals, const uint64_t* keep, const int32_t* goff, int m_real, const float* x, const int32_t* ids, int n,
@@ -403,7 +403,7 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
   const int32_t* goff = d.compact ? Ba->goff : nullptr;
   const int32_t* ids1 = d.compact ? Ba->cids : Ba->d_ids;
   GH_TRY(cell_fwd(Mo->cell1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, d.M1, Mo->embedding, ids1, d.B1, d.R, d.D, H,
-                  Ba->drop_gnn, Ba->seed_cell1, Mo->scorer_w, A + f.score_x, Ba->drop_gnn, Ba->seed_scorer, s));
+                  Ba->drop_gnn, Ba->seed_cell1, Mo->scorer_w, A + f.score_x, Ba->drop_gnn, Ba->seed_scorer, s, 1));
   uint64_t* keep = reinterpret_cast<uint64_t*>(O + f.keep);
   GH_TRY(gh_scorer_gsl(Ba->d_bits, Ba->d_dinv, Ba->d_vals, goff, (d.compact && Ba->collapsed) ? 1 : 0, nullptr, A + f.score_x, Mo->scorer_w,
                        Mo->scorer_gate, d.B1, d.R, H, Ba->k_keep, O + f.score, keep, 0.f, 0, (void*)s));
