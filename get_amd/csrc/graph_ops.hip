@@ -799,7 +799,7 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   if (cap_env == -2) cap_env = measure_env("GH_SPMM_SLAB_KB", -1);
   // round 4, A/B on one box: many graphs of <= 128 nodes (the bench step's 960 x 100) run 0.4 % faster per STEP on 24 KB slabs (five
   // slabs of 15 float4 instead of four of 19), few graphs (218: the realistic step) 1 % slower
-  const int cap_kb = cap_env > 0 ? cap_env : ((n >= 512 && r <= 128 && !bf16) ? 24 : 32);   // measured per step: 48 KB -> 0.314 ms, 32 -> 0.288, 24 -> 0.294, 16 -> 0.344 (R = 100); R = 200: 0.60 -> 0.43
+  const int cap_kb = cap_env > 0 ? cap_env : ((goff && n >= 512 && r <= 128 && !bf16) ? 24 : 32);      // (node-compact layout only: the padded 100-row graphs run 58 -> 69 us on 24 KB slabs)   // measured per step: 48 KB -> 0.314 ms, 32 -> 0.288, 24 -> 0.294, 16 -> 0.344 (R = 100); R = 200: 0.60 -> 0.43
   const int lds_cap = (cap_kb * 1024) / (r * (v4 ? 16 : 4));
   const int slab_max = v4 ? (lds_cap < 32 ? (lds_cap < 4 ? 4 : lds_cap) : 32) : (lds_cap < 128 ? (lds_cap < 16 ? 16 : lds_cap) : 128);
   const int nslab = (hv + slab_max - 1) / slab_max;

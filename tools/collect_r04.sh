@@ -35,4 +35,5 @@ GET_AMD_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 10 --war
 GET_AMD_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 --global-batch 64 --evd-dist snopes > $O/bench_2rank_gloo_gb64_snopes.json 2>> $O/bench_2rank.err
 python bench.py --gpus 2 > $O/bench_gpus2_on_1gpu_box.out 2>&1; echo "rc=$?" >> $O/bench_gpus2_on_1gpu_box.out
 bash tools/batch_sweep_r04.sh > /dev/null 2>&1
+timeout 900 python tools/soak.py 30000 2>/dev/null | grep '^{' > $O/soak.json
 ls -la $O
