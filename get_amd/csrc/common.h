@@ -141,7 +141,8 @@ int att_bwd_impl(const float* left, const float* right, const int32_t* goff, int
 //   instead of the first one, i.e. on the weight-gradient stream, off the critical path; with dw2_buf ([b][heads][ha] floats, the same
 //   pointer in both calls) the per-pair dW2 partials go there instead of the stream workspace and their reduction, like the
 //   per-claim sum of du, moves into the second call as well.
-int linear2_fwd(const float* x0, int k0, const float* x1, int k1, const float* w, const float* bias, float* y, int m, int n, hipStream_t s);
+int linear2_fwd(const float* x0, int k0, const float* x1, int k1, const float* w, const float* bias, float* y, int m, int n, hipStream_t s,
+                const float* w_out = nullptr, const float* b_out = nullptr, float* y_out = nullptr, int n_out = 0);
 int linear2_bwd(const float* x0, int k0, const float* x1, int k1, const float* wt, const float* g, int m, int n, float* dx0,
                 int dx0_accumulate, float* dx1, float* dw, float* db, hipStream_t s);
 

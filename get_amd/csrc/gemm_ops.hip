@@ -452,14 +452,23 @@ nt_finish_kernel(const FinishArgs F) {
         v.x += c4v.x; v.y += c4v.y; v.z += c4v.z; v.w += c4v.w;
       }
       *reinterpret_cast<float4*>(o) = v;
+      if (it.w2) {      // a second, few-column linear layer on the finished row (the head's out[1]): e = v . w2^T (+ in0 as its bias)
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < it.heads) {
+            const float4 w = *reinterpret_cast<const float4*>(it.w2 + (size_t)c * it.N + col);
+            pe[c] += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
+          }
+      }
     }
   }
-  if (it.epi == EPI_ATT && (!split || wave == 0)) {
+  const bool proj = it.epi == EPI_STORE && it.w2 != nullptr;
+  if ((it.epi == EPI_ATT || proj) && (!split || wave == 0)) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       float v = pe[c];
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-      if (lane == 0 && c < it.heads) it.e[(size_t)row * it.heads + c] = v;
+      if (lane == 0 && c < it.heads) it.e[(size_t)row * it.heads + c] = v + ((proj && it.in0) ? it.in0[c] : 0.f);
     }
   }
 }
@@ -479,6 +488,7 @@ struct Batch {
   float* cs_out[GH_MAX_PROBLEMS] = {nullptr};
   float* cs_out2[GH_MAX_PROBLEMS] = {nullptr};
   bool colsum_fused = false;
+  bool split_done = false;      // the last flush took the few-row split-K plan (its finish kernel applied the problems' row epilogues)
   void want_colsum(float* o, float* o2) { if (L.nprob > 0) { cs_out[L.nprob - 1] = o; cs_out2[L.nprob - 1] = o2; } }
 
   float* g_ws = nullptr;
@@ -716,6 +726,7 @@ struct Batch {
     // many partials over few rows: a workgroup per row (the four waves share the partials); otherwise a wave per row
     F.split = (ks >= 16 && max_m <= 8192) ? 1 : 0;      // (ks = 9, M = 960 -- the claim cell, the evidence-level attention -- measured equal or slower split)
     hipLaunchKernelGGL(nt_finish_kernel, dim3(F.split ? max_m : (max_m + 3) / 4, F.n), dim3(256), 0, s, F);
+    split_done = true;
     e = hipGetLastError();
     if (e != hipSuccess) err = e;
     reset();
@@ -1237,14 +1248,21 @@ extern "C" int gh_concat_att_bwd(const float* left, const float* right, const in
 
 // y[m][n] = [x0 | x1] . W^T + bias with W [n][k0 + k1] as stored: the head's first layer on the concatenation
 // [claim vector | attended evidences] (graph_based_semantic_structure.py:251-267) without materialising the concatenation.
-int gh::linear2_fwd(const float* x0, int k0, const float* x1, int k1, const float* w, const float* bias, float* y, int m, int n, hipStream_t s) {
+// w_out / b_out / y_out / n_out (optional): a second linear layer of n_out <= 8 columns on top (the head's out[1], 300 -> 2 classes):
+// y_out = y . w_out^T + b_out rides in the split-K finish kernel when the product takes that plan, else one extra launch.
+int gh::linear2_fwd(const float* x0, int k0, const float* x1, int k1, const float* w, const float* bias, float* y, int m, int n, hipStream_t s,
+                    const float* w_out, const float* b_out, float* y_out, int n_out) {
   Batch b(false, m, s);
   Problem p = gemm_problem(m, n, EPI_STORE, y, n, x0, k0, w, k0 + k1, k0);
   if (k1 > 0) add_seg(p, x1, k1, w + k0, k0 + k1, k1);
   p.bias = bias;
+  const bool two = w_out && y_out && n_out >= 1;
+  const bool fuse = two && n_out <= 8 && n % 4 == 0 && n <= b.bn && al16(w_out);
+  if (fuse) { p.w2 = w_out; p.e = y_out; p.heads = n_out; p.in0 = b_out; }
   b.add(p);
   b.flush();
   GH_CHECK_HIP(b.err);
+  if (two && !(fuse && b.split_done)) return launch_tiny_linear_fwd(y, w_out, b_out, y_out, m, n, n_out, s);
   return 0;
 }
 // dx0 [m][k0] (+)= g Wt[:k0] ; dx1 [m][k1] = g Wt[k0:] (wt = W^T [k0+k1][n]) ; dw [n][k0+k1] += g^T [x0 | x1] ; db += colsum(g).

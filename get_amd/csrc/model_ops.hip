@@ -420,8 +420,13 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
   GH_TRY(att_fwd_impl(A + f.new_left, d.B, nullptr, A + f.right_e, A + f.mask_e, nullptr, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he,
                       Mo->att_evd.w1, Mo->att_evd.w2, A + f.ue, A + f.te, A + f.ee, O + f.we, A + f.att_e, s, 2));
   // ---- head (:251-267, :69-74): Linear([claim | attended evidences]) -> Linear, no activation
-  GH_TRY(linear2_fwd(A + f.new_left, d.Xl, A + f.att_e, d.Dre * d.he, Mo->out0_w, Mo->out0_b, A + f.y0, d.B, H, s));
-  GH_TRY(gh_linear_fwd(A + f.y0, Mo->out1_w, Mo->out1_b, O + f.phi, d.B, H, d.C, (void*)s));
+  if (d.C <= 8) {      // the second layer rides in the first one's finish kernel
+    GH_TRY(linear2_fwd(A + f.new_left, d.Xl, A + f.att_e, d.Dre * d.he, Mo->out0_w, Mo->out0_b, A + f.y0, d.B, H, s, Mo->out1_w, Mo->out1_b,
+                       O + f.phi, d.C));
+  } else {
+    GH_TRY(linear2_fwd(A + f.new_left, d.Xl, A + f.att_e, d.Dre * d.he, Mo->out0_w, Mo->out0_b, A + f.y0, d.B, H, s));
+    GH_TRY(gh_linear_fwd(A + f.y0, Mo->out1_w, Mo->out1_b, O + f.phi, d.B, H, d.C, (void*)s));
+  }
   return 0;
 }
 
