@@ -13,7 +13,8 @@ import bench  # noqa: E402
 from get_amd.dist import FlatTrainer  # noqa: E402
 from get_amd import ops  # noqa: E402
 
-wl = bench.build_workload(device="cuda:0", n_batches=4)
+import sys as _s
+wl = bench.build_workload(device="cuda:0", n_batches=4, evd_dist=("snopes" if "snopes" in _s.argv else "fixed"))
 model = wl["model"]
 trainer = FlatTrainer(model, lr=1e-4, weight_decay=1e-3)
 ops.bump_weight_epoch()
