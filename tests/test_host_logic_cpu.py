@@ -23,3 +23,31 @@ def test_snopes_evidence_histogram():
     assert abs((h * np.arange(1, 27)).sum() / h.sum() - 6.92) < 0.01
     c = snopes_evidence_counts(np.random.default_rng(0), 20000)
     assert c.min() >= 1 and c.max() <= 26 and abs(c.mean() - 6.92) < 0.15
+
+
+def test_reference_tensor_shim_depads_like_the_fitter_on_cpu():
+    """get_amd.batch.kargs_from_reference_tensors in its plain-tensor form (what runs without the HIP library, and what
+    gh_ref_depad is compared with on the GPU): the padded (B, n, R) ids and (B, n, R, R) float64 adjacency come back de-padded
+    claim-major exactly as the fitter's per-claim loop leaves them (char_man_fitter_query_repr1.py:204-223, restated in
+    oracle/assemble.py), including a claim whose count is below n and a claim with a single evidence."""
+    import torch
+
+    from get_amd.batch import kargs_from_reference_tensors
+    from get_amd.synth import make_raw_batch
+    from oracle import get_oracle as O
+    from oracle.assemble import assemble_inputs
+    cfg = SynthConfig(batch=4, emb_dim=32, hidden=32, vocab=200, n_article_src=10, n_claim_src=5, src_dim=8, evd_counts=[3, 30, 1, 9])
+    raw = make_raw_batch(cfg, 17)
+    inp = assemble_inputs(raw, cfg, O.convert_text)
+    B, n, R = inp["document"].shape
+    adj_padded = np.zeros((B, n, R, R))
+    last = 0
+    for b, c in enumerate(inp["evd_counts"]):
+        adj_padded[b, :c] = inp["doc_adj"][last:last + c]
+        last += c
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    k = kargs_from_reference_tensors(T(inp["query_lens"]), T(inp["document"]), T(adj_padded), T(inp["query_adj"]),
+                                     T(np.asarray(inp["evd_counts"])), T(inp["doc_sources"]), T(inp["query_sources"]), n_max=n)
+    assert np.array_equal(k["doc_content_without_padding_evidences"].numpy(), inp["doc_ids"])
+    assert np.array_equal(k["docs_adj"].numpy(), inp["doc_adj"])
+    assert k["fixed_num_evidences"] == n and k["docs_adj"].shape[0] == int(np.sum(inp["evd_counts"]))
