@@ -321,7 +321,7 @@ MIN_TIMED_SECONDS = 2.0        # the K-step block is repeated until the timed re
 MAX_TIMED_BLOCKS = 64
 MIN_TIMED_BLOCKS = 5           # a median over fewer blocks is a mean in disguise
 SETTLE_REL = 0.02              # untimed settle blocks until two consecutive ones agree within this ...
-MAX_SETTLE_BLOCKS = 8          # ... or this many have run
+MAX_SETTLE_BLOCKS = 12         # ... or this many have run (the leg is then flagged `unsettled`)
 UNSTABLE_SPREAD = 0.10         # a leg whose timed blocks spread more than this is flagged, not trusted
 
 
@@ -409,6 +409,7 @@ def measure(args, wl, trainer, world, device, dist, steps, warmup, profile=True,
         if len(settle) >= 2 and abs(settle[-1] - settle[-2]) <= SETTLE_REL * min(settle[-1], settle[-2]):
             break
     pairs_fn()
+    unsettled = not (len(settle) >= 2 and abs(settle[-1] - settle[-2]) <= SETTLE_REL * min(settle[-1], settle[-2]))
     warm_dt = min(settle[-2:]) if len(settle) >= 2 else settle[-1]
     n_blocks = int(min(MAX_TIMED_BLOCKS, max(MIN_TIMED_BLOCKS, np.ceil(min_seconds / max(warm_dt, 1e-6)))))
     prof_dom = None
@@ -431,7 +432,8 @@ def measure(args, wl, trainer, world, device, dist, steps, warmup, profile=True,
             prof_dom = _lib.profile_collect()[DOMINANT]
             prof_dom["steps"] = prof_steps
             _lib.profile_enable(False)
-    return {"blocks_s": blocks, "block_pairs": block_pairs, "settle_s": settle, "loss": loss, "prof_dom": prof_dom, "step": step}
+    return {"blocks_s": blocks, "block_pairs": block_pairs, "settle_s": settle, "unsettled": unsettled, "loss": loss,
+            "prof_dom": prof_dom, "step": step}
 
 
 def phase_split(wl, trainer, steps=5):
@@ -493,6 +495,57 @@ def parity_check(wl, k=4):
 
 DOMINANT = "gemm_big"
 STRONG_GLOBAL_BATCH = 256         # BASELINE configs[3]
+
+# The BASELINE configs the headline invocation does not run as its main workload, printed beside it (`other_configs`) so that
+# the driver's `python bench.py --gpus 1` line carries a timing of each: (name, SynthConfig overrides, gemm mode, steps per block)
+OTHER_CONFIGS = [
+    ("configs[2] PolitiFact-shaped: B=64 x 10 evidences, L_right=200, fp32",
+     dict(batch=64, n_evd=10, len_right=200), "fp32", 10),
+    ("configs[4] h=768, 8 word heads, gnn_window=5, gsl_rate=0.8, B=32 x 30, fp32",
+     dict(batch=32, n_evd=30, hidden=768, emb_dim=768, word_heads=8, window=5, gsl_rate=0.8), "fp32", 4),
+    ("configs[4] h=768, 8 word heads, gnn_window=5, gsl_rate=0.8, B=32 x 30, bf16 storage in the cells",
+     dict(batch=32, n_evd=30, hidden=768, emb_dim=768, word_heads=8, window=5, gsl_rate=0.8), "bf16", 10),
+]
+
+
+def other_config_leg(args, name, overrides, mode, steps, device, dist, seed):
+    """One BASELINE config as a side leg of the headline run: its own model, trainer and resident batches, the same step and
+    the same measure() protocol (settle blocks, >= MIN_TIMED_BLOCKS timed blocks, median), the live roofline of the dominant
+    kernel (HIP events around its launches in the first timed steps) and an evaluation-mode logit slice against the CPU oracle."""
+    from get_amd import _lib, ops
+    from get_amd.dist import FlatTrainer
+    cfg = SynthConfig(**overrides)
+    _lib.set_gemm_mode(mode)
+    ops.bump_weight_epoch()
+    try:
+        wl = build_workload(seed=seed, device=device, cfg=cfg, n_batches=2)
+        wl["model"].train(True)
+        tr = FlatTrainer(wl["model"], lr=1e-4, weight_decay=1e-3)
+        ops.bump_weight_epoch()
+        m = measure(args, wl, tr, 1, device, dist, steps, 3, profile=True, min_seconds=1.0)
+        s = summarize_blocks(m, steps, m["block_pairs"])
+        leg = {"workload": name, "gemm_mode": mode, **leg_summary(s), "pairs_per_step": wl["b1"],
+               "layout_rows": wl["m_real"], "mode": "train (dropout on)"}
+        pd = m["prof_dom"]
+        if pd and pd["launches"] > 0 and pd["ms"] > 0:
+            peak = PEAK_BF16_MFMA_TFLOPS if mode == "bf16" else PEAK_F32_MFMA_TFLOPS
+            rate = pd["work"] / (pd["ms"] * 1e-3) / 1e12
+            leg["roofline"] = {"kernel": DOMINANT, "bound": "mfma", "achieved": rate, "peak": peak, "unit": "TFLOP/s",
+                               "frac": rate / peak, "traffic": None, "avg_launch_ms": pd["ms"] / pd["launches"],
+                               "launches_per_step": pd["launches"] / pd["steps"],
+                               "measured": f"HIP events around every {DOMINANT} launch of the first {pd['steps']} timed steps"}
+        leg["parity"] = parity_check(wl, k=2)
+        if mode == "bf16":
+            leg["parity"]["note"] = "bf16 storage inside the cells: stated bounds are logits 2e-3, keep-set flips <= 0.5 % of the real nodes"
+        fl = flops_per_pair(cfg, wl["nnz_per_graph"], wl["m_real"] / max(wl["b1"], 1) if wl["compact"] else None)
+        fl_run = fl.get("executed", fl["fwd_bwd"])
+        leg["path_tflops"] = fl_run * s["value"] / 1e12
+        del wl, tr, m
+        return leg
+    finally:
+        ops.bump_weight_epoch()
+        _lib.set_gemm_mode("fp32")
+        torch.cuda.empty_cache()
 PROFILE_TIMED_STEPS = 5           # timed steps whose dominant-kernel launches carry HIP events
 
 
@@ -539,6 +592,8 @@ def summarize_blocks(m, steps, world_pairs_per_block):
                      f"MAX over ranks) is timed >= {MIN_TIMED_BLOCKS} times and until >= {MIN_TIMED_SECONDS:g} s; value = median block"}
     if spread is not None and spread > UNSTABLE_SPREAD:
         timed["unstable"] = True
+    if m.get("unsettled"):
+        timed["unsettled"] = True      # the settle loop hit MAX_SETTLE_BLOCKS without two agreeing blocks: warm-up may have leaked in
     return {"value": med, "ms_per_step": 1e3 * float(np.median(secs)) / steps, "timed": timed}
 
 
@@ -550,6 +605,8 @@ def leg_summary(s):
                                        "pairs_per_s_max", "spread_rel", "settle_blocks_untimed", "settle_block_ms_per_step")}}
     if t.get("unstable"):
         out["unstable"] = True
+    if t.get("unsettled"):
+        out["unsettled"] = True
     return out
 
 
@@ -594,6 +651,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-series", action="store_true", help="skip the realistic evidence-count series")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the legs of BASELINE configs[2] / configs[4] fp32 / configs[4] bf16 the headline run prints beside its line")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline (default: the probe's fastest pool size)")
     ap.add_argument("--measure-build", action="store_true",
                     help="kernel A/B tooling only: load lib/libget_hip_measure.so (make -C get_amd/csrc measure), honour the GH_* "
@@ -918,6 +977,10 @@ def main():
             ops.bump_weight_epoch()
             out["realistic_series"] = {"evidence_counts": "empirical Snopes histogram (get_amd.synth.SNOPES_EVD_HIST, mean 6.9, max 26)",
                                        "rows": series}
+        if world == 1 and headline and default_side and not args.no_other_configs:
+            # the other BASELINE configs as legs of the same run (two of five configs had no driver-observed timing)
+            out["other_configs"] = [other_config_leg(args, nm, ov, md, st, device, dist, SEED + 7 * (i + 1))
+                                    for i, (nm, ov, md, st) in enumerate(OTHER_CONFIGS)]
         if world == 1 and not args.no_cpu_baseline and not args.forward_only:
             out["parity"] = parity_check(wl)
             probe = cpu_baseline_probe(wl)

@@ -61,6 +61,7 @@ enum ProfTag : int {
 };
 // streaming-kernel launches over fewer than this many graphs / pairs are booked under PROF_FEW_ROWS
 constexpr int PROF_FEW_GROUPS = 256;
+unsigned int* clamp_counter();      // four device counters of clamped out-of-range inputs on the current device (gh_clamp_events); NULL = allocation failed
 bool prof_enabled();
 void prof_begin(hipStream_t s, int tag);   // events are recorded only for tags selected by gh_profile_select
 void prof_end(int tag, double work, hipStream_t s);

@@ -3,6 +3,8 @@
 // weight transpose, fused flat Adam.  Plus the library's error plumbing.
 #include "../../include/get_hip.h"
 #include "common.h"
+#include <mutex>
+#include <unordered_map>
 #include "gemm.hip.h"
 #include <stdarg.h>
 #include <vector>
@@ -65,7 +67,14 @@ transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int rows, 
   }
 }
 
-struct TransposeBatch { const float* src[32]; float* dst[32]; int rows[32]; int cols[32]; int tile0[33]; int n; };
+struct TransposeBatch { const float* src[32]; float* dst[32]; int rows[32]; int cols[32]; int tile0[33]; int n;
+                        unsigned short* w16[32]; unsigned short* t16[32]; };      // optional bf16 twins of src and of src^T (gh_weights_refresh)
+__device__ __forceinline__ unsigned short bf16_rne(float f) {
+  unsigned u = __builtin_bit_cast(unsigned, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);      // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
 __global__ void __launch_bounds__(256)
 transpose_batch_kernel(const TransposeBatch B) {
   __shared__ float tile[32][33];
@@ -77,14 +86,24 @@ transpose_batch_kernel(const TransposeBatch B) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const float* w = B.src[m];
   float* wt = B.dst[m];
+  unsigned short* w16 = B.w16[m];
+  unsigned short* t16 = B.t16[m];
   for (int j = ty; j < 32; j += 8) {
     const int r = by + j, c = bx + tx;
-    if (r < rows && c < cols) tile[j][tx] = w[(size_t)r * cols + c];
+    if (r < rows && c < cols) {
+      const float v = w[(size_t)r * cols + c];
+      tile[j][tx] = v;
+      if (w16) w16[(size_t)r * cols + c] = bf16_rne(v);
+    }
   }
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
     const int c = bx + j, r = by + tx;
-    if (r < rows && c < cols) wt[(size_t)c * rows + r] = tile[tx][j];
+    if (r < rows && c < cols) {
+      const float v = tile[tx][j];
+      if (wt) wt[(size_t)c * rows + r] = v;
+      if (t16) t16[(size_t)c * rows + r] = bf16_rne(v);
+    }
   }
 }
 
@@ -1067,7 +1086,7 @@ template <typename TS, typename TD>
 __global__ void __launch_bounds__(256)
 evd_assemble_fwd_kernel(const float* __restrict__ avg, const int32_t* __restrict__ offsets, const float* __restrict__ table,
                         const TS* __restrict__ sources, const TD* __restrict__ document, float* __restrict__ right,
-                        float* __restrict__ mask, int n_max, int Xa, int Ds, int R) {
+                        float* __restrict__ mask, int n_max, int Xa, int Ds, int R, int table_rows, unsigned int* __restrict__ clamped) {
   const int b = blockIdx.x / n_max, slot = blockIdx.x % n_max;
   const int lo = offsets[b], cnt = min(offsets[b + 1] - lo, n_max);
   float* d = right + (size_t)blockIdx.x * (Xa + Ds);
@@ -1079,7 +1098,11 @@ evd_assemble_fwd_kernel(const float* __restrict__ avg, const int32_t* __restrict
   }
   if (Ds > 0) {
     long long sid = (long long)sources[blockIdx.x];
-    if (sid < 0) sid = 0;                                        // -1 padding -> row 0 (:166-168)
+    // -1 padding -> row 0 (:166-168).  Any other id outside the table would raise in nn.Embedding (:169); here it is clamped
+    // for memory safety and counted (gh_clamp_events)
+    if ((sid < -1 || sid >= table_rows) && threadIdx.x == 0) atomicAdd(clamped + 2, 1u);
+    if (sid < 0) sid = 0;
+    if (sid >= table_rows) sid = table_rows - 1;
     const float* tp = table + (size_t)sid * Ds;
     for (int i = threadIdx.x; i < Ds; i += blockDim.x) d[Xa + i] = tp[i];
   }
@@ -1097,7 +1120,7 @@ evd_assemble_fwd_kernel(const float* __restrict__ avg, const int32_t* __restrict
 template <typename TS>
 __global__ void __launch_bounds__(256)
 evd_assemble_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ offsets, const TS* __restrict__ sources,
-                        float* __restrict__ d_avg, float* __restrict__ d_table, int n_slots, int n_max, int Xa, int Ds) {
+                        float* __restrict__ d_avg, float* __restrict__ d_table, int n_slots, int n_max, int Xa, int Ds, int table_rows) {
   extern __shared__ __attribute__((aligned(16))) int sids[];
   const int me = blockIdx.x;
   const int b = me / n_max, slot = me % n_max;
@@ -1115,7 +1138,7 @@ evd_assemble_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__
     const int bi = i / n_max;
     const bool real = (i - bi * n_max) < min(offsets[bi + 1] - offsets[bi], n_max);
     const long long v = (long long)sources[i];
-    sids[i] = real ? (v < 0 ? 0 : (int)v) : -1;
+    sids[i] = real ? (v < 0 ? 0 : (v >= table_rows ? table_rows - 1 : (int)v)) : -1;      // same clamp as the forward
   }
   __syncthreads();
   const int mine = sids[me];
@@ -1238,9 +1261,38 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
   }
 }
 
+// Device counters of clamped out-of-range inputs (include/get_hip.h gh_clamp_events): four unsigned ints per device, allocated
+// on first use, handed to the kernels that clamp (cross_entropy: [0], left_assemble: [1], evd_assemble: [2]).
+static std::mutex g_clamp_mu;
+static std::unordered_map<int, unsigned int*> g_clamp_buf;
+unsigned int* clamp_counter() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_clamp_mu);
+  auto it = g_clamp_buf.find(dev);
+  if (it != g_clamp_buf.end()) return it->second;
+  unsigned int* p = nullptr;
+  if (hipMalloc((void**)&p, 4 * sizeof(unsigned int)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMemset(p, 0, 4 * sizeof(unsigned int)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+  g_clamp_buf.emplace(dev, p);
+  return p;
+}
+
 }  // namespace gh
 
 using namespace gh;
+
+extern "C" int gh_clamp_events(int64_t* out, int reset) {
+  GH_REQUIRE(out, "clamp_events: NULL output");
+  unsigned int* p = clamp_counter();
+  GH_REQUIRE(p, "clamp_events: cannot allocate the counter");
+  unsigned int h[4] = {0, 0, 0, 0};
+  GH_CHECK_HIP(hipDeviceSynchronize());
+  GH_CHECK_HIP(hipMemcpy(h, p, sizeof(h), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 4; ++i) out[i] = (int64_t)h[i];
+  if (reset) GH_CHECK_HIP(hipMemset(p, 0, sizeof(h)));
+  return 0;
+}
 
 extern "C" int gh_abi_version(void) { return GH_ABI_VERSION; }
 extern "C" const char* gh_last_error(void) { return g_err; }
@@ -1280,15 +1332,18 @@ extern "C" int gh_transpose(const float* w, float* wt, int rows, int cols, gh_st
   return 0;
 }
 
-extern "C" int gh_transpose_batch(int n, const void* const* src, void* const* dst, const int* rows, const int* cols,
-                                  gh_stream_t stream) {
+extern "C" int gh_weights_refresh(int n, const void* const* src, void* const* dst, void* const* dst_w16, void* const* dst_t16,
+                                  const int* rows, const int* cols, gh_stream_t stream) {
+  GH_REQUIRE(n >= 0 && (n == 0 || (src && rows && cols)), "weights_refresh: NULL arrays");
   for (int i0 = 0; i0 < n; i0 += 32) {
     TransposeBatch B;
     B.n = (n - i0 < 32) ? n - i0 : 32;
     int tiles = 0;
     for (int i = 0; i < B.n; ++i) {
-      GH_REQUIRE(rows[i0 + i] > 0 && cols[i0 + i] > 0, "transpose_batch: bad size at %d", i0 + i);
-      B.src[i] = (const float*)src[i0 + i]; B.dst[i] = (float*)dst[i0 + i];
+      GH_REQUIRE(rows[i0 + i] > 0 && cols[i0 + i] > 0 && src[i0 + i], "weights_refresh: bad matrix at %d", i0 + i);
+      B.src[i] = (const float*)src[i0 + i]; B.dst[i] = dst ? (float*)dst[i0 + i] : nullptr;
+      B.w16[i] = dst_w16 ? (unsigned short*)dst_w16[i0 + i] : nullptr;
+      B.t16[i] = dst_t16 ? (unsigned short*)dst_t16[i0 + i] : nullptr;
       B.rows[i] = rows[i0 + i]; B.cols[i] = cols[i0 + i];
       B.tile0[i] = tiles;
       tiles += ((rows[i0 + i] + 31) / 32) * ((cols[i0 + i] + 31) / 32);
@@ -1298,6 +1353,12 @@ extern "C" int gh_transpose_batch(int n, const void* const* src, void* const* ds
     GH_LAUNCH_CHECK();
   }
   return 0;
+}
+
+extern "C" int gh_transpose_batch(int n, const void* const* src, void* const* dst, const int* rows, const int* cols,
+                                  gh_stream_t stream) {
+  GH_REQUIRE(n == 0 || dst, "transpose_batch: NULL dst");
+  return gh_weights_refresh(n, src, dst, nullptr, nullptr, rows, cols, stream);
 }
 
 extern "C" int gh_seg_offsets(const int64_t* counts, int b, int32_t* offsets, int32_t* pair2claim, int b1, float* has,
@@ -1365,15 +1426,18 @@ extern "C" int gh_adam_step(float* p, const float* g, float* m, float* v, int64_
   return 0;
 }
 
-extern "C" int gh_evd_assemble_fwd(const float* avg, const int32_t* offsets, const float* table, const void* sources,
+extern "C" int gh_evd_assemble_fwd(const float* avg, const int32_t* offsets, const float* table, int table_rows, const void* sources,
                                    int sources_i64, const void* document, int document_i64, int b, int n_max, int xa, int ds,
                                    int r, float* right, float* mask, gh_stream_t stream) {
   GH_REQUIRE(b > 0 && n_max > 0 && xa > 0 && ds >= 0 && r > 0, "evd_assemble_fwd: bad sizes");
   GH_REQUIRE(ds == 0 || (table && sources), "evd_assemble_fwd: article-source width %d needs a table and source ids", ds);
+  GH_REQUIRE(ds == 0 || table_rows > 0, "evd_assemble_fwd: table_rows must give the article-source table's row count");
   hipStream_t s = (hipStream_t)stream;
+  unsigned int* cl = clamp_counter();
+  GH_REQUIRE(cl, "evd_assemble_fwd: cannot allocate the clamp counter");
   const dim3 grid(b * n_max), blk(256);
 #define GH_EA(TS, TD) hipLaunchKernelGGL((evd_assemble_fwd_kernel<TS, TD>), grid, blk, 0, s, avg, offsets, table, (const TS*)sources, \
-                                         (const TD*)document, right, mask, n_max, xa, ds, r)
+                                         (const TD*)document, right, mask, n_max, xa, ds, r, table_rows, cl)
   if (sources_i64 && document_i64) GH_EA(int64_t, int64_t);
   else if (sources_i64) GH_EA(int64_t, int32_t);
   else if (document_i64) GH_EA(int32_t, int64_t);
@@ -1383,9 +1447,10 @@ extern "C" int gh_evd_assemble_fwd(const float* avg, const int32_t* offsets, con
   return 0;
 }
 
-extern "C" int gh_evd_assemble_bwd(const float* g, const int32_t* offsets, const void* sources, int sources_i64, int b, int n_max,
+extern "C" int gh_evd_assemble_bwd(const float* g, const int32_t* offsets, const void* sources, int sources_i64, int table_rows, int b, int n_max,
                                    int xa, int ds, float* d_avg, float* d_table, gh_stream_t stream) {
   GH_REQUIRE(b > 0 && n_max > 0 && xa > 0 && ds >= 0, "evd_assemble_bwd: bad sizes");
+  GH_REQUIRE(ds == 0 || !d_table || table_rows > 0, "evd_assemble_bwd: table_rows must give the article-source table's row count");
   const int n_slots = b * n_max;
   // every workgroup stages the source id of every slot (4 B) + a match bit per slot in LDS: 160 KB hold 38 000 slots,
   // i.e. 1266 claims x 30 evidence slots per call
@@ -1402,10 +1467,10 @@ extern "C" int gh_evd_assemble_bwd(const float* g, const int32_t* offsets, const
   }
   if (sources_i64)
     hipLaunchKernelGGL((evd_assemble_bwd_kernel<int64_t>), dim3(n_slots), dim3(256), lds_bytes, s, g, offsets,
-                       (const int64_t*)sources, d_avg, d_table, n_slots, n_max, xa, ds);
+                       (const int64_t*)sources, d_avg, d_table, n_slots, n_max, xa, ds, table_rows);
   else
     hipLaunchKernelGGL((evd_assemble_bwd_kernel<int32_t>), dim3(n_slots), dim3(256), lds_bytes, s, g, offsets,
-                       (const int32_t*)sources, d_avg, d_table, n_slots, n_max, xa, ds);
+                       (const int32_t*)sources, d_avg, d_table, n_slots, n_max, xa, ds, table_rows);
   GH_LAUNCH_CHECK();
   return 0;
 }

@@ -17,8 +17,11 @@ struct Dims {
   int B, B1, L, R, n, D, H, hw, he, C, cs, as, Xl, Xa, Dre, E, W;
   bool compact;
   int Mr, Mt, M1, Mq;
+  bool bf;            // the two evidence cells run the bf16 storage pipeline (model->storage = 1 and the shapes qualify)
+  bool fuse_scorer;   // the GSL scorer's projection rides in the first cell's last epilogue (whole rows in <= 2 column blocks: h <= 320)
 };
-struct CellBuf { int64_t xp, a, z, rr, rx, hh, out; };
+// out32: the fp32 cell output (== out in fp32 storage; a buffer of its own beside the bf16 twin `out` in bf16 storage)
+struct CellBuf { int64_t xp, a, z, rr, rx, hh, out, out32; };
 struct FwdBuf {
   int64_t offsets, pair2claim, has, lens_eff, rowc, maskf_p;
   CellBuf q, c1, c2;
@@ -45,8 +48,9 @@ static int make_dims(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d) {
   d.cs = Mo->claim_src_dim; d.as = Mo->article_src_dim;
   GH_REQUIRE(d.B > 0 && d.B1 > 0 && d.L > 0 && d.R > 0 && d.n > 0, "get: bad batch sizes b=%d b1=%d l=%d r=%d n_max=%d", d.B, d.B1, d.L, d.R, d.n);
   GH_REQUIRE(d.R <= 256 && d.L <= 256, "get: padded graph sizes above 256 nodes are not supported (l=%d r=%d)", d.L, d.R);
-  GH_REQUIRE(d.D % 4 == 0 && d.H % 4 == 0 && d.D >= 4 && d.D <= d.H && d.H <= 320,
-             "get: the composite path needs float4-shaped widths with d <= h <= 320 (d=%d h=%d); use the per-module entry points", d.D, d.H);
+  GH_REQUIRE(d.D % 4 == 0 && d.H % 4 == 0 && d.D >= 4 && d.D <= d.H && d.H <= 1024,
+             "get: the composite path needs float4-shaped widths with d <= h <= 1024 (d=%d h=%d); use the per-module entry points", d.D, d.H);
+  GH_REQUIRE(Mo->storage == 0 || Mo->storage == 1, "get: model->storage %d not in {0 (fp32), 1 (bf16 storage in the evidence cells)}", Mo->storage);
   GH_REQUIRE(d.hw >= 1 && d.hw <= 8 && d.he >= 1 && d.he <= 8, "get: heads %d / %d not in [1,8]", d.hw, d.he);
   GH_REQUIRE(Ba->k_keep >= 0 && Ba->k_keep <= d.R, "get: k_keep=%d not in [0, r=%d]", Ba->k_keep, d.R);
   GH_REQUIRE(d.C >= 1 && d.cs >= 0 && d.as >= 0 && d.cs % 4 == 0 && d.as % 4 == 0, "get: bad class / source widths (%d, %d, %d)", d.C, d.cs, d.as);
@@ -63,12 +67,24 @@ static int make_dims(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d) {
     d.Mr = d.Mt; d.M1 = d.Mt;
   }
   d.Mq = d.B * d.L;
+  d.fuse_scorer = d.H <= 320;
+  // same rule as the per-module path (get_amd/ops.py bf16_cell_ok): 16-byte bf16 rows and activation-sized launches
+  d.bf = Mo->storage == 1 && d.D % 8 == 0 && d.H % 8 == 0 && d.Mr >= 8192;
+  if (d.bf) {
+    const gh_cell_bf16* cs[2] = {&Mo->cell1_16, &Mo->cell2_16};
+    for (const gh_cell_bf16* c : cs)
+      GH_REQUIRE(c->w_p && c->w_z0 && c->w_z1 && c->w_r0 && c->w_r1 && c->w_h0 && c->w_h1,
+                 "get: storage = 1 needs the bf16 twins of both evidence cells' weights (gh_weights_refresh)");
+    GH_REQUIRE(Mo->embedding16, "get: storage = 1 needs the bf16 copy of the word table (embedding16)");
+  }
   return 0;
 }
 
-static void cell_buf(Bump& b, CellBuf& c, int64_t rows, int H) {
-  c.xp = b.take(rows * H); c.a = b.take(rows * H); c.z = b.take(rows * H); c.rr = b.take(rows * H);
-  c.rx = b.take(rows * H); c.hh = b.take(rows * H); c.out = b.take(rows * H);
+static void cell_buf(Bump& b, CellBuf& c, int64_t rows, int H, bool bf = false) {
+  const int64_t e = bf ? rows * H / 2 : rows * H;      // floats per saved tensor (bf16 storage: two values per float slot)
+  c.xp = b.take(e); c.a = b.take(e); c.z = b.take(e); c.rr = b.take(e);
+  c.rx = b.take(e); c.hh = b.take(e); c.out = b.take(e);
+  c.out32 = bf ? b.take(rows * H) : c.out;
 }
 
 static int layout(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d, FwdBuf& f, BwdBuf& w) {
@@ -90,9 +106,9 @@ static int layout(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d, FwdBu
   }
   cell_buf(b, f.q, d.Mq, d.H);
   f.q_repr = b.take((int64_t)d.B * d.H);
-  cell_buf(b, f.c1, d.M1, d.H);
+  cell_buf(b, f.c1, d.M1, d.H, d.bf);
   f.score_x = b.take(d.M1);
-  cell_buf(b, f.c2, d.Mr, d.H);
+  cell_buf(b, f.c2, d.Mr, d.H, d.bf);
   f.uw = b.take((int64_t)d.B * d.H); f.tw = b.take((int64_t)d.Mr * d.H); f.ew = b.take((int64_t)d.Mr * d.hw);
   f.avg = b.take((int64_t)d.B1 * d.Xa);
   f.new_left = d.cs > 0 ? b.take((int64_t)d.B * d.Xl) : f.q_repr;
@@ -114,9 +130,12 @@ static int layout(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d, FwdBu
   for (int i = 0; i < 5; ++i) w.qs[i] = c.take((int64_t)d.Mq * d.H);
   // one scratch set per evidence cell: the weight-gradient stream still reads the second cell's dzp / drp / dhp / dxp
   // while the main stream already runs the first cell's chain
-  for (int i = 0; i < 5; ++i) w.sc2[i] = c.take((int64_t)d.Mr * d.H);
-  for (int i = 0; i < 5; ++i) w.sc1[i] = c.take((int64_t)d.Mr * d.H);
-  w.dx2 = c.take((int64_t)d.Mr * d.H);
+  // (bf16 storage: the scratch holds bf16; dx2 -- the fp32 gradient between the two cells -- exists only there, the fp32
+  //  pipeline writes it straight into the first cell's gate head)
+  const int64_t se = d.bf ? (int64_t)d.Mr * d.H / 2 : (int64_t)d.Mr * d.H;
+  for (int i = 0; i < 5; ++i) w.sc2[i] = c.take(se);
+  for (int i = 0; i < 5; ++i) w.sc1[i] = c.take(se);
+  w.dx2 = d.bf ? c.take((int64_t)d.Mr * d.H) : w.g2;
   // per-pair partials of the two attention layers' dW2 (reduced on the side stream)
   w.dw2p_e = c.take((int64_t)d.B * d.he * d.H); w.dw2p_w = c.take((int64_t)d.B1 * d.hw * d.H);
   w.total = c.off;
@@ -226,10 +245,12 @@ seg_rows_kernel(const int64_t* __restrict__ counts, int B, int b1, const int32_t
 template <typename TS>
 __global__ void __launch_bounds__(256)
 left_assemble_fwd_kernel(const float* __restrict__ table, const TS* __restrict__ src, const float* __restrict__ q_repr,
-                         const float* __restrict__ has, float* __restrict__ new_left, int cs, int H, int rows) {
+                         const float* __restrict__ has, float* __restrict__ new_left, int cs, int H, int rows,
+                         unsigned int* __restrict__ clamped) {
   const int b = blockIdx.x;
   const float hb = has[b];
   const long long sb = (long long)src[b];
+  if ((sb < 0 || sb >= rows) && threadIdx.x == 0) atomicAdd(clamped + 1, 1u);      // nn.Embedding would raise (:113); counted, gh_clamp_events
   const float* tp = table + (size_t)(sb < 0 ? 0 : (sb >= rows ? rows - 1 : sb)) * cs;
   float* o = new_left + (size_t)b * (cs + H);
   for (int i = threadIdx.x; i < cs; i += blockDim.x) o[i] = tp[i] * hb;
@@ -257,7 +278,7 @@ left_assemble_bwd_kernel(const float* __restrict__ d_new_left, const TS* __restr
 // reduced in a fixed order.
 __global__ void __launch_bounds__(256)
 cross_entropy_kernel(const float* __restrict__ phi, const int64_t* __restrict__ labels, int B, int C, float* __restrict__ loss,
-                     float* __restrict__ dphi) {
+                     float* __restrict__ dphi, unsigned int* __restrict__ clamped) {
   __shared__ float part[256];
   float acc = 0.f;
   const float invb = 1.f / (float)B;
@@ -269,7 +290,8 @@ cross_entropy_kernel(const float* __restrict__ phi, const int64_t* __restrict__ 
     for (int c = 0; c < C; ++c) se += expf(p[c] - mx);
     const float lse = mx + logf(se);
     const long long yl = labels[b];
-    const int y = yl < 0 ? 0 : (yl >= C ? C - 1 : (int)yl);      // (no ignore_index; out-of-range labels are clamped)
+    const int y = yl < 0 ? 0 : (yl >= C ? C - 1 : (int)yl);      // (no ignore_index; out-of-range labels are clamped ...
+    if (yl < 0 || yl >= C) atomicAdd(clamped, 1u);               //  ... and counted: nn.CrossEntropyLoss raises there, gh_clamp_events)
     acc += lse - p[y];
     for (int c = 0; c < C; ++c) dphi[(size_t)b * C + c] = (expf(p[c] - lse) - (c == y ? 1.f : 0.f)) * invb;
   }
@@ -306,6 +328,7 @@ extern "C" int gh_get_plan_buffers(const gh_get_model* Mo, const gh_get_batch* B
 extern "C" int gh_get_struct_sizes(int64_t* out) {
   GH_REQUIRE(out, "get_struct_sizes: NULL");
   out[0] = sizeof(gh_get_model); out[1] = sizeof(gh_get_batch); out[2] = sizeof(gh_get_plan); out[3] = sizeof(gh_cell_params);
+  out[4] = sizeof(gh_cell_bf16);
   return 0;
 }
 
@@ -314,19 +337,38 @@ extern "C" int gh_get_struct_sizes(int64_t* out) {
 static inline const int32_t* I32(const float* A, int64_t off) { return reinterpret_cast<const int32_t*>(A + off); }
 static inline int32_t* I32(float* A, int64_t off) { return reinterpret_cast<int32_t*>(A + off); }
 
-static int cell_fwd(const gh_cell_params& c, const CellBuf& cb, float* A, const uint64_t* bits, const float* dinv, const float* vals,
-                    const uint64_t* keep, const int32_t* goff, int m_real, int m_rows, const float* x, const int32_t* ids, int n, int r,
-                    int din, int h, float drop_p, uint32_t seed, const float* score_w, float* score_x, float sdrop, uint32_t sseed,
-                    hipStream_t s, int pad_out_dead = 0) {
+// c16 != NULL: bf16 storage pipeline -- x (or the table behind ids) and the saved tensors hold bf16, the weights come from the twins
+static int cell_fwd(const gh_cell_params& c, const gh_cell_bf16* c16, const CellBuf& cb, float* A, const uint64_t* bits, const float* dinv,
+                    const float* vals, const uint64_t* keep, const int32_t* goff, int m_real, int m_rows, const float* x, const int32_t* ids,
+                    int n, int r, int din, int h, float drop_p, uint32_t seed, const float* score_w, float* score_x, float sdrop,
+                    uint32_t sseed, hipStream_t s, int pad_out_dead = 0) {
+  typedef const float* cf;
+  if (c16)
+    return cell_fwd_impl(1, A + cb.out32, bits, dinv, vals, keep, goff, m_real, m_rows, x, ids, n, r, din, h, (cf)c16->w_p, (cf)c16->w_z0,
+                         (cf)c16->w_z1, (cf)c16->w_r0, (cf)c16->w_r1, (cf)c16->w_h0, (cf)c16->w_h1, c.b_z0, c.b_z1, c.b_r0, c.b_r1, c.b_h0,
+                         c.b_h1, A + cb.xp, A + cb.a, A + cb.z, A + cb.rr, A + cb.rx, A + cb.hh, A + cb.out, drop_p, seed, score_w, score_x,
+                         sdrop, sseed, (void*)s, 0);
   return cell_fwd_impl(0, nullptr, bits, dinv, vals, keep, goff, m_real, m_rows, x, ids, n, r, din, h, c.w_p, c.w_z0, c.w_z1, c.w_r0,
                        c.w_r1, c.w_h0, c.w_h1, c.b_z0, c.b_z1, c.b_r0, c.b_r1, c.b_h0, c.b_h1, A + cb.xp, A + cb.a, A + cb.z,
                        A + cb.rr, A + cb.rx, A + cb.hh, A + cb.out, drop_p, seed, score_w, score_x, sdrop, sseed, (void*)s, pad_out_dead);
 }
-static int cell_bwd(const gh_cell_params& c, const CellBuf& cb, const float* A, const uint64_t* bits, const float* dinv,
+static int cell_bwd(const gh_cell_params& c, const gh_cell_bf16* c16, const CellBuf& cb, const float* A, const uint64_t* bits, const float* dinv,
                     const float* vals, const uint64_t* keep, const int32_t* goff, int m_real, const float* x, const int32_t* ids, int n,
                     int r, int din, int h, const float* g, float* W, const int64_t* sc, float* dx, float drop_p, uint32_t seed,
                     hipStream_t s, int pre_done = 0, const GateFuse* next = nullptr) {
-  GH_REQUIRE(c.wt_p && c.dw_p && c.db_z0 && c.db_z1, "get_backward: a cell's transposes / gradient outputs are missing");
+  GH_REQUIRE(c.dw_p && c.db_z0 && c.db_z1, "get_backward: a cell's gradient outputs are missing");
+  if (c16) {
+    typedef const float* cf;
+    GH_REQUIRE(c16->wt_p && c16->wt_z0 && c16->wt_z1 && c16->wt_r0 && c16->wt_r1 && c16->wt_h0 && c16->wt_h1,
+               "get_backward: storage = 1 needs the bf16 twins of the cells' transposed weights (gh_weights_refresh)");
+    GH_REQUIRE(!pre_done && !next, "get_backward: internal -- the fused gate head exists in the fp32 pipeline only");
+    return cell_bwd_impl(1, bits, dinv, vals, keep, goff, m_real, x, ids, n, r, din, h, (cf)c16->wt_p, (cf)c16->wt_z0, (cf)c16->wt_z1,
+                         (cf)c16->wt_r0, (cf)c16->wt_r1, (cf)c16->wt_h0, (cf)c16->wt_h1, A + cb.xp, A + cb.a, A + cb.z, A + cb.rr,
+                         A + cb.rx, A + cb.hh, g, W + sc[0], W + sc[1], W + sc[2], W + sc[3], W + sc[4], dx, c.dw_p, c.dw_z0, c.dw_z1,
+                         c.dw_r0, c.dw_r1, c.dw_h0, c.dw_h1, c.db_z0, c.db_r0, c.db_h0, c.db_z1, c.db_r1, c.db_h1, drop_p, seed, (void*)s,
+                         nullptr, nullptr, nullptr, 0, nullptr);
+  }
+  GH_REQUIRE(c.wt_p, "get_backward: a cell's transposes are missing");
   return cell_bwd_impl(0, bits, dinv, vals, keep, goff, m_real, x, ids, n, r, din, h, c.wt_p, c.wt_z0, c.wt_z1, c.wt_r0, c.wt_r1,
                        c.wt_h0, c.wt_h1, A + cb.xp, A + cb.a, A + cb.z, A + cb.rr, A + cb.rx, A + cb.hh, g, W + sc[0], W + sc[1],
                        W + sc[2], W + sc[3], W + sc[4], dx, c.dw_p, c.dw_z0, c.dw_z1, c.dw_r0, c.dw_r1, c.dw_h0, c.dw_h1, c.db_z0,
@@ -347,6 +389,7 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
   GH_REQUIRE((d.cs == 0) == (Mo->claim_src_table == nullptr) && (d.as == 0) == (Mo->article_src_table == nullptr),
              "get_forward: source tables and their widths must come together");
   GH_REQUIRE(d.cs == 0 || Mo->claim_src_rows > 0, "get_forward: claim_src_rows must give the claim-source table's row count");
+  GH_REQUIRE(d.as == 0 || Mo->article_src_rows > 0, "get_forward: article_src_rows must give the article-source table's row count");
   GH_REQUIRE(Ba->drop_claim >= 0.f && Ba->drop_claim < 1.f && Ba->drop_gnn >= 0.f && Ba->drop_gnn < 1.f, "get_forward: dropout p not in [0,1)");
   hipStream_t s = (hipStream_t)stream, ss = side_stream ? (hipStream_t)side_stream : s;
   DevEvents ev;
@@ -380,16 +423,18 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
   }
   // ---- claim branch on the side stream (graph_based_semantic_structure.py:144-155): cell -> masked mean (x has)
   GH_TRY(stream_after(ss, s, ev.ev[0]));
-  GH_TRY(cell_fwd(Mo->claim, f.q, A, Ba->q_bits, Ba->q_dinv, Ba->q_vals, nullptr, nullptr, 0, 0, Mo->embedding, Ba->q_ids, d.B, d.L, d.D, H,
-                  Ba->drop_claim, Ba->seed_claim, nullptr, nullptr, 0.f, 0, ss));
+  GH_TRY(cell_fwd(Mo->claim, nullptr, f.q, A, Ba->q_bits, Ba->q_dinv, Ba->q_vals, nullptr, nullptr, 0, 0, Mo->embedding, Ba->q_ids, d.B, d.L,
+                  d.D, H, Ba->drop_claim, Ba->seed_claim, nullptr, nullptr, 0.f, 0, ss));
   GH_TRY(gh_masked_mean_fwd(A + f.q.out, Ba->q_ids, A + f.lens_eff, A + f.q_repr, d.B, d.L, H, (void*)ss));
   if (d.cs > 0) {
+    unsigned int* cl = clamp_counter();
+    GH_REQUIRE(cl, "get_forward: cannot allocate the clamp counter");
     if (Ba->query_sources_i64)
       hipLaunchKernelGGL(left_assemble_fwd_kernel<int64_t>, dim3(d.B), dim3(256), 0, ss, Mo->claim_src_table, (const int64_t*)Ba->query_sources,
-                         A + f.q_repr, A + f.has, A + f.new_left, d.cs, H, Mo->claim_src_rows);
+                         A + f.q_repr, A + f.has, A + f.new_left, d.cs, H, Mo->claim_src_rows, cl);
     else
       hipLaunchKernelGGL(left_assemble_fwd_kernel<int32_t>, dim3(d.B), dim3(256), 0, ss, Mo->claim_src_table, (const int32_t*)Ba->query_sources,
-                         A + f.q_repr, A + f.has, A + f.new_left, d.cs, H, Mo->claim_src_rows);
+                         A + f.q_repr, A + f.has, A + f.new_left, d.cs, H, Mo->claim_src_rows, cl);
     GH_LAUNCH_CHECK();
   }
   // the left projections of both attention layers depend on the claim branch only (two_branches_attention.py:137-140:
@@ -402,20 +447,30 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
   // ---- evidence branch (:107; wrapper.py:165-172): cell -> scorer + top-k -> cell on the refined graph
   const int32_t* goff = d.compact ? Ba->goff : nullptr;
   const int32_t* ids1 = d.compact ? Ba->cids : Ba->d_ids;
-  GH_TRY(cell_fwd(Mo->cell1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, d.M1, Mo->embedding, ids1, d.B1, d.R, d.D, H,
-                  Ba->drop_gnn, Ba->seed_cell1, Mo->scorer_w, A + f.score_x, Ba->drop_gnn, Ba->seed_scorer, s, 1));
+  const gh_cell_bf16* c16_1 = d.bf ? &Mo->cell1_16 : nullptr;
+  const gh_cell_bf16* c16_2 = d.bf ? &Mo->cell2_16 : nullptr;
+  const float* table1 = d.bf ? (const float*)Mo->embedding16 : Mo->embedding;
   uint64_t* keep = reinterpret_cast<uint64_t*>(O + f.keep);
-  GH_TRY(gh_scorer_gsl(Ba->d_bits, Ba->d_dinv, Ba->d_vals, goff, (d.compact && Ba->collapsed) ? 1 : 0, nullptr, A + f.score_x, Mo->scorer_w,
-                       Mo->scorer_gate, d.B1, d.R, H, Ba->k_keep, O + f.score, keep, 0.f, 0, (void*)s));
-  GH_TRY(cell_fwd(Mo->cell2, f.c2, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, keep, goff, d.Mr, d.Mr, A + f.c1.out, nullptr, d.B1, d.R, H, H,
+  if (d.fuse_scorer) {      // the scorer's 300 -> 1 projection of the cell output rides in the cell's last epilogue (score_x)
+    GH_TRY(cell_fwd(Mo->cell1, c16_1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, d.M1, table1, ids1, d.B1, d.R, d.D, H,
+                    Ba->drop_gnn, Ba->seed_cell1, Mo->scorer_w, A + f.score_x, Ba->drop_gnn, Ba->seed_scorer, s, 1));
+    GH_TRY(gh_scorer_gsl(Ba->d_bits, Ba->d_dinv, Ba->d_vals, goff, (d.compact && Ba->collapsed) ? 1 : 0, nullptr, A + f.score_x, Mo->scorer_w,
+                         Mo->scorer_gate, d.B1, d.R, H, Ba->k_keep, O + f.score, keep, 0.f, 0, (void*)s));
+  } else {                  // wide hidden layer (h = 768): a row spans more column blocks than an epilogue can reduce -- the scorer kernel projects
+    GH_TRY(cell_fwd(Mo->cell1, c16_1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, d.M1, table1, ids1, d.B1, d.R, d.D, H,
+                    Ba->drop_gnn, Ba->seed_cell1, nullptr, nullptr, 0.f, 0, s, 0));
+    GH_TRY(gh_scorer_gsl(Ba->d_bits, Ba->d_dinv, Ba->d_vals, goff, (d.compact && Ba->collapsed) ? 1 : 0, A + f.c1.out32, nullptr, Mo->scorer_w,
+                         Mo->scorer_gate, d.B1, d.R, H, Ba->k_keep, O + f.score, keep, Ba->drop_gnn, Ba->seed_scorer, (void*)s));
+  }
+  GH_TRY(cell_fwd(Mo->cell2, c16_2, f.c2, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, keep, goff, d.Mr, d.Mr, A + f.c1.out, nullptr, d.B1, d.R, H, H,
                   Ba->drop_gnn, Ba->seed_cell2, nullptr, nullptr, 0.f, 0, s));
   GH_TRY(stream_after(s, ss, ev.ev[1]));
   // ---- word-level attention (:173-193): the left input is the claim vector -> ONE u row per claim
-  GH_TRY(att_fwd_impl(A + f.q_repr, d.B, I32(A, f.rowc), A + f.c2.out, d.compact ? Ba->maskf : A + f.maskf_p, goff,
+  GH_TRY(att_fwd_impl(A + f.q_repr, d.B, I32(A, f.rowc), A + f.c2.out32, d.compact ? Ba->maskf : A + f.maskf_p, goff,
                       d.compact ? Ba->rowg : nullptr, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1, Mo->att_word.w2, A + f.uw, A + f.tw,
                       A + f.ew, O + f.ww, A + f.avg, s, 2));
   // ---- evidence-level assembly + attention (:157-171, :195-221)
-  GH_TRY(gh_evd_assemble_fwd(A + f.avg, I32(A, f.offsets), Mo->article_src_table, d.as > 0 ? Ba->doc_sources : nullptr, Ba->doc_sources_i64,
+  GH_TRY(gh_evd_assemble_fwd(A + f.avg, I32(A, f.offsets), Mo->article_src_table, Mo->article_src_rows, d.as > 0 ? Ba->doc_sources : nullptr, Ba->doc_sources_i64,
                              Ba->document, Ba->document_i64, d.B, d.n, d.Xa, d.as, d.R, A + f.right_e, A + f.mask_e, (void*)s));
   GH_TRY(att_fwd_impl(A + f.new_left, d.B, nullptr, A + f.right_e, A + f.mask_e, nullptr, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he,
                       Mo->att_evd.w1, Mo->att_evd.w2, A + f.ue, A + f.te, A + f.ee, O + f.we, A + f.att_e, s, 2));
@@ -449,6 +504,12 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
   // gate heads fused into the producing GEMMs' epilogues: cell scratch order is {dhp, dzp, drp, dxp, da}
   const GateFuse gf2 = {A + f.c2.z, A + f.c2.hh, A + f.c2.xp, Wb + w.sc2[0], Wb + w.sc2[1], Wb + w.sc2[3]};
   const GateFuse gf1 = {A + f.c1.z, A + f.c1.hh, A + f.c1.xp, Wb + w.sc1[0], Wb + w.sc1[1], Wb + w.sc1[3]};
+  // bf16 storage: the gate heads' scratch holds bf16, which the fused epilogue does not write -- the gradient between the
+  // layers stays an fp32 tensor (g2, dx2) and every cell runs its own gate_bwd_pre pass
+  const bool fuse_gate = !d.bf;
+  const gh_cell_bf16* c16_1 = d.bf ? &Mo->cell1_16 : nullptr;
+  const gh_cell_bf16* c16_2 = d.bf ? &Mo->cell2_16 : nullptr;
+  const float* table1 = d.bf ? (const float*)Mo->embedding16 : Mo->embedding;
   if (phase != 2) {
     // ---- head
     GH_TRY(gh_linear_bwd(A + f.y0, Mo->out1_wt, Mo->out1_w, g_phi, d.B, H, d.C, Wb + w.d_y0, Mo->d_out1_w, Mo->d_out1_b, (void*)s));
@@ -480,33 +541,41 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
     // (always: rows of claims with more than n_max evidences are never written by the assembly's backward.  `counts_fit` used to
     //  skip these 3 us on the caller's word; a wrong promise fed uninitialised memory into the gradients -- ADVICE r3)
     GH_CHECK_HIP(hipMemsetAsync(Wb + w.d_avg, 0, sizeof(float) * (size_t)d.B1 * d.Xa, s));
-    GH_TRY(gh_evd_assemble_bwd(Wb + w.dright_e, I32(A, f.offsets), d.as > 0 ? Ba->doc_sources : nullptr, Ba->doc_sources_i64, d.B, d.n, d.Xa,
+    GH_TRY(gh_evd_assemble_bwd(Wb + w.dright_e, I32(A, f.offsets), d.as > 0 ? Ba->doc_sources : nullptr, Ba->doc_sources_i64, Mo->article_src_rows, d.B, d.n, d.Xa,
                                d.as, Wb + w.d_avg, d.as > 0 ? Mo->d_article_src_table : nullptr, (void*)s));
     // ---- word-level attention: per-pair du summed per claim; d(claim vector) accumulates on top of the head / evidence part.
     //      Its dright GEMM produces the gradient of the second evidence cell's output and nothing else reads it: the GEMM's
     //      epilogue applies that cell's gate head (gf2); likewise the second cell's dX GEMM feeds the first cell's (gf1).
-    GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
+    GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out32, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
                         O + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, Wb + w.g2, nullptr,
-                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, s, d.compact ? Ba->rowg : nullptr, Wb + w.dw_w, &gf2, 1,
-                        Wb + w.dw2p_w));
+                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, s, d.compact ? Ba->rowg : nullptr, Wb + w.dw_w,
+                        fuse_gate ? &gf2 : nullptr, 1, Wb + w.dw2p_w));
     // ---- side stream: linear1's weight gradient of the word attention, then the claim branch's backward -- underneath
     //      the evidence cells' chain on the main stream
     GH_TRY(stream_after(ss, s, ev.ev[4]));
-    GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
+    GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out32, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
                         O + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, nullptr, Mo->att_word.dw1,
                         Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, ss, nullptr, nullptr, nullptr, 1, Wb + w.dw2p_w));
     GH_TRY(gh_masked_mean_bwd(Wb + w.d_q, Ba->q_ids, A + f.lens_eff, Wb + w.d_qhid, d.B, d.L, H, (void*)ss));
-    GH_TRY(cell_bwd(Mo->claim, f.q, A, Ba->q_bits, Ba->q_dinv, Ba->q_vals, nullptr, nullptr, 0, Mo->embedding, Ba->q_ids, d.B, d.L, d.D, H,
+    GH_TRY(cell_bwd(Mo->claim, nullptr, f.q, A, Ba->q_bits, Ba->q_dinv, Ba->q_vals, nullptr, nullptr, 0, Mo->embedding, Ba->q_ids, d.B, d.L, d.D, H,
                     Wb + w.d_qhid, Wb, w.qs, nullptr, Ba->drop_claim, Ba->seed_claim, ss));
     // ---- second evidence cell.  (cell_bwd_impl can put the weight-gradient GEMMs on the side stream -- measured on the
     //      bench step: 6.31 -> 6.23 ms, two MFMA-bound streams mostly slow each other down, while every kernel's wall time
     //      and with it the per-kernel roofline figures inflate by 20-30 %.  Not used: one stream, honest kernel times.)
-    GH_TRY(cell_bwd(Mo->cell2, f.c2, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, keep, goff, d.Mr, A + f.c1.out, nullptr, d.B1, d.R, H, H,
-                    Wb + w.g2, Wb, w.sc2, nullptr, Ba->drop_gnn, Ba->seed_cell2, s, 1, &gf1));
+    if (fuse_gate)
+      GH_TRY(cell_bwd(Mo->cell2, nullptr, f.c2, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, keep, goff, d.Mr, A + f.c1.out, nullptr, d.B1, d.R, H, H,
+                      Wb + w.g2, Wb, w.sc2, nullptr, Ba->drop_gnn, Ba->seed_cell2, s, 1, &gf1));
+    else
+      GH_TRY(cell_bwd(Mo->cell2, c16_2, f.c2, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, keep, goff, d.Mr, A + f.c1.out, nullptr, d.B1, d.R, H, H,
+                      Wb + w.g2, Wb, w.sc2, Wb + w.dx2, Ba->drop_gnn, Ba->seed_cell2, s, 0, nullptr));
   }
   if (phase != 1) {
-    GH_TRY(cell_bwd(Mo->cell1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, Mo->embedding, ids1, d.B1, d.R, d.D, H,
-                    nullptr, Wb, w.sc1, nullptr, Ba->drop_gnn, Ba->seed_cell1, s, 1, nullptr));
+    if (fuse_gate)
+      GH_TRY(cell_bwd(Mo->cell1, nullptr, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, Mo->embedding, ids1, d.B1, d.R, d.D, H,
+                      nullptr, Wb, w.sc1, nullptr, Ba->drop_gnn, Ba->seed_cell1, s, 1, nullptr));
+    else
+      GH_TRY(cell_bwd(Mo->cell1, c16_1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, table1, ids1, d.B1, d.R, d.D, H,
+                      Wb + w.dx2, Wb, w.sc1, nullptr, Ba->drop_gnn, Ba->seed_cell1, s, 0, nullptr));
     GH_TRY(stream_after(s, ss, ev.ev[5]));
   }
   return 0;
@@ -514,7 +583,9 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
 
 extern "C" int gh_cross_entropy(const float* phi, const int64_t* labels, int b, int c, float* loss, float* dphi, gh_stream_t stream) {
   GH_REQUIRE(b > 0 && c > 0 && phi && labels && loss && dphi, "cross_entropy: bad arguments");
-  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, phi, labels, b, c, loss, dphi);
+  unsigned int* cl = clamp_counter();
+  GH_REQUIRE(cl, "cross_entropy: cannot allocate the clamp counter");
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, phi, labels, b, c, loss, dphi, cl);
   GH_LAUNCH_CHECK();
   return 0;
 }

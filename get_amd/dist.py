@@ -102,6 +102,11 @@ class LibComm:
             dev = torch.device("cuda", torch.cuda.current_device())
         self.device, self.rank, self.world = dev, int(rank), int(world)
         self._comm_stream = None       # asynchronous collectives get a stream of their own (all_reduce_async)
+        # One communicator serialises its collectives: a collective enqueued on the caller's stream while an asynchronous one
+        # is still pending on the communicator's stream would let two streams drive the same RCCL communicator concurrently
+        # (possible deadlock / cross-rank misordering).  Every enqueue therefore first orders its stream behind the last
+        # asynchronous collective (_pending): FlatTrainer's wait()-before-next-collective discipline is no longer load-bearing.
+        self._pending = None
         buf = ctypes.create_string_buffer(bytes(id_bytes), 128)
         out = ctypes.c_void_p()
         with torch.cuda.device(dev):
@@ -146,7 +151,13 @@ class LibComm:
         from . import _lib
         self._check(t)
         with torch.cuda.device(self.device):
+            self._order_behind_pending(torch.cuda.current_stream(self.device))
             _lib.call("gh_flat_allreduce", self._comm, t.data_ptr(), t.numel(), _lib.stream())
+
+    def _order_behind_pending(self, stream):
+        if self._pending is not None:
+            stream.wait_event(self._pending)
+            self._pending = None
 
     def all_reduce_async(self, t: torch.Tensor) -> "_StreamWork":
         """In-place sum over the ranks on the communicator's OWN stream, ordered behind everything the current stream has
@@ -162,15 +173,18 @@ class LibComm:
             cs = self._comm_stream
             cs.wait_stream(torch.cuda.current_stream(self.device))
             t.record_stream(cs)
+            # (two asynchronous collectives follow each other on the communicator's stream: ordered by the stream itself)
             _lib.call("gh_flat_allreduce", self._comm, t.data_ptr(), t.numel(), cs.cuda_stream)
             ev = torch.cuda.Event()
             ev.record(cs)
+            self._pending = ev
         return _StreamWork(ev)
 
     def broadcast(self, t: torch.Tensor, root: int = 0):
         from . import _lib
         self._check(t)
         with torch.cuda.device(self.device):
+            self._order_behind_pending(torch.cuda.current_stream(self.device))
             _lib.call("gh_flat_broadcast", self._comm, t.data_ptr(), t.numel(), int(root), _lib.stream())
 
     def close(self):

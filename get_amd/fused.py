@@ -1,8 +1,8 @@
 """The whole GET forward / backward as ONE library call each (include/get_hip.h: gh_get_forward / gh_get_backward).
 
-``Graph_basedSemantiStructure.forward`` routes through :func:`forward` whenever the model/batch qualify (fp32 mode,
-frozen word table, float4-shaped widths with d <= h <= 320 -- every shape BASELINE.json's fp32 configs name); anything
-else keeps the module-by-module path of get_amd/modules.py + get_amd/ops.py, which stays the API for callers that use
+``Graph_basedSemantiStructure.forward`` routes through :func:`forward` whenever the model/batch qualify (frozen word
+table, float4-shaped widths with d <= h <= 1024 -- every shape BASELINE.json names, in every arithmetic mode incl. the
+bf16 storage pipeline of configs[4]); anything else keeps the module-by-module path of get_amd/modules.py + get_amd/ops.py, which stays the API for callers that use
 the reference's modules one by one.  Same kernels underneath; what disappears is ~120 Python -> ctypes -> autograd round
 trips per training step (~2.2 ms of host time, the bound of the realistic-evidence-count regime) and the at::native
 glue between them.
@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -31,6 +32,10 @@ class CellParams(ctypes.Structure):
                 [("d" + n, _P) for n in _CELL_W] + [("d" + n, _P) for n in _CELL_B])
 
 
+class CellBf16(ctypes.Structure):
+    _fields_ = [(n, _P) for n in _CELL_W] + [("wt" + n[1:], _P) for n in _CELL_W]
+
+
 class AttParams(ctypes.Structure):
     _fields_ = [("w1", _P), ("w2", _P), ("w1t", _P), ("dw1", _P), ("dw2", _P)]
 
@@ -46,7 +51,8 @@ class GetModel(ctypes.Structure):
                 ("d_claim_src_table", _P), ("d_article_src_table", _P),
                 ("out0_w", _P), ("out0_b", _P), ("out0_wt", _P),
                 ("out1_w", _P), ("out1_b", _P), ("out1_wt", _P),
-                ("d_out0_w", _P), ("d_out0_b", _P), ("d_out1_w", _P), ("d_out1_b", _P)]
+                ("d_out0_w", _P), ("d_out0_b", _P), ("d_out1_w", _P), ("d_out1_b", _P),
+                ("storage", _I), ("embedding16", _P), ("cell1_16", CellBf16), ("cell2_16", CellBf16)]
 
 
 class GetBatch(ctypes.Structure):
@@ -85,7 +91,7 @@ class Binding:
     tuple comparison of the data pointers)."""
 
     def __init__(self, model):
-        self.model = model
+        self._model = weakref.ref(model)      # (the model owns the binding: no reference cycle around the arena pool's buffers)
         gw = model.ggnn_with_gsl
         self.cells = [model.ggnn4claim_1, gw.feat_prop1, gw.feat_prop2]
         self.params = []          # live parameters in a fixed order (gradient outputs follow the same order)
@@ -108,6 +114,11 @@ class Binding:
         self._sig = {False: None, True: None}
         self._mat_ids = [id(m) for m in self.mats]
         self._checked = False
+        self.pool = _ArenaPool()
+
+    @property
+    def model(self):
+        return self._model()
 
     def eligible(self) -> bool:
         m = self.model
@@ -115,7 +126,7 @@ class Binding:
         h = m.hidden_size
         cs = m.claim_emb_size if m.use_claim_source else 0
         as_ = m.article_emb_size if m.use_article_source else 0
-        return (not m.embedding.weight.requires_grad and d % 4 == 0 and h % 4 == 0 and 4 <= d <= h <= 320 and
+        return (not m.embedding.weight.requires_grad and d % 4 == 0 and h % 4 == 0 and 4 <= d <= h <= 1024 and
                 1 <= m.num_att_heads_for_words <= 8 and 1 <= m.num_att_heads_for_evds <= 8 and cs % 4 == 0 and as_ % 4 == 0 and
                 m.ggnn4claim_1.proj.linear.weight.shape == (h, d) and m.out[1].weight.shape[1] == h and
                 all(p.dtype == torch.float32 and p.is_contiguous() for p in self.params))
@@ -125,9 +136,10 @@ class Binding:
         parameters' .grad (FlatTrainer bucket); otherwise a zeroed flat buffer receives them and `views` maps id(parameter)
         to its slice (returned to autograd)."""
         if not self._checked:          # the ctypes mirrors must have the C structs' sizes
-            sz = (ctypes.c_int64 * 4)()
+            sz = (ctypes.c_int64 * 5)()
             _lib.call("gh_get_struct_sizes", ctypes.cast(sz, ctypes.c_void_p))
-            mine = (ctypes.sizeof(GetModel), ctypes.sizeof(GetBatch), ctypes.sizeof(GetPlan), ctypes.sizeof(CellParams))
+            mine = (ctypes.sizeof(GetModel), ctypes.sizeof(GetBatch), ctypes.sizeof(GetPlan), ctypes.sizeof(CellParams),
+                    ctypes.sizeof(CellBf16))
             if tuple(sz) != mine:
                 raise RuntimeError(f"get_amd: struct layout mismatch between fused.py {mine} and libget_hip.so {tuple(sz)}")
             self._checked = True
@@ -135,7 +147,16 @@ class Binding:
         direct = need_grads and all(ops._direct(p) for p in self.params) and all((not t.requires_grad) or ops._direct(t) for t in self.tables)
         wts = [ops.transposed(w) for w in self.mats] if need_grads else None
         gscorer = m.ggnn_with_gsl._gate12()
+        # bf16 storage mode (BASELINE configs[4]): bf16 twins of the two evidence cells' matrices (persistent buffers, refreshed
+        # with the transposes after the optimiser step) and of the frozen word table
+        bf = _lib.gemm_mode() == "bf16" and S_bf16_shapes(m)
+        twins = emb16 = None
+        if bf:
+            twins = [[ops.bf16_twins(w) for w in _cell_tensors(c)[0]] for c in self.cells[1:]]
+            emb = m.embedding.weight
+            emb16 = ops.derived("table_bf16", (emb,), lambda: emb.detach().to(torch.bfloat16), frozen=not emb.requires_grad)
         sig = (tuple(p.data_ptr() for p in self.params), tuple(t.data_ptr() for t in self.tables),
+               (emb16.data_ptr(), tuple(t.data_ptr() for cell in twins for pair in cell for t in pair)) if bf else None,
                tuple(t.data_ptr() for t in wts) if wts else None,
                tuple(p.grad.data_ptr() for p in self.params) if direct else None,
                tuple((t.grad.data_ptr() if t.requires_grad else 0) for t in self.tables) if direct else None,
@@ -158,6 +179,13 @@ class Binding:
         S.claim_src_rows = m.claim_source_embs.weight.shape[0] if m.use_claim_source else 0
         S.article_src_rows = m.article_source_embs.weight.shape[0] if m.use_article_source else 0
         S.embedding = m.embedding.weight.data_ptr()
+        S.storage = 1 if bf else 0
+        if bf:
+            S.embedding16 = emb16.data_ptr()
+            for c16, cell in zip((S.cell1_16, S.cell2_16), twins):
+                for name, (w16, wt16) in zip(_CELL_W, cell):
+                    setattr(c16, name, w16.data_ptr())
+                    setattr(c16, "wt" + name[1:], wt16.data_ptr())
         gptr = None
         if need_grads:
             gl = [p.grad for p in self.params] if direct else [views[id(p)] for p in self.params]
@@ -179,7 +207,7 @@ class Binding:
                 k += 1
         S.scorer_w = m.ggnn_with_gsl.word_scorer1.proj.linear.weight.data_ptr()
         S.scorer_gate = gscorer.data_ptr()
-        self._keep_alive = (gscorer, wts)
+        self._keep_alive = (gscorer, wts, twins, emb16)
         for a_, att in zip((S.att_word, S.att_evd), (m.self_att_word, m.self_att_evd)):
             a_.w1, a_.w2 = att.linear1.weight.data_ptr(), att.linear2.weight.data_ptr()
             if need_grads:
@@ -203,6 +231,12 @@ class Binding:
         if gbuf is None:
             self.struct[need_grads], self._sig[need_grads] = S, sig
         return S, direct, gbuf, views
+
+
+def S_bf16_shapes(m) -> bool:
+    """Widths the bf16 storage cells take (16-byte bf16 rows); the row-count half of the rule (>= 8192 real node rows) is
+    checked per batch inside the library (model_ops.hip make_dims), as ops.bf16_cell_ok does on the per-module path."""
+    return m.embedding.weight.shape[1] % 8 == 0 and m.hidden_size % 8 == 0
 
 
 def _binding(model) -> Binding:
@@ -308,6 +342,51 @@ def _arena_floats(n: int) -> int:
     return (n + g - 1) // g * g
 
 
+class _ArenaPool:
+    """Persistent activation / scratch arenas of one model (per device), for forwards that will be followed by a backward.
+    A training step used to allocate its two multi-GB arenas from torch's caching allocator in size classes; batches whose
+    node counts fall into different classes made the allocator hand blocks back to the driver and ask for new ones for many
+    steps (the B = 256 strong-scaling leg of round 4 needed 40 steps to settle, 90 -> 42 ms per step).  take() hands out the
+    smallest free buffer that holds the request and is at most SLACK times larger; otherwise it allocates in the coarse size
+    class and drops the free buffers the new one supersedes (those less than SLACK times smaller), so the pool converges to
+    one buffer per kind (forward arena, backward scratch) sized for the largest batch seen.  A buffer comes back when its
+    backward has been issued: gh_get_backward joins its side stream into the caller's stream, so the next forward's writes
+    are ordered behind the backward's reads.  A forward whose graph is dropped without a backward never returns its buffer
+    (the tensor dies with the graph); no-grad forwards do not use the pool at all (evaluation keeps nothing resident)."""
+    MAX_FREE = 4
+    SLACK = 1.30
+
+    def __init__(self):
+        self.free = {}          # device index -> list of tensors
+
+    def _list(self, dev):
+        return self.free.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
+
+    def take(self, n: int, dev) -> torch.Tensor:
+        lst = self._list(dev)
+        best = None
+        for i, t in enumerate(lst):
+            if n <= t.numel() <= max(n * self.SLACK, n + (1 << 22)) and (best is None or t.numel() < lst[best].numel()):
+                best = i
+        if best is not None:
+            return lst.pop(best)
+        size = _arena_floats(n)
+        lst[:] = [t for t in lst if not (size / self.SLACK <= t.numel() < size)]
+        return torch.empty(size, device=dev, dtype=torch.float32)
+
+    def give(self, t: torch.Tensor):
+        lst = self._list(t.device)
+        lst.append(t)
+        while len(lst) > self.MAX_FREE:
+            lst.pop(min(range(len(lst)), key=lambda i: lst[i].numel()))
+
+    def clear(self):
+        self.free.clear()
+
+
+POOL_ARENAS = os.environ.get("GET_AMD_ARENA_POOL", "1") != "0"
+
+
 class _GetFused(torch.autograd.Function):
     """graph_based_semantic_structure.py:76-125 in one forward and one backward library call."""
 
@@ -317,14 +396,16 @@ class _GetFused(torch.autograd.Function):
         M, _, _, _ = binding.get(False)
         plan = GetPlan()
         _lib.call("gh_get_plan_buffers", ctypes.addressof(M), ctypes.addressof(prep.struct), ctypes.addressof(plan))
-        arena = torch.empty(_arena_floats(plan.fwd_floats), device=dev, dtype=torch.float32)
+        pool = binding.pool if (POOL_ARENAS and any(ctx.needs_input_grad)) else None
+        arena = pool.take(plan.fwd_floats, dev) if pool is not None else torch.empty(_arena_floats(plan.fwd_floats), device=dev, dtype=torch.float32)
         # the observables (logits, attention weights, scores, keep-sets: a few MB) get a buffer of their own: whoever keeps
         # them -- the model's last_score / last_keep, batched_predict's per-chunk lists -- does not pin the activation arena
         obs = torch.empty(int(plan.obs_floats), device=dev, dtype=torch.float32)
         main = _lib.stream()
         side_raw = side.cuda_stream if side is not None else main
         if side is not None:
-            arena.record_stream(side)
+            if pool is None:
+                arena.record_stream(side)      # (pooled arenas never go back to the allocator while work is in flight)
             obs.record_stream(side)
         _lib.call("gh_get_forward", ctypes.addressof(M), ctypes.addressof(prep.struct), arena.data_ptr(), obs.data_ptr(), main, side_raw)
         B, b1, R = prep.b, prep.b1, prep.r
@@ -337,6 +418,7 @@ class _GetFused(torch.autograd.Function):
         ctx.anchor_ids = [id(a) for a in anchors]
         ctx.mark_non_differentiable(score, keep)
         ctx.set_materialize_grads(False)      # no zero-filled gradient tensors for unused outputs (fill launches per step)
+        ctx.pool = pool
         return phi, word_w, evd_w, score, keep
 
     @staticmethod
@@ -362,9 +444,10 @@ class _GetFused(torch.autograd.Function):
         if side is not None and not _lib.has_workspace(dev, side_raw):
             with torch.cuda.stream(side):
                 _lib.ensure_workspace(dev)
-        work = torch.empty(_arena_floats(ctx.plan_bwd), device=dev, dtype=torch.float32)
+        pool = ctx.pool
+        work = pool.take(ctx.plan_bwd, dev) if pool is not None else torch.empty(_arena_floats(ctx.plan_bwd), device=dev, dtype=torch.float32)
         if side is not None:
-            for t in (work, g_phi, gbuf, g_word_w, g_evd_w):
+            for t in ((None if pool is not None else work), g_phi, gbuf, g_word_w, g_evd_w):
                 if t is not None:
                     t.record_stream(side)
         args = (ctypes.addressof(M), ctypes.addressof(prep.struct), arena.data_ptr(), obs.data_ptr(), work.data_ptr(), g_phi.data_ptr(),
@@ -381,13 +464,16 @@ class _GetFused(torch.autograd.Function):
             hook()
             _lib.call("gh_get_backward", *args, 2, main, side_raw)
         ctx.arena = None                  # (a second backward on this graph raises above)
+        if pool is not None:              # both streams are joined at the end of gh_get_backward: later launches are ordered behind it
+            pool.give(arena)
+            pool.give(work)
         if direct:
             return (None, None, None) + (None,) * len(ctx.anchor_ids)
         return (None, None, None) + tuple(views.get(i) for i in ctx.anchor_ids)
 
 
 def eligible(model, query, kargs) -> bool:
-    if not ENABLED or not query.is_cuda or _lib.gemm_mode() == "bf16":
+    if not ENABLED or not query.is_cuda:
         return False
     if K.DocContentNoPaddingEvidence not in kargs or kargs[K.DocContentNoPaddingEvidence].shape[0] == 0:
         return False

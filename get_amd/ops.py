@@ -92,6 +92,7 @@ def bump_weight_epoch():
     global _WEIGHT_EPOCH
     _WEIGHT_EPOCH += 1
     _WT_CACHE.clear()
+    _BF16_CACHE.clear()
     _DERIVED_CACHE.clear()
     if _lib.gemm_mode() == "fp32x3p":       # the library's pre-split weight images: drop them (weights may have been replaced)
         call("gh_fp32x3_clear")
@@ -104,6 +105,7 @@ def _bump_trainer_epoch():
     global _WEIGHT_EPOCH
     _WEIGHT_EPOCH += 1
     _WT_CACHE.clear()
+    _BF16_CACHE.clear()
     for k in [k for k, v in _DERIVED_CACHE.items() if v[0][-1] != -1]:
         del _DERIVED_CACHE[k]
     if _lib.gemm_mode() == "fp32x3p":       # every image stale; refresh_transposes re-makes them all in one launch
@@ -173,6 +175,37 @@ def transposed(w: torch.Tensor) -> torch.Tensor:
 
 _DERIVED_CACHE: dict = {}
 _WT_PERSIST: dict = {}
+# bf16 storage mode (BASELINE configs[4]): bf16 twins of a weight matrix and of its transpose, in persistent buffers (their
+# addresses are part of the composite entry points' cached descriptor), validity tracked like the transposes'
+_BF16_CACHE: dict = {}       # id(w) -> (ref, data_ptr, version, epoch, w16, wt16)
+_BF16_PERSIST: dict = {}     # id(w) -> (ref, w16, wt16)
+
+
+def _bf16_buffers(w: torch.Tensor):
+    hit = _BF16_PERSIST.get(id(w))
+    if hit is None or hit[0]() is not w or hit[1].shape != w.shape or hit[1].device != w.device:
+        if len(_BF16_PERSIST) > 512:
+            for k in [k for k, v in _BF16_PERSIST.items() if v[0]() is None]:
+                del _BF16_PERSIST[k]
+        hit = (weakref.ref(w), torch.empty(tuple(w.shape), device=w.device, dtype=torch.bfloat16),
+               torch.empty((w.shape[1], w.shape[0]), device=w.device, dtype=torch.bfloat16))
+        _BF16_PERSIST[id(w)] = hit
+    return hit[1], hit[2]
+
+
+def bf16_twins(w: torch.Tensor):
+    """(bf16(W) [n_out][n_in], bf16(W^T) [n_in][n_out]) of a weight matrix, cached per parameter object / storage address /
+    in-place version / weight epoch; re-made together with the fp32 transpose in ONE launch (gh_weights_refresh), by
+    refresh_transposes after the optimiser step or here on a miss."""
+    hit = _BF16_CACHE.get(id(w))
+    if hit is not None:
+        ref, dptr, ver, epoch, w16, wt16 = hit
+        if ref() is w and dptr == w.data_ptr() and ver == w._version and epoch == _WEIGHT_EPOCH:
+            return w16, wt16
+    _bf16_buffers(w)
+    refresh_transposes([w])
+    hit = _BF16_CACHE[id(w)]
+    return hit[4], hit[5]
 
 
 def derived(tag: str, tensors, fn, frozen: bool = False):
@@ -216,7 +249,18 @@ def refresh_transposes(weights):
     rows = (ctypes.c_int * n)(*[w.shape[0] for w in ws])
     cols = (ctypes.c_int * n)(*[w.shape[1] for w in ws])
     cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
-    call("gh_transpose_batch", n, cast(src), cast(dst), cast(rows), cast(cols), stream())
+    # bf16 twins ride in the same launch for every matrix that has them (i.e. that a bf16-storage cell has asked for)
+    twins = [_BF16_PERSIST.get(id(w)) for w in ws]
+    twins = [t if (t is not None and t[0]() is w and t[1].device == w.device) else None for t, w in zip(twins, ws)]
+    if any(t is not None for t in twins):
+        w16 = (ctypes.c_void_p * n)(*[(t[1].data_ptr() if t is not None else None) for t in twins])
+        t16 = (ctypes.c_void_p * n)(*[(t[2].data_ptr() if t is not None else None) for t in twins])
+        call("gh_weights_refresh", n, cast(src), cast(dst), cast(w16), cast(t16), cast(rows), cast(cols), stream())
+        for w, t in zip(ws, twins):
+            if t is not None:
+                _BF16_CACHE[id(w)] = (weakref.ref(w), w.data_ptr(), w._version, _WEIGHT_EPOCH, t[1], t[2])
+    else:
+        call("gh_transpose_batch", n, cast(src), cast(dst), cast(rows), cast(cols), stream())
     if _lib.gemm_mode() == "fp32x3p":
         call("gh_fp32x3_refresh", stream())
     for w, wt in zip(ws, wts):
@@ -416,8 +460,12 @@ class _GGNNCell(torch.autograd.Function):
         ctx.bf = bf
         if bf:
             wkeys = (w_p, w_z0, w_z1, w_r0, w_r1, w_h0, w_h1)
-            ws_b = derived("cell_w_bf16", wkeys, lambda: tuple(t.to(torch.bfloat16) for t in ws))
-            wts_b = derived("cell_wt_bf16", wkeys, lambda: tuple(t.to(torch.bfloat16) for t in wts))
+            if all(t.dtype == torch.float32 and t.is_contiguous() for t in wkeys):
+                tw = [bf16_twins(t) for t in wkeys]          # persistent buffers, refreshed with the transposes in one launch
+                ws_b, wts_b = tuple(t[0] for t in tw), tuple(t[1] for t in tw)
+            else:
+                ws_b = derived("cell_w_bf16", wkeys, lambda: tuple(t.to(torch.bfloat16) for t in ws))
+                wts_b = derived("cell_wt_bf16", wkeys, lambda: tuple(t.to(torch.bfloat16) for t in wts))
             if ids is not None:
                 xb = derived("table_bf16", (x,), lambda: x.detach().to(torch.bfloat16), frozen=not x.requires_grad)
             else:
@@ -830,7 +878,8 @@ class _EvdAssemble(torch.autograd.Function):
         assert document.numel() == b * n * r
         right = torch.empty((b, n, xa + ds), device=avg.device, dtype=torch.float32)
         mask = torch.empty((b, n), device=avg.device, dtype=torch.float32)
-        call("gh_evd_assemble_fwd", ptr(avg), ptr(seg.offsets), ptr(tb), ptr(sources) if table is not None else None,
+        call("gh_evd_assemble_fwd", ptr(avg), ptr(seg.offsets), ptr(tb), tb.shape[0] if tb is not None else 0,
+             ptr(sources) if table is not None else None,
              1 if (table is not None and sources.dtype == torch.int64) else 0, ptr(document),
              1 if document.dtype == torch.int64 else 0, b, n, xa, ds, r, ptr(right), ptr(mask), stream())
         ctx.seg, ctx.dims, ctx.table = seg, (xa, ds), table
@@ -856,7 +905,7 @@ class _EvdAssemble(torch.autograd.Function):
                 ret_table = d_table
         src = ctx.sources
         call("gh_evd_assemble_bwd", ptr(g), ptr(seg.offsets), ptr(src), 1 if (src is not None and src.dtype == torch.int64) else 0,
-             seg.b, seg.n_max, xa, ds, ptr(d_avg), ptr(d_table), stream())      # ds is also g's row pitch: always the real width
+             table.shape[0] if table is not None else 0, seg.b, seg.n_max, xa, ds, ptr(d_avg), ptr(d_table), stream())      # ds is also g's row pitch: always the real width
         return d_avg, ret_table, None, None, None
 
 

@@ -56,7 +56,7 @@ extern "C" {
 
 typedef void* gh_stream_t;
 
-#define GH_ABI_VERSION 8
+#define GH_ABI_VERSION 9
 
 int gh_abi_version(void);
 /* Thread-local message of the last failing call on this thread (never NULL). */
@@ -120,6 +120,9 @@ int gh_transpose_batch(int n, const void* const* src_host, void* const* dst_host
  * pass the same (drop_p, drop_seed) to the backward.  Needs din % 4 == 0 and h % 4 == 0.
  * goff != NULL: node-compact layout; the cell runs on the first m_rows rows (m_real <= m_rows <= n*r; rows beyond
  * m_real are padding nodes: no neighbours).  goff == NULL: m_real/m_rows are ignored, m = n*r.
+ * NOTE (node-compact, m_rows > m_real): rows >= m_real of the SAVED tensors r (`rr`) and h~ (`hh`) are UNDEFINED on return --
+ * they are backward-only state and the backward never touches a padding row, so the fast epilogues do not store them
+ * (xp, a, z, rx and out ARE written for every row < m_rows).  Do not dump or reuse those rows.
  * score_w/score_x (both or neither; needs h % 4 == 0 and h <= 320): the GSL word scorer that consumes this cell's
  * output (wrapper.py:167, GGNN(h->1)) starts with proj(dropout(out)), a [m][h] x [h] product; with score_w[h] =
  * that proj weight the last GEMM's epilogue writes score_x[m] = dropout(out)[m] . score_w while `out` is still in
@@ -280,15 +283,23 @@ int gh_seg_unpad(const float* src, const int32_t* offsets, float* dst, int b, in
 /* ---- evidence-level assembly: graph_based_semantic_structure.py:157-170,195-215 in one launch ----
  * right[b][slot][0:xa] = avg row of the claim's slot-th evidence (zeros beyond its count); right[b][slot][xa:xa+ds] =
  * table[max(sources[b][slot], 0)] (article-source embedding, -1 padding -> row 0; ds = 0: no table);
- * mask[b][slot] = (sum_r document[b][slot][r] >= 1).  sources/document are int32 or int64 (flag). */
-int gh_evd_assemble_fwd(const float* avg, const int32_t* offsets, const float* table, const void* sources, int sources_i64,
+ * mask[b][slot] = (sum_r document[b][slot][r] >= 1).  sources/document are int32 or int64 (flag).
+ * table_rows (ABI 9): rows of `table`; ids are clamped into [0, table_rows) -- nn.Embedding raises for an id beyond the table
+ * (graph_based_semantic_structure.py:169), a device kernel cannot, so the event is COUNTED instead (gh_clamp_events). */
+int gh_evd_assemble_fwd(const float* avg, const int32_t* offsets, const float* table, int table_rows, const void* sources, int sources_i64,
                         const void* document, int document_i64, int b, int n_max, int xa, int ds, int r,
                         float* right, float* mask, gh_stream_t stream);
 /* Backward: d_avg[b1][xa] (NULL ok) = unpad(g[:, :, :xa]); d_table[s][ds] += the g[:, :, xa:] rows of the slots with source s,
  * summed in slot order (deterministic).  g [b][n_max][xa+ds] -- ds is g's row pitch as well: pass the real width even
  * when d_table is NULL (a frozen table just skips the table part).  At most 38 000 slots (b * n_max) per call. */
-int gh_evd_assemble_bwd(const float* g, const int32_t* offsets, const void* sources, int sources_i64, int b, int n_max,
+int gh_evd_assemble_bwd(const float* g, const int32_t* offsets, const void* sources, int sources_i64, int table_rows, int b, int n_max,
                         int xa, int ds, float* d_avg, float* d_table, gh_stream_t stream);
+/* Out-of-range inputs the kernels clamped for memory safety where the reference would have RAISED (nn.Embedding /
+ * nn.CrossEntropyLoss index errors): out_host[0] = labels outside [0, c) seen by gh_cross_entropy, [1] = claim-source ids,
+ * [2] = article-source ids outside their table (other than the -1 padding id), [3] = reserved; counted on the CURRENT device since
+ * the last reset.  Synchronises the device.  A training loop checks it once per epoch (or per step in debug runs): a non-zero
+ * count means corrupt input data was trained on as if it were class / row 0 or the last one. */
+int gh_clamp_events(int64_t* out4_host, int reset);
 /* masked mean over claim nodes (graph_based_semantic_structure.py:153): dst[b][h] = sum_l hid*mask / len */
 int gh_masked_mean_fwd(const float* hid, const int32_t* ids, const float* lens, float* dst, int b, int l, int h,
                        gh_stream_t stream);
@@ -322,7 +333,9 @@ int gh_flat_broadcast(void* comm, float* buf, int64_t count, int root, gh_stream
  * with the GSL refinement (:107; wrapper.py:165-172), word-level attention (:173-193), evidence-level assembly and
  * attention (:157-171, :195-221), head (:251-267, :69-74) -- on caller-provided buffers, so that a training step costs
  * the host two library calls instead of ~120 (the per-module entry points above remain the building blocks and the
- * API for callers that use the modules one by one).  Everything is fp32; the word-embedding table is frozen (as
+ * API for callers that use the modules one by one).  Everything is fp32 unless model->storage asks for the bf16 storage
+ * pipeline inside the evidence cells; widths: d % 4 == 0, h % 4 == 0, 4 <= d <= h <= 1024 (h > 320: the GSL scorer's projection
+ * runs inside gh_scorer_gsl instead of the first cell's last epilogue); the word-embedding table is frozen (as
  * master_get.py:143 constructs it); the claim branch runs on `side_stream` (may equal `stream`) underneath the evidence
  * cells.  Pointers are device pointers; the structs themselves live on the host. */
 typedef struct gh_cell_params {            /* one GGNN cell, Models/BiDAF/wrapper.py:177-183 */
@@ -332,6 +345,10 @@ typedef struct gh_cell_params {            /* one GGNN cell, Models/BiDAF/wrappe
   float *dw_p, *dw_z0, *dw_z1, *dw_r0, *dw_r1, *dw_h0, *dw_h1;          /* gradients, ACCUMULATED (+=); backward only */
   float *db_z0, *db_z1, *db_r0, *db_r1, *db_h0, *db_h1;
 } gh_cell_params;
+typedef struct gh_cell_bf16 {              /* bf16 twins of one cell's matrices (bf16 storage mode; gh_weights_refresh makes them) */
+  const void *w_p, *w_z0, *w_z1, *w_r0, *w_r1, *w_h0, *w_h1;            /* bf16 [h][din] / [h][h] */
+  const void *wt_p, *wt_z0, *wt_z1, *wt_r0, *wt_r1, *wt_h0, *wt_h1;     /* bf16 transposes; backward only */
+} gh_cell_bf16;
 typedef struct gh_att_params {             /* ConcatNotEqualSelfAtt, thirdparty/two_branches_attention.py:112-148 */
   const float *w1, *w2, *w1t;              /* linear1.weight [ha][xl+dr], linear2.weight [heads][ha], linear1.weight^T */
   float *dw1, *dw2;                        /* ACCUMULATED */
@@ -351,6 +368,12 @@ typedef struct gh_get_model {
   const float *out0_w, *out0_b, *out0_wt;           /* head: out.0 weight [h][e] (+ transpose [e][h]), bias */
   const float *out1_w, *out1_b, *out1_wt;           /* out.1 weight [n_classes][h] (+ transpose), bias */
   float *d_out0_w, *d_out0_b, *d_out1_w, *d_out1_b; /* ACCUMULATED */
+  /* ABI 9 -- BASELINE configs[4]: storage = 1 runs the two EVIDENCE cells in the bf16 storage pipeline of
+   * gh_ggnn_cell_fwd_bf16 / gh_ggnn_cell_bwd_bf16 (activations and weights bf16 in HBM, fp32 accumulation, fp32 cell outputs)
+   * whenever d % 8 == 0, h % 8 == 0 and the batch has >= 8192 real node rows; everything else stays fp32.  0 = fp32 throughout. */
+  int storage;
+  const void* embedding16;                          /* bf16 copy of the word table (storage 1) */
+  gh_cell_bf16 cell1_16, cell2_16;                  /* bf16 twins of cell1 / cell2 (storage 1) */
 } gh_get_model;
 typedef struct gh_get_batch {
   int b, b1, l, r, n_max;                           /* claims, pairs, claim length, evidence length, evidence slots per claim */
@@ -381,8 +404,8 @@ typedef struct gh_get_plan {
                                                        evd_w [b][n_max][evd_heads]; score [b1][r]; keep [b1][W] uint64 (8-byte aligned) */
 } gh_get_plan;
 int gh_get_plan_buffers(const gh_get_model* model, const gh_get_batch* batch, gh_get_plan* plan);
-/* sizeof of {gh_get_model, gh_get_batch, gh_get_plan, gh_cell_params}: lets a binding verify its mirror of the structs. */
-int gh_get_struct_sizes(int64_t* out4_host);
+/* sizeof of {gh_get_model, gh_get_batch, gh_get_plan, gh_cell_params, gh_cell_bf16}: lets a binding verify its mirror of the structs. */
+int gh_get_struct_sizes(int64_t* out5_host);
 /* Forward into `arena_fwd` (plan.fwd_floats floats) and `obs` (plan.obs_floats floats); both 256-byte aligned and kept until
  * the backward has run (evaluation: the arena may be released as soon as the call has been issued and the stream drained). */
 int gh_get_forward(const gh_get_model* model, const gh_get_batch* batch, float* arena_fwd, float* obs, gh_stream_t stream,
@@ -407,6 +430,12 @@ int gh_get_prepare(const int32_t* claim_tokens, const int32_t* claim_len, int b,
                    int32_t* d_ids, int32_t* d_n, uint64_t* d_bits, float* d_dinv,
                    int m_real, int32_t* goff, int32_t* rowg, int32_t* src, int32_t* cids, float* maskf,
                    const int64_t* slot, int32_t* document, gh_stream_t stream);
+
+/* Everything the forward / backward need that is DERIVED from weight matrices, for n matrices in one launch (after the
+ * optimiser step): dst_t[i] = src[i]^T as fp32 [cols][rows] (the backward's dX operands), and -- bf16 storage mode, any of the
+ * two arrays or any entry may be NULL -- dst_w16[i] = bf16(src[i]) [rows][cols], dst_t16[i] = bf16(src[i]^T) [cols][rows]. */
+int gh_weights_refresh(int n, const void* const* src, void* const* dst_t, void* const* dst_w16, void* const* dst_t16,
+                       const int* rows, const int* cols, gh_stream_t stream);
 
 /* ---- measurement hook (bench.py): HIP events around every kernel launch on its own stream ----
  * rows of `out` (each {total ms, total algorithmic work, launches}; work = flops for GEMMs, bytes otherwise):

@@ -45,7 +45,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     for name in _lib.SIGNATURES:
         assert name in decl, f"{name} bound in Python but not declared in get_hip.h"
     lib.gh_abi_version.restype = ctypes.c_int
-    assert lib.gh_abi_version() == 8
+    assert lib.gh_abi_version() == 9
     _lib.load()
 
 
@@ -146,14 +146,20 @@ def test_composite_descriptor_mirrors_and_buffer_plan(lib_path):
     import ctypes
     from get_amd import _lib, fused
     _lib.load()
-    sz = (ctypes.c_int64 * 4)()
+    sz = (ctypes.c_int64 * 5)()
     _lib.call("gh_get_struct_sizes", ctypes.cast(sz, ctypes.c_void_p))
     assert tuple(sz) == (ctypes.sizeof(fused.GetModel), ctypes.sizeof(fused.GetBatch), ctypes.sizeof(fused.GetPlan),
-                         ctypes.sizeof(fused.CellParams))
+                         ctypes.sizeof(fused.CellParams), ctypes.sizeof(fused.CellBf16))
 
-    def plan(b, b1, m_real, h=300, d=300):
+    def plan(b, b1, m_real, h=300, d=300, storage=0, twins=False):
         M, B, P = fused.GetModel(), fused.GetBatch(), fused.GetPlan()
         M.d, M.h, M.word_heads, M.evd_heads, M.n_classes, M.article_src_dim = d, h, 5, 2, 2, 128
+        M.storage = storage
+        if twins:          # (only checked for being non-NULL)
+            M.embedding16 = 4096
+            for c16 in (M.cell1_16, M.cell2_16):
+                for name, _ in fused.CellBf16._fields_:
+                    setattr(c16, name, 4096)
         B.b, B.b1, B.l, B.r, B.n_max, B.m_real, B.k_keep = b, b1, 30, 100, 30, m_real, 60
         if m_real >= 0:
             B.goff = B.rowg = B.cids = B.maskf = 4096        # (only checked for being non-NULL)
@@ -167,8 +173,20 @@ def test_composite_descriptor_mirrors_and_buffer_plan(lib_path):
         assert 0 < 4 * p.obs_floats < 16e6          # observables: a few MB, never the activation arena
     assert small.fwd_floats < big.fwd_floats < padded.fwd_floats and small.bwd_floats < big.bwd_floats
     assert 1.2e9 < 4 * big.fwd_floats < 2.5e9          # ~1.5 GB of saved activations at the bench shape
-    with pytest.raises(RuntimeError, match="320"):
-        plan(4, 40, 2600, h=768, d=768)
+    # ABI 9: wide hidden layers (BASELINE configs[4], h = 768) take the composite path; beyond 1024 they do not
+    wide = plan(32, 960, 62128, h=768, d=768)
+    assert wide.fwd_floats > 2.3 * big.fwd_floats
+    with pytest.raises(RuntimeError, match="1024"):
+        plan(4, 40, 2600, h=1028, d=1028)
+    # bf16 storage inside the evidence cells: needs the bf16 twins, halves the cells' saved activations, and only applies to
+    # batches with >= 8192 real node rows (a small batch keeps the fp32 plan)
+    with pytest.raises(RuntimeError, match="twins"):
+        plan(32, 960, 62128, h=768, d=768, storage=1)
+    wide16 = plan(32, 960, 62128, h=768, d=768, storage=1, twins=True)
+    assert 0.5 * wide.fwd_floats < wide16.fwd_floats < 0.75 * wide.fwd_floats and wide16.bwd_floats < wide.bwd_floats
+    assert plan(4, 40, 2600, h=768, d=768, storage=1, twins=True).fwd_floats == plan(4, 40, 2600, h=768, d=768).fwd_floats
+    with pytest.raises(RuntimeError, match="storage"):
+        plan(4, 40, 2600, storage=2)
     with pytest.raises(RuntimeError, match="m_real"):
         plan(4, 40, 40 * 100 + 1)
     # arena size classes: at most 1/8 above the request for large sizes
