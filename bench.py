@@ -158,10 +158,22 @@ class ReferenceApiBatch:
         self.bytes_handed_over = sum(t.numel() * t.element_size() for t in
                                      (self.query, self.query_adj, self.doc_ids, self.docs_adj, self.counts, self.doc_sources))
 
+        self._pending = None
+
+    def tensors(self):
+        return (self.query_lens, self.doc_ids, self.docs_adj, self.query_adj, self.counts, self.doc_sources, self.query_sources)
+
+    def start(self, stream):
+        """Launch the de-padding on `stream` now (get_amd.batch.ReferenceDepad); inputs() then only waits for its counters."""
+        from get_amd.batch import ReferenceDepad
+        self._pending = ReferenceDepad(*self.tensors(), n_max=self.n_max, stream=stream)
+
     def inputs(self):
         from get_amd.batch import kargs_from_reference_tensors
-        kargs = kargs_from_reference_tensors(self.query_lens, self.doc_ids, self.docs_adj, self.query_adj, self.counts,
-                                             self.doc_sources, self.query_sources, n_max=self.n_max)
+        if self._pending is not None:
+            dep, self._pending = self._pending, None
+            return self.query, self.doc_ids, dep.kargs()
+        kargs = kargs_from_reference_tensors(*self.tensors(), n_max=self.n_max)
         return self.query, self.doc_ids, kargs
 
 
@@ -333,8 +345,13 @@ def make_step(args, wl, trainer, source="resident"):
     from get_amd import ops
     model = wl["model"]
     state = {"i": 0, "pairs": 0}
-    batches = wl["ref_batches"] if source == "reference" else wl["batches"]
+    batches = wl["ref_batches"] if source in ("reference", "reference_sync") else wl["batches"]
     streamed = wl.get("streamed") if source == "streamed" else None
+    # "reference": the dense hand-over of batch i+1 is de-padded on a side stream while step i runs (batch.prefetch_reference's
+    # schedule); "reference_sync": de-padding and its read-back at the start of every step (kargs_from_reference_tensors)
+    ref_side = torch.cuda.Stream(device=batches[0].docs_adj.device) if source == "reference" else None
+    if ref_side is not None:
+        batches[0].start(ref_side)
 
     def step():
         if streamed is not None:
@@ -355,6 +372,8 @@ def make_step(args, wl, trainer, source="resident"):
         trainer.step()
         if streamed is not None:
             streamed.prefetch()
+        if ref_side is not None:
+            batches[state["i"] % len(batches)].start(ref_side)
         return loss
 
     def pairs():
@@ -922,12 +941,20 @@ def main():
                          min_seconds=1.0)
             sr = summarize_blocks(mr, max(4, args.steps // 2), mr["block_pairs"])
             hb = wl["ref_batches"][0].bytes_handed_over
+            mr2 = measure(args, wl, trainer, 1, device, dist, max(4, args.steps // 2), 3, profile=False, source="reference_sync",
+                          min_seconds=0.5)
+            sr2 = summarize_blocks(mr2, max(4, args.steps // 2), mr2["block_pairs"])
+            extra["reference_api_sync"] = {**leg_summary(sr2),
+                                           "what": "the same hand-over WITHOUT the one-batch-ahead schedule: kargs_from_reference_tensors at the "
+                                                   "start of every step, whose counter read-back waits for the previous step to drain"}
             extra["reference_api"] = {**leg_summary(sr),
                                       "bytes_handed_over_per_step": hb,
                                       "pairs_per_s_if_shipped_over_pcie_63GBps": wl["ref_batches"][0].b1 / (sr["ms_per_step"] * 1e-3 + hb / 63e9),
-                                      "what": "dense float64 (B,n,R,R) adjacency + padded ids resident in HBM -> kargs_from_reference_tensors "
-                                              "(one mask gather) -> PackedAdj.from_dense on the device -> node-compact plan derived from the ids (one 8-byte read-back); same model, "
-                                              "same optimiser step (mz_sampler.py:146-160, char_man_fitter_query_repr1.py:92-107,204-250)"}
+                                      "what": "dense float64 (B,n,R,R) adjacency + padded ids resident in HBM -> get_amd.batch.ReferenceDepad "
+                                              "(gh_ref_depad: one launch -- ids narrowed, adjacency packed, D^-1/2 A D^-1/2 recognised -> bit rows + "
+                                              "dinv, node-compact plan from the ids), launched one batch ahead on a side stream "
+                                              "(batch.prefetch_reference) so that its 40-byte read-back never waits for a step; same model, same "
+                                              "optimiser step (mz_sampler.py:146-160, char_man_fitter_query_repr1.py:92-107,204-250)"}
             del wl["ref_batches"]
             torch.cuda.empty_cache()
         if do_stream:

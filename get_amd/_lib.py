@@ -25,7 +25,7 @@ ABI_VERSION = 9          # GH_ABI_VERSION of include/get_hip.h
 SIGNATURES = {
     "gh_graph_build": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "gh_adj_pack_f64": [_P, _I, _I, _P, _P, _P],
-    "gh_ref_depad": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
+    "gh_ref_depad": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "gh_adj_pack_f32": [_P, _I, _I, _P, _P, _P],
     "gh_ragged_plan": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "gh_spmm": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -94,8 +94,11 @@ int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m
 int launch_tiny_linear_fwd(const float* x, const float* w, const float* bias, float* y, int m, int k, int n, hipStream_t s);
 int launch_tiny_linear_bwd(const float* x, const float* w, const float* g, float* dx, float* dw, float* db, int m, int k, int n,
                            hipStream_t s);
-int launch_att_softmax_fwd(const float* e, const float* mask, const float* right, const int32_t* goff, int m_real,
-                           int b, int l, int dr, int heads, float* weights, float* attended, hipStream_t s);
+int launch_att_softmax_fwd(float* e, const float* mask, const float* right, const int32_t* goff, int m_real,
+                           int b, int l, int dr, int heads, float* weights, float* attended, hipStream_t s,
+                           const float* e_parts = nullptr, int n_parts = 0, long long part_stride = 0);
+// (e_parts: n_parts partial score tensors [rows][heads], part_stride floats apart -- one per column block of a wide hidden
+//  layer; the kernel sums them in block order and writes the sum to e)
 int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w,
                            const int32_t* goff, int m_real, int b, int l, int dr, int heads, float* de, float* dright,
                            hipStream_t s, const int32_t* rowg = nullptr, float* dw_tmp = nullptr, int* dw_written = nullptr);
@@ -103,11 +106,11 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
 //  dw in dw_tmp instead of de -- *dw_written says so -- and launch_att_dpre(dw_in = dw_tmp, weights, de_out = de) finishes de)
 int launch_att_dpre(const float* de, const float* w2, const float* t, const int32_t* goff, int m_real, int b, int l,
                     int ha, int heads, float* dpre, float* du, float* dw2_part, hipStream_t s, const float* dw_in = nullptr,
-                    const float* weights = nullptr, float* de_out = nullptr);
+                    const float* weights = nullptr, float* de_out = nullptr, void* dpre16 = nullptr);      // dpre16: dpre as bf16 there instead
 
 // Where the gradient w.r.t. a GGNN cell's output goes when the GEMM that produces it applies that cell's gate head in its
 // epilogue (EPI_GATE_PRE): the cell's saved z / hh / xp and its dhp / dzp / dxp scratch (all [rows][h] fp32).
-struct GateFuse { const float* z; const float* hh; const float* xp; float* dhp; float* dzp; float* dxp; };
+struct GateFuse { const float* z; const float* hh; const float* xp; float* dhp; float* dzp; float* dxp; int bf16; };      // bf16: all six hold bf16 (bf16 storage pipeline)
 
 // fused building blocks shared by the per-module entry points (gemm_ops.hip) and the composite model entry points
 // (model_ops.hip); argument meaning as the gh_* functions of the same name in include/get_hip.h
@@ -130,13 +133,16 @@ int cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const float* 
                                                          // next: write the dX product into the previous cell's gate head instead of dx
 int att_fwd_impl(const float* left, int nl, const int32_t* rowu, const float* right, const float* mask, const int32_t* goff,
                  const int32_t* rowg, int m_real, int b, int l, int xl, int dr, int ha, int heads, const float* w1, const float* w2,
-                 float* u, float* t, float* e, float* weights, float* attended, hipStream_t s, int u_mode = 0);
+                 float* u, float* t, float* e, float* weights, float* attended, hipStream_t s, int u_mode = 0,
+                 const void* right16 = nullptr, const void* w1_16 = nullptr);      // bf16 twins of `right` and of w1 (bf16 storage mode)
 int att_bwd_impl(const float* left, const float* right, const int32_t* goff, int m_real, int b, int l, int xl, int dr, int ha,
                  int heads, const float* w1t, const float* w2, const float* t, const float* weights, const float* g_att,
                  const float* g_w, float* de, float* dpre, float* du, float* dleft, float* dright, float* dw1, float* dw2,
                  const int32_t* claim_offsets, int nl, float* du_c, int dleft_accumulate, hipStream_t s,
                  const int32_t* rowg = nullptr, float* dw_tmp = nullptr, const GateFuse* next = nullptr, int dleft_late = 0,
-                 float* dw2_buf = nullptr);
+                 float* dw2_buf = nullptr, const void* right16 = nullptr, const void* w1t_16 = nullptr);
+// right16 / w1t_16 (bf16 storage mode, both calls of a two-phase backward alike): bf16 twins of `right` and of w1t; dpre is then
+// produced as bf16 (in the first half of the caller's dpre buffer) and the dright / dW1 products run on the bf16-storage kernels
 // att_fwd_impl u_mode: 0 = the whole layer; 1 = ONLY the left projection u (the caller runs it early, e.g. on the claim branch's
 //   stream); 2 = u is already there.  att_bwd_impl dleft_late: the left gradient's GEMM runs in the dw1-only call (dright == NULL)
 //   instead of the first one, i.e. on the weight-gradient stream, off the critical path; with dw2_buf ([b][heads][ha] floats, the same

@@ -68,7 +68,8 @@ struct Problem {
   //            hashing in the TN loader pushed that kernel over 168 VGPRs, i.e. from 3 to 2 waves per SIMD.)
   int drop_mode; int drop_ld; int drop_col0; unsigned drop_seed; unsigned drop_thresh; float drop_scale;
   // bf16 storage pipeline (gemm_nt.hip.h MODE 2 / gemm_tn.hip.h bf16): elt = 1 -> A and B hold bf16 (lda/ldb/K in
-  // elements); io bits say which epilogue streams are bf16: 1 = C, 2 = out1, 4 = in0, 8 = in1; c32 (EPI_TANH_H): also
+  // elements); io bits say which epilogue streams are bf16: 1 = C, 2 = out1, 4 = in0, 8 = in1, 16 = in2, 32 = out2 (the last
+  // two: EPI_GATE_PRE); c32 (EPI_TANH_H): also
   // write the fp32 value of out1 there (the cell output the fp32 consumers read)
   int elt; int io; float* c32;
   // EPI_TANH_H with the fused scorer projection on a COLUMN BLOCK of the row (narrow tile): this block's partial dot product is

@@ -639,10 +639,10 @@ gemm_nt_kernel(const Launch L_byval) {
                 xb[j] = ld4(in1, o, io & 8);
                 xc[j] = ld4(out1, o, io & 2);
               } else if (E == EPI_GATE_PRE) {
-                xa[j] = ld4(in0, o, false);
-                xb[j] = ld4(in1, o, false);
-                xc[j] = ld4(P.in2, o, false);
-                if (P.gin) xd[j] = ld4(P.gin, o, false);
+                xa[j] = ld4(in0, o, io & 4);
+                xb[j] = ld4(in1, o, io & 8);
+                xc[j] = ld4(P.in2, o, io & 16);
+                if (P.gin) xd[j] = ld4(P.gin, o, false);      // (the addend of g is always fp32)
               } else if (E == EPI_ATT)
                 xa[j] = *reinterpret_cast<const float4*>(P.u + (size_t)(P.rowg ? P.rowg[row] : row / P.R) * P.ldu + col);
             }
@@ -706,9 +706,13 @@ gemm_nt_kernel(const Launch L_byval) {
             c.f = w.f * (1.f - Z.f);
             GH_ONE(x) GH_ONE(y) GH_ONE(z) GH_ONE(w)
 #undef GH_ONE
-            *reinterpret_cast<float4*>(C + o) = a;
-            *reinterpret_cast<float4*>(out1 + o) = b;
-            *reinterpret_cast<float4*>(P.out2 + o) = c;
+            if constexpr (MODE == 2) {      // bf16 storage: the gate head's scratch holds bf16 (io bits 1 / 2 / 32)
+              st4(C, o, a, io & 1); st4(out1, o, b, io & 2); st4(P.out2, o, c, io & 32);
+            } else {
+              *reinterpret_cast<float4*>(C + o) = a;
+              *reinterpret_cast<float4*>(out1 + o) = b;
+              *reinterpret_cast<float4*>(P.out2 + o) = c;
+            }
           } else if (E == EPI_ATT) {
             const float4 u4 = xa[j];
             const float4 t4 = make_float4(tanhf_(w.x + u4.x), tanhf_(w.y + u4.y), tanhf_(w.z + u4.z), tanhf_(w.w + u4.w));
@@ -764,7 +768,7 @@ gemm_nt_kernel(const Launch L_byval) {
       };
 #pragma unroll
       for (int it0 = 0; it0 < NIT8; it0 += CH) {
-        F8 xa[CH], xb[CH], xc[CH];
+        F8 xa[CH], xb[CH], xc[CH], xd[E == EPI_GATE_PRE ? CH : 1];
         auto where = [&](int j, int& row, int& col, float*& sp) __attribute__((always_inline)) {
           const int i = tid + (it0 + j) * NTHR;
           const int rr = i / C8, c8 = i - rr * C8;
@@ -783,6 +787,10 @@ gemm_nt_kernel(const Launch L_byval) {
               else if (E == EPI_SIGMOID_R) xa[j] = ld8(in0, o, io & 4);
               else if (E == EPI_TANH_H) { xa[j] = ld8(in0, o, io & 4); xb[j] = ld8(in1, o, io & 8); }
               else if (E == EPI_BWD_DRX) { xa[j] = ld8(in0, o, io & 4); xb[j] = ld8(in1, o, io & 8); xc[j] = ld8(out1, o, io & 2); }
+              else if (E == EPI_GATE_PRE) {
+                xa[j] = ld8(in0, o, io & 4); xb[j] = ld8(in1, o, io & 8); xc[j] = ld8(P.in2, o, io & 16);
+                if (P.gin) xd[j] = ld8(P.gin, o, false);
+              }
             }
           }
         }
@@ -816,14 +824,34 @@ gemm_nt_kernel(const Launch L_byval) {
           } else if (E == EPI_BWD_DRX) {
             st8(C, o, drx4(wa, xa[j].a, xb[j].a), drx4(wb, xa[j].b, xb[j].b), io & 1);
             st8(out1, o, add4(xc[j].a, mul4(wa, xb[j].a)), add4(xc[j].b, mul4(wb, xb[j].b)), io & 2);
+          } else if (E == EPI_GATE_PRE) {      // g = w (+ gin), masked when g is the gradient w.r.t. a dropped-out input: the gate head of the cell below
+            if (drop_mode == 3) {
+              const unsigned idx = (unsigned)row * (unsigned)drop_ld + (unsigned)(P.drop_col0 + col);
+              wa = drop4(wa, drop_seed, idx, drop_thresh, drop_scale);
+              wb = drop4(wb, drop_seed, idx + 4u, drop_thresh, drop_scale);
+            }
+            if (P.gin) { wa = add4(wa, xd[j].a); wb = add4(wb, xd[j].b); }
+            auto head = [](const float4 g, const float4 Z, const float4 Hh, const float4 X, float4& a, float4& b, float4& c) __attribute__((always_inline)) {
+#define GH_ONE8(f)                                    \
+              a.f = g.f * Z.f * (1.f - Hh.f * Hh.f);          \
+              b.f = g.f * (Hh.f - X.f) * Z.f * (1.f - Z.f);   \
+              c.f = g.f * (1.f - Z.f);
+              GH_ONE8(x) GH_ONE8(y) GH_ONE8(z) GH_ONE8(w)
+#undef GH_ONE8
+            };
+            float4 a0, b0, c0, a1, b1, c1;
+            head(wa, xa[j].a, xb[j].a, xc[j].a, a0, b0, c0);
+            head(wb, xa[j].b, xb[j].b, xc[j].b, a1, b1, c1);
+            st8(C, o, a0, a1, io & 1); st8(out1, o, b0, b1, io & 2); st8(P.out2, o, c0, c1, io & 32);
           }
         }
       }
     };
     constexpr bool WIDE8 = (MODE == 2) && (BN % 8 == 0);
     if constexpr (WIDE8) {
-      if (!rowred && epi != EPI_GATE_PRE && epi != EPI_ATT) {
+      if (!rowred && epi != EPI_ATT) {
         if (epi == EPI_STORE) pass8(std::integral_constant<int, EPI_STORE>{});
+        else if (epi == EPI_GATE_PRE) pass8(std::integral_constant<int, EPI_GATE_PRE>{});
         else if (epi == EPI_SIGMOID_Z) pass8(std::integral_constant<int, EPI_SIGMOID_Z>{});
         else if (epi == EPI_SIGMOID_R) pass8(std::integral_constant<int, EPI_SIGMOID_R>{});
         else if (epi == EPI_TANH_H) pass8(std::integral_constant<int, EPI_TANH_H>{});
@@ -836,7 +864,7 @@ gemm_nt_kernel(const Launch L_byval) {
     else if (epi == EPI_SIGMOID_R) pass(std::integral_constant<int, EPI_SIGMOID_R>{});
     else if (epi == EPI_TANH_H) pass(std::integral_constant<int, EPI_TANH_H>{});
     else if (epi == EPI_BWD_DRX) pass(std::integral_constant<int, EPI_BWD_DRX>{});
-    else if (epi == EPI_GATE_PRE) { if constexpr (MODE != 2) pass(std::integral_constant<int, EPI_GATE_PRE>{}); }
+    else if (epi == EPI_GATE_PRE) pass(std::integral_constant<int, EPI_GATE_PRE>{});
     else if (epi == EPI_ATT) pass(std::integral_constant<int, EPI_ATT>{});
     if (rowred) {
       // e[row][c] = sum_k y[row][k] w2[c][k] for the 16*WM finished rows in LDS: a [16 x N] x [N x <=8] product per row
@@ -846,7 +874,8 @@ gemm_nt_kernel(const Launch L_byval) {
       const int nred = scorer ? 1 : heads;
       const int b = wave % WM, kp = wave / WM;
       const float* arow = ep + (b * 16 + l15) * EP_PITCH + 4 * q;
-      const float* wrow = P.w2 + (size_t)min(l15, nred - 1) * N + 4 * q;
+      // (EPI_ATT on a column block of a wider row -- Batch::add, att_blocks: w2 is [heads][ldu], this block starts at its column)
+      const float* wrow = P.w2 + (size_t)min(l15, nred - 1) * (epi == EPI_ATT ? P.ldu : N) + 4 * q;
       f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int k0 = kp * 16; k0 < N; k0 += 16 * KSPL) {
         const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + k0);          // columns >= N of the staged tile are exact zeros
@@ -868,7 +897,7 @@ gemm_nt_kernel(const Launch L_byval) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (4 * q + r < nred) {
-              if (P.e_atomic) atomicAdd(&P.e[(size_t)row * nred + 4 * q + r], sum[r]);
+              if (P.e_atomic == 1) atomicAdd(&P.e[(size_t)row * nred + 4 * q + r], sum[r]);
               else P.e[(size_t)row * nred + 4 * q + r] = sum[r];
             }
         }

@@ -45,7 +45,7 @@ static bool fast_ok(const Launch& L, bool tn) {
     if (p.epi == EPI_ATT && (!al16(p.u) || p.ldu % 4 || !al16(p.w2))) { fast_why(10, i); return false; }
     if (p.epi == EPI_TANH_H && p.w2 && !al16(p.w2)) { fast_why(11, i); return false; }
     if (p.epi == EPI_GATE_PRE && (tn || !p.in0 || !p.in1 || !p.in2 || !p.out1 || !p.out2 || !al16(p.in2) || !al16(p.out2) ||
-                                  (p.gin && !al16(p.gin)) || p.elt)) { fast_why(12, i); return false; }
+                                  (p.gin && !al16(p.gin)))) { fast_why(12, i); return false; }
   }
   return true;
 }
@@ -101,7 +101,8 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
   if (!fast && wants_dropout(L)) return hipErrorInvalidValue;     // fused dropout exists in the fast kernels only
   if (!fast && !tn)
     for (int i = 0; i < L.nprob; ++i)
-      if ((L.p[i].epi == EPI_TANH_H && L.p[i].w2) || L.p[i].epi == EPI_GATE_PRE) return hipErrorInvalidValue;   // so do the fused scorer projection and the fused gate head
+      if ((L.p[i].epi == EPI_TANH_H && L.p[i].w2) || L.p[i].epi == EPI_GATE_PRE || (L.p[i].epi == EPI_ATT && L.p[i].e_atomic == 2))
+        return hipErrorInvalidValue;   // so do the fused scorer projection, the fused gate head and the head scores of column blocks
   bool launched = false;
   bool any_elt = false, all_elt = true;
   for (int i = 0; i < L.nprob; ++i) { any_elt = any_elt || L.p[i].elt; all_elt = all_elt && L.p[i].elt; }
@@ -498,6 +499,10 @@ struct Batch {
   // the K loops: launches with stream-heavy epilogues gain, plain-store launches lose (prototype, tools/glds_proto.hip NHALF:
   // h-gate-like epilogue K = 300: 62.6 -> 68.2 TF, K = 600: 87.7 -> 90.5; plain store: 92.4 -> 88.7).  Chosen per call site.
   bool narrow = false;
+  // EPI_ATT on rows wider than one column block (h = 768): every block applies tanh(. + u) to its columns and reduces ITS share
+  // of the head scores W2 . t into a partial buffer of its own, e + block * e_block_stride (plain stores: the consumer,
+  // att_softmax_fwd, adds the partials in block order -- deterministic).  0 = whole rows only.
+  long long e_block_stride = 0;
   bool wide = false;      // 128 x 256 bf16 tile (launch_cfg<2, 2, 8, 4>)
   bool wide256 = false;   // 256 x 256 bf16 tile, 8 waves (launch_cfg<4, 2, 8, 4>)
   bool wide128 = false;   // 128 x 128 bf16 tile, three workgroups per CU (launch_cfg<2, 2, 4, 4>; tool build: GH_BF16_TILE=128)
@@ -545,7 +550,8 @@ struct Batch {
   void add(const Problem& p) {
     // row reductions need whole rows -- except the scorer's single dot product, which two column blocks may add up (e_atomic)
     const bool scorer_blocks = p.epi == EPI_TANH_H && p.w2 && p.N > bn && narrow && p.N <= 2 * bn;
-    if ((p.epi == EPI_ATT || (p.epi == EPI_TANH_H && p.w2)) && p.N > bn && !scorer_blocks) { err = hipErrorInvalidValue; return; }
+    const bool att_blocks = p.epi == EPI_ATT && p.N > bn && e_block_stride > 0;
+    if ((p.epi == EPI_ATT || (p.epi == EPI_TANH_H && p.w2)) && p.N > bn && !scorer_blocks && !att_blocks) { err = hipErrorInvalidValue; return; }
     for (int n0 = 0; n0 < p.N; n0 += bn) {
       Problem q = p;
       q.N = (p.N - n0 < bn) ? p.N - n0 : bn;
@@ -568,9 +574,10 @@ struct Batch {
       if (q.in1) q.in1 = adv(q.in1, (size_t)n0, q.io & 8);
       if (q.c32) q.c32 += n0;
       if (q.gin) q.gin += n0;
-      if (q.in2) q.in2 += n0;
-      if (q.out2) q.out2 += n0;
+      if (q.in2) q.in2 = adv(q.in2, (size_t)n0, q.io & 16);
+      if (q.out2) q.out2 = (float*)adv(q.out2, (size_t)n0, q.io & 32);
       if (scorer_blocks) { q.w2 += n0; q.e_atomic = 1; }
+      if (att_blocks) { q.w2 += n0; q.u += n0; q.e = p.e + (size_t)(n0 / bn) * (size_t)e_block_stride; q.e_atomic = 2; }      // (2: own partial buffer, plain stores)
       if (L.nprob == GH_MAX_PROBLEMS) flush();
       L.p[L.nprob++] = q;
       const int mt = (q.M + bm - 1) / bm;
@@ -587,7 +594,12 @@ struct Batch {
       if (target < 0) target = measure_env("GH_TN_SPLIT_TARGET", 2304);
       int ks = (target + n_inner - 1) / n_inner;   // three resident rounds of 256 CUs x 3 workgroups (measured on the bench step: 1152 -> 2.06 ms,
                                                    // 1536 -> 1.95, 2304 -> 1.86, 3072 -> 1.84 but more partials to reduce; one round 20 % slower)
-      const int ks_max = (k_total / 256 > 1) ? k_total / 256 : 1;
+      // shortest K chunk: 256 rows (fp32).  bf16 storage, wide outputs (h = 768: 64 x 320 partial tiles of 80 KB each): a single
+      // 768 x 768 product split into 64 chunks writes and re-reads more partial-tile bytes than it streams operands
+      static int min_rows16 = -1;
+      if (min_rows16 < 0) min_rows16 = measure_env("GH_TN_MIN_ROWS16", 4096);      // (A/B on configs[4]: 256 / 1024 / 2048 / 4096 rows = 106.76 / 106.72 / 106.81 / 107.17 K pairs/s)
+      const int min_rows = L.p[0].elt ? min_rows16 : 256;
+      const int ks_max = (k_total / min_rows > 1) ? k_total / min_rows : 1;
       if (ks > ks_max) ks = ks_max;
       if (ks < 1) ks = 1;
       // The K chunks are dealt round-robin to the 8 XCDs (chunk c runs on XCD c % 8, gemm_tn.hip.h): a chunk count that is
@@ -697,7 +709,13 @@ struct Batch {
       tmax = t;
     }
     int ks = tmax / 4;
-    const int want = (256 + blocks - 1) / blocks;
+    // workgroups wanted: one per CU -- two for long contractions (>= 128 K tiles, e.g. the evidence-level attention at h = 768:
+    // K = 6272), where a split-K workgroup is MFMA-bound rather than latency-bound (A/B configs[4] bf16: 256 / 512 / 768 =
+    // 107.7 / 108.7 / 108.1 K pairs/s; headline and Snopes-count steps unchanged at any of them)
+    static int target = -1;
+    if (target < 0) target = measure_env("GH_NT_SPLIT_TARGET", 0);
+    const int tgt = target > 0 ? target : (tmax >= 128 ? 512 : 256);
+    const int want = (tgt + blocks - 1) / blocks;
     if (ks > want) ks = want;
     if (ks < 2) return false;
     const int ct = (tmax + ks - 1) / ks;     // tiles per chunk
@@ -941,7 +959,6 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
   // out = h z + xp (1-z):  dhp = g z (1-h^2), dzp = g (h-xp) z (1-z), dxp = g (1-z)
   // (pre_done: the GEMM that produced g already wrote the three straight from its epilogue, EPI_GATE_PRE -- g itself was
   //  never stored and gate_bwd_pre's 4 reads + 3 writes shrink to the 3 + 3 the producing epilogue added)
-  GH_REQUIRE(!(pre_done && bf), "ggnn_cell_bwd: the fused gate head exists for the fp32 pipeline only");
   if (!pre_done)
     if (int e = launch_gate_bwd_pre(g, z, hh, xp, dhp, dzp, dxp, (size_t)M * h, s, bf)) return e;
   const bool wide = bf && h % 256 == 0;
@@ -994,11 +1011,12 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
     GH_CHECK_HIP(hipStreamWaitEvent(sw, ev_agg, 0));
   }
   if (dx || next) {  // dx = (dxp Wp) . mask/(1-p)
-    GH_REQUIRE(!next || (!bf && din % 4 == 0), "ggnn_cell_bwd: the fused gate head needs the fp32 pipeline and float4-shaped rows");
+    GH_REQUIRE(!next || (din % 4 == 0 && (next->bf16 != 0) == (bf != 0)), "ggnn_cell_bwd: the fused gate head needs float4-shaped rows and both cells in the same storage mode");
     Batch b(false, M, s, wide && din % 256 == 0, 5, din);
     Problem p = gemm_problem(M, din, next ? EPI_GATE_PRE : EPI_STORE, next ? next->dhp : dx, din, dxp, h, wt_p, h, h, nullptr, bf);      // dx itself is fp32
     if (next) {      // dx IS the gradient w.r.t. the previous cell's output: write that cell's dhp / dzp / dxp instead of dx
       p.in0 = next->z; p.in1 = next->hh; p.in2 = next->xp; p.out1 = next->dzp; p.out2 = next->dxp;
+      p.io = next->bf16 ? (1 | 2 | 4 | 8 | 16 | 32) : 0;
     }
     set_dropout(p, 3, din, drop_p, drop_seed);
     b.add(p);
@@ -1077,7 +1095,8 @@ extern "C" int gh_ggnn_cell_bwd_bf16(const uint64_t* bits, const float* dinv, co
 //   att_out / att_ld: where `attended` goes (row pitch att_ld >= dr * heads: straight into a wider concatenation buffer).
 int gh::att_fwd_impl(const float* left, int nl, const int32_t* rowu, const float* right, const float* mask, const int32_t* goff,
                  const int32_t* rowg, int m_real, int b, int l, int xl, int dr, int ha, int heads, const float* w1, const float* w2,
-                 float* u, float* t, float* e, float* weights, float* attended, hipStream_t s, int u_mode) {
+                 float* u, float* t, float* e, float* weights, float* attended, hipStream_t s, int u_mode,
+                 const void* right16, const void* w1_16) {
   GH_REQUIRE(heads >= 1 && heads <= 8, "concat_att: heads=%d not in [1,8]", heads);
   GH_REQUIRE(b > 0 && l > 0 && dr > 0 && ha > 0, "concat_att_fwd: bad sizes");
   GH_REQUIRE(u_mode >= 0 && u_mode <= 2, "concat_att_fwd: u_mode %d not in {0,1,2}", u_mode);
@@ -1103,15 +1122,40 @@ int gh::att_fwd_impl(const float* left, int nl, const int32_t* rowu, const float
   if (u_mode == 1) return 0;
   if (!(left && xl > 0)) xl = 0;
   const int32_t* urow = rowu ? rowu : rowg;
+  const float* e_parts = nullptr;
+  int n_parts = 0;
   if (M > 0) {  // t = tanh(W1[:, xl:] . right_t + u) ; e = W2 t  (:140-141)
-    Batch bt(false, M, s);
-    Problem p = gemm_problem(M, ha, EPI_ATT, t, ha, right, dr, w1 + xl_in, xl_in + dr, dr);
+    // bf16 storage mode with the twins at hand (right16 = the producing cell's bf16 output, w1_16 = bf16(linear1.weight)): the
+    // product runs on the bf16-storage kernel (v_mfma_f32_16x16x32_bf16 from bf16 LDS images, half the operand bytes) instead of
+    // rounding fp32 fragments in registers (MODE 1) -- the same bf16 operand values, fp32 accumulation and fp32 t either way
+    const bool use16 = right16 && w1_16 && g_gemm_mode == 1 && M >= 8192 && dr % 8 == 0 && (xl_in + dr) % 8 == 0 && xl_in % 8 == 0 && ha % 8 == 0;
+    Batch bt(false, M, s, use16 && ha % 256 == 0);
+    Problem p = use16 ? gemm_problem(M, ha, EPI_ATT, t, ha, (const float*)right16, dr,
+                                     (const float*)((const unsigned short*)w1_16 + xl_in), xl_in + dr, dr, nullptr, 1)
+                      : gemm_problem(M, ha, EPI_ATT, t, ha, right, dr, w1 + xl_in, xl_in + dr, dr);
     p.u = u; p.ldu = ha; p.R = l; p.w2 = w2; p.heads = heads; p.e = e; p.rowg = urow;
-    if (!one_block) p.epi = EPI_STORE;     // wide hidden layer (h = 768): the head scores need whole rows, so the
-    bt.add(p);                             // tanh + W2 reduction runs as a row-per-wave pass over the stored product
+    // wide hidden layer (h = 768): a row spans several column blocks.  Activation-sized launches let every block reduce its share
+    // of the head scores into a partial buffer of its own (stream workspace; att_softmax_fwd sums the partials in block order);
+    // without the workspace (or for few-row launches, whose split-K plan finishes whole rows anyway) the product is stored and the
+    // tanh + W2 reduction runs as a row-per-wave pass over it.
+    bool blocks = false;
+    if (!one_block) {
+      const int nb = (ha + bt.bn - 1) / bt.bn;
+      const Workspace wsp = workspace_for(s);
+      const size_t need = (size_t)nb * (size_t)M * heads * sizeof(float);
+      if (M >= 8192 && wsp.p && need <= wsp.bytes && ha % 4 == 0) {
+        blocks = true;
+        bt.e_block_stride = (long long)M * heads;
+        p.e = wsp.p;
+        e_parts = wsp.p; n_parts = nb;
+      } else {
+        p.epi = EPI_STORE;
+      }
+    }
+    bt.add(p);
     bt.flush();
     GH_CHECK_HIP(bt.err);
-    if (!one_block) {
+    if (!one_block && !blocks) {
       FinishArgs F;
       F.n = 1; F.split = 0;
       F.it[0] = FinishItem{t, 0, 1, M, ha, EPI_ATT, 0, ha, t, nullptr, nullptr, nullptr, nullptr, nullptr, u, w2, e, ha, l, heads, urow};
@@ -1119,7 +1163,8 @@ int gh::att_fwd_impl(const float* left, int nl, const int32_t* rowu, const float
       GH_LAUNCH_CHECK();
     }
   }
-  return launch_att_softmax_fwd(e, mask, right, goff, m_real, b, l, dr, heads, weights, attended, s);   // (:142-147)
+  return launch_att_softmax_fwd(e, mask, right, goff, m_real, b, l, dr, heads, weights, attended, s, e_parts, n_parts,
+                                (long long)M * heads);   // (:142-147)
 }
 
 extern "C" int gh_concat_att_fwd(const float* left, const float* right, const float* mask, const int32_t* goff,
@@ -1139,7 +1184,8 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
                  const float* g_att, const float* g_w, float* de, float* dpre, float* du,
                  float* dleft, float* dright, float* dw1, float* dw2,
                  const int32_t* claim_offsets, int nl, float* du_c, int dleft_accumulate, hipStream_t s,
-                 const int32_t* rowg, float* dw_tmp, const GateFuse* next, int dleft_late, float* dw2_buf) {
+                 const int32_t* rowg, float* dw_tmp, const GateFuse* next, int dleft_late, float* dw2_buf,
+                 const void* right16, const void* w1t_16) {
   GH_REQUIRE(heads >= 1 && heads <= 8, "concat_att: heads=%d not in [1,8]", heads);
   if (!goff) m_real = b * l;
   GH_REQUIRE(m_real >= 0 && m_real <= b * l, "concat_att_bwd: node-compact rows %d do not fit b*l=%d", m_real, b * l);
@@ -1153,6 +1199,10 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
   // launches; dright == NULL is the complementary "dw1 only" call on buffers (dpre, du) a first call has filled.
   const bool weights_only = (dright == nullptr);
   GH_REQUIRE(!weights_only || dw1, "concat_att_bwd: dright == NULL asks for the dw1-only phase, which needs dw1");
+  // bf16 storage mode with the twins at hand: dpre is produced as bf16 (the products below round it to bf16 anyway) and the
+  // dright / dW1 products run on the bf16-storage kernels -- same operand values as the in-register rounding of MODE 1
+  const bool use16 = right16 && w1t_16 && g_gemm_mode == 1 && m_real >= 8192 && dr % 8 == 0 && ha % 8 == 0 && xl % 8 == 0;
+  void* const dpre16 = use16 ? (void*)dpre : nullptr;
   float* dw2_part = nullptr;
   if (!weights_only) {
   int dw_written = 0;
@@ -1163,7 +1213,7 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
   const bool late = dleft_late && dw2_buf && ha % 4 == 0;      // partials in the caller's buffer, reduced by the second call
   dw2_part = late ? dw2_buf : ((wsp.p && dw2_bytes <= wsp.bytes && ha % 4 == 0) ? wsp.p : nullptr);
   if (int e = launch_att_dpre(de, w2, t, goff, m_real, b, l, ha, heads, dpre, du, dw2_part, s, dw_written ? dw_tmp : nullptr,
-                              dw_written ? weights : nullptr, dw_written ? de : nullptr)) return e;
+                              dw_written ? weights : nullptr, dw_written ? de : nullptr, dpre16)) return e;
   if (dw2_part && !late) {
     ReduceArgs R;
     R.n = 1;
@@ -1173,16 +1223,21 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
   }
   if (claim_offsets && xl > 0 && !dleft_late)
     if (int e = gh_seg_sum(du, claim_offsets, du_c, nl, ha, (gh_stream_t)s)) return e;
+  const float* w1t_r16 = use16 ? (const float*)((const unsigned short*)w1t_16 + (size_t)xl * ha) : nullptr;
+  GH_REQUIRE(!next || !next->bf16 || use16, "concat_att_bwd: a bf16 gate head needs the bf16 twins of right and w1t");
   if (M > 0 && next) {  // dright (= the gradient of the cell that produced `right`) is consumed by that cell's gate head only:
-    Batch bt(false, M, s, false, 6, dr);      // g = softmax part (in dright) + dpre W1[:, xl:] goes straight into dhp / dzp / dxp
-    Problem p = gemm_problem(M, dr, EPI_GATE_PRE, next->dhp, dr, dpre, ha, w1t + (size_t)xl * ha, ha, ha);
+    Batch bt(false, M, s, use16 && dr % 256 == 0, 6, dr);      // g = softmax part (in dright) + dpre W1[:, xl:] goes straight into dhp / dzp / dxp
+    Problem p = use16 ? gemm_problem(M, dr, EPI_GATE_PRE, next->dhp, dr, (const float*)dpre16, ha, w1t_r16, ha, ha, nullptr, 1)
+                      : gemm_problem(M, dr, EPI_GATE_PRE, next->dhp, dr, dpre, ha, w1t + (size_t)xl * ha, ha, ha);
     p.gin = dright; p.in0 = next->z; p.in1 = next->hh; p.in2 = next->xp; p.out1 = next->dzp; p.out2 = next->dxp;
+    p.io = next->bf16 ? (1 | 2 | 4 | 8 | 16 | 32) : 0;
     bt.add(p);
     bt.flush();
     GH_CHECK_HIP(bt.err);
   } else if (M > 0) {  // dright += dpre W1[:, xl:]
-    Batch bt(false, M, s);
-    Problem p = gemm_problem(M, dr, EPI_STORE, dright, dr, dpre, ha, w1t + (size_t)xl * ha, ha, ha);
+    Batch bt(false, M, s, use16 && dr % 256 == 0);
+    Problem p = use16 ? gemm_problem(M, dr, EPI_STORE, dright, dr, (const float*)dpre16, ha, w1t_r16, ha, ha, nullptr, 1)
+                      : gemm_problem(M, dr, EPI_STORE, dright, dr, dpre, ha, w1t + (size_t)xl * ha, ha, ha);
     p.accumulate = 1;
     bt.add(p);
     bt.flush();
@@ -1225,7 +1280,8 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
   if (!dw1) return 0;
   if (M > 0) {
     Batch bt(true, M, s);
-    bt.add(tn_problem(ha, dr, dw1 + xl, ldw, dpre, ha, right, dr, M));
+    if (use16) bt.add(tn_problem(ha, dr, dw1 + xl, ldw, (const float*)dpre16, ha, (const float*)right16, dr, M, nullptr, 1));
+    else bt.add(tn_problem(ha, dr, dw1 + xl, ldw, dpre, ha, right, dr, M));
     bt.flush();
     GH_CHECK_HIP(bt.err);
   }

@@ -125,17 +125,22 @@ adj_pack_kernel(const T* __restrict__ adj, int R, uint64_t* __restrict__ bits, f
 // packing of the adjacency and the node counts the node-compact plan needs, in ONE pass over the handed-over tensors:
 // workgroup (claim c, slot j) with j < counts[c] is pair p = sum(counts[:c]) + j; it narrows the ids, counts the real nodes
 // (id >= 1), packs its R x R block (as adj_pack_kernel) and checks what the node-compact layout assumes (ids prefix-shaped,
-// no edge on a padding node).  stats = {pairs, real nodes, pairs that violate the assumption}: one read-back sizes everything.
+// no edge on a padding node).  It also recognises the adjacency convert_text produces (interactions.py:11-18: D^-1/2 A D^-1/2
+// of a binary graph, A[i][j] = dinv[i] dinv[j] with dinv = 1 / sqrt(row degree)): such a block is fully described by its bit
+// rows + dinv (the kernels' "normalised" mode, 2 KB instead of 40 KB per graph); only for other blocks, or when `force_vals`
+// says that some graph of the batch needs them, the dense fp32 values are written.
+// stats = {pairs, real nodes, pairs that violate the layout assumption, pairs that are NOT normalised graphs, reserved}.
 template <typename TI>
 __global__ void __launch_bounds__(256)
 ref_depad_kernel(const int64_t* __restrict__ counts, int B, int n_max, int R, const TI* __restrict__ ids, const double* __restrict__ adj,
-                 int32_t* __restrict__ d_ids, uint64_t* __restrict__ bits, float* __restrict__ vals, int32_t* __restrict__ n_nodes,
-                 unsigned long long* __restrict__ stats) {
+                 int32_t* __restrict__ d_ids, uint64_t* __restrict__ bits, float* __restrict__ vals, float* __restrict__ dinv,
+                 int32_t* __restrict__ n_nodes, unsigned long long* __restrict__ stats, int force_vals) {
   const int c = blockIdx.x / n_max, j = blockIdx.x % n_max;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ int red[4];
   __shared__ int s_real[256];
-  __shared__ int s_bad;
+  __shared__ float s_dinv[256];
+  __shared__ int s_bad, s_weighted;
   const long long cnt_c = counts[c];
   const int cc = cnt_c < 0 ? 0 : (cnt_c > n_max ? n_max : (int)cnt_c);
   if (j >= cc) return;
@@ -144,7 +149,7 @@ ref_depad_kernel(const int64_t* __restrict__ counts, int B, int n_max, int R, co
   for (int i = tid; i < c; i += 256) { const long long v = counts[i]; part += v < 0 ? 0 : (v > n_max ? n_max : (int)v); }
   for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
   if (lane == 0) red[wave] = part;
-  if (tid == 0) s_bad = 0;
+  if (tid == 0) { s_bad = 0; s_weighted = 0; }
   __syncthreads();
   const int p = red[0] + red[1] + red[2] + red[3] + j;
   const size_t slot = (size_t)c * n_max + j;
@@ -163,32 +168,52 @@ ref_depad_kernel(const int64_t* __restrict__ counts, int B, int n_max, int R, co
   __syncthreads();
   nn = red[0] + red[1] + red[2] + red[3];
   int bad = (tid < R && real != (tid < nn ? 1 : 0)) ? 1 : 0;
-  // adjacency block: row i per wave iteration, 64 columns per pass
+  // pass 1 over the block: bit rows (union of A's and A^T's patterns) and row degrees -> dinv as gh_graph_build computes it
   const int W = (R + 63) / 64;
   const double* ab = adj + slot * (size_t)R * R;
   for (int i = wave; i < R; i += 4) {
-    bool any = false;
+    int deg = 0;
     for (int w = 0; w < W; ++w) {
       const int jj = w * 64 + lane;
-      float v = 0.f, vt = 0.f;
-      if (jj < R) {
-        v = (float)ab[(size_t)i * R + jj];
-        vals[((size_t)p * R + i) * R + jj] = v;
-        vt = (float)ab[(size_t)jj * R + i];
-      }
-      const unsigned long long m = __ballot(v != 0.f || vt != 0.f);
+      double v = 0.0, vt = 0.0;
+      if (jj < R) { v = ab[(size_t)i * R + jj]; vt = ab[(size_t)jj * R + i]; }
+      const unsigned long long m = __ballot((float)v != 0.f || (float)vt != 0.f);
       if (lane == 0) bits[((size_t)p * R + i) * W + w] = m;
-      any = any || m != 0ull;
+      deg += __popcll(m);
     }
-    if (any && !s_real[i]) bad = 1;     // a padding node with edges: the node-compact layout would drop them
+    if (deg > 0 && !s_real[i]) bad = 1;     // a padding node with edges: the node-compact layout would drop them
+    if (lane == 0) s_dinv[i] = deg > 0 ? (float)(1.0 / sqrt((double)deg)) : 0.f;
   }
   if (bad) s_bad = 1;
   __syncthreads();
+  if (tid < R) dinv[(size_t)p * R + tid] = s_dinv[tid];
+  // pass 2 (the block is in L2 now): is every entry dinv[i] dinv[j] (to fp32 rounding of the fitter's float64 product)?
+  int weighted = 0;
+  for (int i = wave; i < R; i += 4) {
+    const float di = s_dinv[i];
+    for (int w = 0; w < W; ++w) {
+      const int jj = w * 64 + lane;
+      if (jj < R) {
+        const float v = (float)ab[(size_t)i * R + jj];
+        const float e = di * s_dinv[jj];
+        // (a pattern entry whose own value is 0 -- present on the transposed side only -- is not a normalised graph either)
+        const bool on = v != 0.f || (float)ab[(size_t)jj * R + i] != 0.f;
+        if (on && !(fabsf(v - e) <= 4e-7f * e)) weighted = 1;
+      }
+    }
+  }
+  if (weighted) s_weighted = 1;
+  __syncthreads();
+  if (s_weighted || force_vals) {
+    for (int i = wave; i < R; i += 4)
+      for (int jj = lane; jj < R; jj += 64) vals[((size_t)p * R + i) * R + jj] = (float)ab[(size_t)i * R + jj];
+  }
   if (tid == 0) {
     n_nodes[p] = nn;
     atomicAdd(&stats[0], 1ull);
     atomicAdd(&stats[1], (unsigned long long)nn);
     if (s_bad) atomicAdd(&stats[2], 1ull);
+    if (s_weighted) atomicAdd(&stats[3], 1ull);
   }
 }
 
@@ -1140,17 +1165,18 @@ extern "C" int gh_adj_pack_f32(const float* adj, int n, int r, uint64_t* bits, f
 }
 
 extern "C" int gh_ref_depad(const int64_t* counts, int b, int n_max, int r, const void* ids, int ids_i64, const double* adj,
-                            int32_t* d_ids, uint64_t* bits, float* vals, int32_t* n_nodes, int64_t* stats, gh_stream_t stream) {
+                            int32_t* d_ids, uint64_t* bits, float* vals, float* dinv, int32_t* n_nodes, int64_t* stats, int force_vals,
+                            gh_stream_t stream) {
   GH_REQUIRE(r > 0 && r <= MAX_R, "ref_depad: r=%d not in [1,%d]", r, MAX_R);
-  GH_REQUIRE(b >= 0 && n_max > 0 && counts && ids && adj && d_ids && bits && vals && n_nodes && stats, "ref_depad: bad arguments");
-  GH_CHECK_HIP(hipMemsetAsync(stats, 0, 3 * sizeof(int64_t), (hipStream_t)stream));
+  GH_REQUIRE(b >= 0 && n_max > 0 && counts && ids && adj && d_ids && bits && vals && dinv && n_nodes && stats, "ref_depad: bad arguments");
+  GH_CHECK_HIP(hipMemsetAsync(stats, 0, 5 * sizeof(int64_t), (hipStream_t)stream));
   if (b == 0) return 0;
   if (ids_i64)
     hipLaunchKernelGGL(ref_depad_kernel<int64_t>, dim3(b * n_max), dim3(256), 0, (hipStream_t)stream, counts, b, n_max, r,
-                       (const int64_t*)ids, adj, d_ids, bits, vals, n_nodes, (unsigned long long*)stats);
+                       (const int64_t*)ids, adj, d_ids, bits, vals, dinv, n_nodes, (unsigned long long*)stats, force_vals);
   else
     hipLaunchKernelGGL(ref_depad_kernel<int32_t>, dim3(b * n_max), dim3(256), 0, (hipStream_t)stream, counts, b, n_max, r,
-                       (const int32_t*)ids, adj, d_ids, bits, vals, n_nodes, (unsigned long long*)stats);
+                       (const int32_t*)ids, adj, d_ids, bits, vals, dinv, n_nodes, (unsigned long long*)stats, force_vals);
   GH_LAUNCH_CHECK();
   return 0;
 }

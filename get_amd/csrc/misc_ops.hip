@@ -372,16 +372,15 @@ int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m
 // e [b][l][C] -> weights = softmax over l (two_branches_attention.py:142-146), attended[b][d][c] = sum_l right[b][l][d] w[l][c] (:147)
 template <int CT>     // compile-time bound on the number of heads (accumulator registers)
 __global__ void __launch_bounds__(256, 4)
-att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ mask, const float* __restrict__ right,
+att_softmax_fwd_kernel(float* __restrict__ e, const float* __restrict__ mask, const float* __restrict__ right,
                        const int32_t* __restrict__ goff, int Lmax, int Dr, int C, float* __restrict__ weights,
-                       float* __restrict__ attended) {
+                       float* __restrict__ attended, const float* __restrict__ e_parts, int n_parts, long long part_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   float* ws = reinterpret_cast<float*>(dsm);   // [Lmax][C]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // node-compact layout: pair b owns rows [goff[b], goff[b+1]) of e / mask / right / weights
   const int row0 = goff ? goff[b] : b * Lmax;
   const int L = goff ? goff[b + 1] - row0 : Lmax;
-  const float* eb = e + (size_t)row0 * C;
   const float* mb = mask + (size_t)row0;
   const int NT = blockDim.x, NWV = NT >> 6;
   // The right tile is what the kernel streams (L rows x Dr floats per pair): the first batch of this wave's rows is
@@ -414,6 +413,21 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
 #pragma unroll
       for (int h = 0; h < NCH; ++h) rv[u][h] = zero4;
   }
+  // scores staged in LDS (read twice below).  n_parts > 0: the producing GEMM left one partial per column block of the hidden
+  // layer (wide rows, h = 768): summed here in block order, and the sum is written back as the layer's `e` output
+  float* eb = ws + (size_t)Lmax * C + (size_t)NWV * 64 * 4 * C;      // [Lmax][C], behind the weights and the reduce partials
+  for (int i = tid; i < L * C; i += NT) {
+    float v;
+    if (n_parts > 0) {
+      v = 0.f;
+      for (int p = 0; p < n_parts; ++p) v += e_parts[(size_t)p * part_stride + (size_t)row0 * C + i];
+      if (blockIdx.y == 0) e[(size_t)row0 * C + i] = v;
+    } else {
+      v = e[(size_t)row0 * C + i];
+    }
+    eb[i] = v;
+  }
+  __syncthreads();
   for (int c = wave; c < C; c += NWV) {
     float mx = -INFINITY;
     for (int l = lane; l < L; l += 64)
@@ -488,18 +502,19 @@ att_softmax_fwd_kernel(const float* __restrict__ e, const float* __restrict__ ma
   }
 }
 
-int launch_att_softmax_fwd(const float* e, const float* mask, const float* right, const int32_t* goff, int m_real,
-                           int b, int l, int dr, int heads, float* weights, float* attended, hipStream_t s) {
+int launch_att_softmax_fwd(float* e, const float* mask, const float* right, const int32_t* goff, int m_real,
+                           int b, int l, int dr, int heads, float* weights, float* attended, hipStream_t s,
+                           const float* e_parts, int n_parts, long long part_stride) {
   GH_REQUIRE(dr % 4 == 0 && (reinterpret_cast<uintptr_t>(right) & 15) == 0, "att_softmax_fwd: right rows must be float4-shaped (dr=%d)", dr);
   const int nthr = 256;      // (8 waves per pair measured no faster: the kernel is not parallelism-bound)
-  const size_t lds = ((size_t)l * heads + (nthr / 64) * 64 * 4 * heads) * 4;
+  const size_t lds = ((size_t)2 * l * heads + (nthr / 64) * 64 * 4 * heads) * 4;
   GH_REQUIRE(lds <= 64 * 1024, "att_softmax_fwd: sequence %d x heads %d too large", l, heads);
   prof_begin(s, b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_SOFTMAX_FWD);
   GH_REQUIRE(heads >= 1 && heads <= 8, "att_softmax_fwd: %d heads (1..8 supported)", heads);
   const dim3 grid(b, (dr / 4 + 127) / 128);
-  if (heads <= 2) hipLaunchKernelGGL(att_softmax_fwd_kernel<2>, grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended);
-  else if (heads <= 5) hipLaunchKernelGGL(att_softmax_fwd_kernel<5>, grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended);
-  else hipLaunchKernelGGL(att_softmax_fwd_kernel<8>, grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended);
+  if (heads <= 2) hipLaunchKernelGGL(att_softmax_fwd_kernel<2>, grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended, e_parts, n_parts, part_stride);
+  else if (heads <= 5) hipLaunchKernelGGL(att_softmax_fwd_kernel<5>, grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended, e_parts, n_parts, part_stride);
+  else hipLaunchKernelGGL(att_softmax_fwd_kernel<8>, grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended, e_parts, n_parts, part_stride);
   const double rows = goff ? (double)m_real : (double)b * l;
   prof_end(b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_SOFTMAX_FWD, 4.0 * (rows * dr + 2.0 * rows * heads + rows + (double)b * dr * heads), s);
   GH_LAUNCH_CHECK();
@@ -837,7 +852,8 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
 __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __restrict__ w2, const float* __restrict__ t,
                                 const int32_t* __restrict__ goff, int Lmax, int Ha, int C, int RL, int S4,
                                 float* __restrict__ dpre, float* __restrict__ du, float* __restrict__ dw2_part,
-                                const float* __restrict__ dw_in, const float* __restrict__ wts, float* __restrict__ de_out) {
+                                const float* __restrict__ dw_in, const float* __restrict__ wts, float* __restrict__ de_out,
+                                unsigned short* __restrict__ dpre16) {      // dpre16 != NULL: dpre is written THERE as bf16 (RNE) instead
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   float4* red = reinterpret_cast<float4*>(dsm);           // [RL][1 + C][S4]
   const int b = blockIdx.x;
@@ -921,7 +937,15 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
           }
         const float4 dp = make_float4(dt.x * (1.f - tv.x * tv.x), dt.y * (1.f - tv.y * tv.y), dt.z * (1.f - tv.z * tv.z),
                                       dt.w * (1.f - tv.w * tv.w));
-        reinterpret_cast<float4*>(dpre + m * Ha)[c4] = dp;
+        if (dpre16) {
+          typedef float f32x2_t __attribute__((ext_vector_type(2)));
+          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+          const f32x2_t lo = {dp.x, dp.y}, hi = {dp.z, dp.w};
+          reinterpret_cast<uint2*>(dpre16 + m * Ha)[c4] = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_t)),
+                                                                     __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_t)));
+        } else {
+          reinterpret_cast<float4*>(dpre + m * Ha)[c4] = dp;
+        }
         acc.x += dp.x; acc.y += dp.y; acc.z += dp.z; acc.w += dp.w;
       }
     }
@@ -947,7 +971,7 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
 
 int launch_att_dpre(const float* de, const float* w2, const float* t, const int32_t* goff, int m_real, int b, int l,
                     int ha, int heads, float* dpre, float* du, float* dw2_part, hipStream_t s, const float* dw_in,
-                    const float* weights, float* de_out) {
+                    const float* weights, float* de_out, void* dpre16) {
   GH_REQUIRE(ha % 4 == 0 && ha / 4 <= 256, "att_dpre: attention hidden %d must be a multiple of 4 and <= 1024", ha);
   const int n4 = ha / 4;
   // column slabs of <= 32 float4 (512 B of a row per lane group: whole 128-byte lines), ~3 slabs at ha = 300; few pairs
@@ -965,7 +989,7 @@ int launch_att_dpre(const float* de, const float* w2, const float* t, const int3
   const size_t lds = (size_t)RL * (1 + heads) * S4 * 16 + (size_t)l * heads * 4 * (dw_in ? 2 : 1) + (dw_in ? 64 : 0);
   prof_begin(s, b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_DPRE);
   hipLaunchKernelGGL(att_dpre_kernel, dim3(b, nsl), dim3(threads), lds, s, de, w2, t, goff, l, ha, heads, RL, S4, dpre, du, dw2_part,
-                     dw_in, weights, de_out);
+                     dw_in, weights, de_out, (unsigned short*)dpre16);
   const double rows = goff ? (double)m_real : (double)b * l;
   prof_end(b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_DPRE, 4.0 * (2.0 * rows * ha + rows * heads + (double)b * ha), s);
   GH_LAUNCH_CHECK();

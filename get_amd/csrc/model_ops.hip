@@ -361,12 +361,11 @@ static int cell_bwd(const gh_cell_params& c, const gh_cell_bf16* c16, const Cell
     typedef const float* cf;
     GH_REQUIRE(c16->wt_p && c16->wt_z0 && c16->wt_z1 && c16->wt_r0 && c16->wt_r1 && c16->wt_h0 && c16->wt_h1,
                "get_backward: storage = 1 needs the bf16 twins of the cells' transposed weights (gh_weights_refresh)");
-    GH_REQUIRE(!pre_done && !next, "get_backward: internal -- the fused gate head exists in the fp32 pipeline only");
     return cell_bwd_impl(1, bits, dinv, vals, keep, goff, m_real, x, ids, n, r, din, h, (cf)c16->wt_p, (cf)c16->wt_z0, (cf)c16->wt_z1,
                          (cf)c16->wt_r0, (cf)c16->wt_r1, (cf)c16->wt_h0, (cf)c16->wt_h1, A + cb.xp, A + cb.a, A + cb.z, A + cb.rr,
                          A + cb.rx, A + cb.hh, g, W + sc[0], W + sc[1], W + sc[2], W + sc[3], W + sc[4], dx, c.dw_p, c.dw_z0, c.dw_z1,
                          c.dw_r0, c.dw_r1, c.dw_h0, c.dw_h1, c.db_z0, c.db_r0, c.db_h0, c.db_z1, c.db_r1, c.db_h1, drop_p, seed, (void*)s,
-                         nullptr, nullptr, nullptr, 0, nullptr);
+                         nullptr, nullptr, nullptr, pre_done, next);
   }
   GH_REQUIRE(c.wt_p, "get_backward: a cell's transposes are missing");
   return cell_bwd_impl(0, bits, dinv, vals, keep, goff, m_real, x, ids, n, r, din, h, c.wt_p, c.wt_z0, c.wt_z1, c.wt_r0, c.wt_r1,
@@ -468,7 +467,7 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
   // ---- word-level attention (:173-193): the left input is the claim vector -> ONE u row per claim
   GH_TRY(att_fwd_impl(A + f.q_repr, d.B, I32(A, f.rowc), A + f.c2.out32, d.compact ? Ba->maskf : A + f.maskf_p, goff,
                       d.compact ? Ba->rowg : nullptr, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1, Mo->att_word.w2, A + f.uw, A + f.tw,
-                      A + f.ew, O + f.ww, A + f.avg, s, 2));
+                      A + f.ew, O + f.ww, A + f.avg, s, 2, d.bf ? (const void*)(A + f.c2.out) : nullptr, d.bf ? Mo->att_word_w1_16 : nullptr));
   // ---- evidence-level assembly + attention (:157-171, :195-221)
   GH_TRY(gh_evd_assemble_fwd(A + f.avg, I32(A, f.offsets), Mo->article_src_table, Mo->article_src_rows, d.as > 0 ? Ba->doc_sources : nullptr, Ba->doc_sources_i64,
                              Ba->document, Ba->document_i64, d.B, d.n, d.Xa, d.as, d.R, A + f.right_e, A + f.mask_e, (void*)s));
@@ -502,11 +501,14 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
   const int32_t* ids1 = d.compact ? Ba->cids : Ba->d_ids;
   const uint64_t* keep = reinterpret_cast<const uint64_t*>(O + f.keep);
   // gate heads fused into the producing GEMMs' epilogues: cell scratch order is {dhp, dzp, drp, dxp, da}
-  const GateFuse gf2 = {A + f.c2.z, A + f.c2.hh, A + f.c2.xp, Wb + w.sc2[0], Wb + w.sc2[1], Wb + w.sc2[3]};
-  const GateFuse gf1 = {A + f.c1.z, A + f.c1.hh, A + f.c1.xp, Wb + w.sc1[0], Wb + w.sc1[1], Wb + w.sc1[3]};
-  // bf16 storage: the gate heads' scratch holds bf16, which the fused epilogue does not write -- the gradient between the
-  // layers stays an fp32 tensor (g2, dx2) and every cell runs its own gate_bwd_pre pass
-  const bool fuse_gate = !d.bf;
+  const GateFuse gf2 = {A + f.c2.z, A + f.c2.hh, A + f.c2.xp, Wb + w.sc2[0], Wb + w.sc2[1], Wb + w.sc2[3], d.bf ? 1 : 0};
+  const GateFuse gf1 = {A + f.c1.z, A + f.c1.hh, A + f.c1.xp, Wb + w.sc1[0], Wb + w.sc1[1], Wb + w.sc1[3], d.bf ? 1 : 0};
+  // bf16 storage: the gate heads' scratch holds bf16; the fused epilogue writes it as such (io bits), which needs the bf16 twins
+  // of the word attention's linear1 (the dright product then runs on the bf16-storage kernel).  Without them the gradient
+  // between the layers stays an fp32 tensor (g2, dx2) and every cell runs its own gate_bwd_pre pass.
+  const bool fuse_gate = !d.bf || (Mo->att_word_w1t_16 != nullptr);
+  const void* att_r16 = d.bf ? (const void*)(A + f.c2.out) : nullptr;
+  const void* att_w1t16 = d.bf ? Mo->att_word_w1t_16 : nullptr;
   const gh_cell_bf16* c16_1 = d.bf ? &Mo->cell1_16 : nullptr;
   const gh_cell_bf16* c16_2 = d.bf ? &Mo->cell2_16 : nullptr;
   const float* table1 = d.bf ? (const float*)Mo->embedding16 : Mo->embedding;
@@ -549,13 +551,14 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
     GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out32, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
                         O + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, Wb + w.g2, nullptr,
                         Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, s, d.compact ? Ba->rowg : nullptr, Wb + w.dw_w,
-                        fuse_gate ? &gf2 : nullptr, 1, Wb + w.dw2p_w));
+                        fuse_gate ? &gf2 : nullptr, 1, Wb + w.dw2p_w, att_r16, att_w1t16));
     // ---- side stream: linear1's weight gradient of the word attention, then the claim branch's backward -- underneath
     //      the evidence cells' chain on the main stream
     GH_TRY(stream_after(ss, s, ev.ev[4]));
     GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out32, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
                         O + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, nullptr, Mo->att_word.dw1,
-                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, ss, nullptr, nullptr, nullptr, 1, Wb + w.dw2p_w));
+                        Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, ss, nullptr, nullptr, nullptr, 1, Wb + w.dw2p_w, att_r16,
+                        att_w1t16));
     GH_TRY(gh_masked_mean_bwd(Wb + w.d_q, Ba->q_ids, A + f.lens_eff, Wb + w.d_qhid, d.B, d.L, H, (void*)ss));
     GH_TRY(cell_bwd(Mo->claim, nullptr, f.q, A, Ba->q_bits, Ba->q_dinv, Ba->q_vals, nullptr, nullptr, 0, Mo->embedding, Ba->q_ids, d.B, d.L, d.D, H,
                     Wb + w.d_qhid, Wb, w.qs, nullptr, Ba->drop_claim, Ba->seed_claim, ss));
@@ -563,7 +566,7 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
     //      bench step: 6.31 -> 6.23 ms, two MFMA-bound streams mostly slow each other down, while every kernel's wall time
     //      and with it the per-kernel roofline figures inflate by 20-30 %.  Not used: one stream, honest kernel times.)
     if (fuse_gate)
-      GH_TRY(cell_bwd(Mo->cell2, nullptr, f.c2, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, keep, goff, d.Mr, A + f.c1.out, nullptr, d.B1, d.R, H, H,
+      GH_TRY(cell_bwd(Mo->cell2, c16_2, f.c2, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, keep, goff, d.Mr, A + f.c1.out, nullptr, d.B1, d.R, H, H,
                       Wb + w.g2, Wb, w.sc2, nullptr, Ba->drop_gnn, Ba->seed_cell2, s, 1, &gf1));
     else
       GH_TRY(cell_bwd(Mo->cell2, c16_2, f.c2, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, keep, goff, d.Mr, A + f.c1.out, nullptr, d.B1, d.R, H, H,
@@ -571,7 +574,7 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
   }
   if (phase != 1) {
     if (fuse_gate)
-      GH_TRY(cell_bwd(Mo->cell1, nullptr, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, Mo->embedding, ids1, d.B1, d.R, d.D, H,
+      GH_TRY(cell_bwd(Mo->cell1, c16_1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, table1, ids1, d.B1, d.R, d.D, H,
                       nullptr, Wb, w.sc1, nullptr, Ba->drop_gnn, Ba->seed_cell1, s, 1, nullptr));
     else
       GH_TRY(cell_bwd(Mo->cell1, c16_1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, table1, ids1, d.B1, d.R, d.D, H,

@@ -52,7 +52,8 @@ class GetModel(ctypes.Structure):
                 ("out0_w", _P), ("out0_b", _P), ("out0_wt", _P),
                 ("out1_w", _P), ("out1_b", _P), ("out1_wt", _P),
                 ("d_out0_w", _P), ("d_out0_b", _P), ("d_out1_w", _P), ("d_out1_b", _P),
-                ("storage", _I), ("embedding16", _P), ("cell1_16", CellBf16), ("cell2_16", CellBf16)]
+                ("storage", _I), ("embedding16", _P), ("cell1_16", CellBf16), ("cell2_16", CellBf16),
+                ("att_word_w1_16", _P), ("att_word_w1t_16", _P)]
 
 
 class GetBatch(ctypes.Structure):
@@ -153,6 +154,7 @@ class Binding:
         twins = emb16 = None
         if bf:
             twins = [[ops.bf16_twins(w) for w in _cell_tensors(c)[0]] for c in self.cells[1:]]
+            twins.append([ops.bf16_twins(m.self_att_word.linear1.weight)])
             emb = m.embedding.weight
             emb16 = ops.derived("table_bf16", (emb,), lambda: emb.detach().to(torch.bfloat16), frozen=not emb.requires_grad)
         sig = (tuple(p.data_ptr() for p in self.params), tuple(t.data_ptr() for t in self.tables),
@@ -182,7 +184,8 @@ class Binding:
         S.storage = 1 if bf else 0
         if bf:
             S.embedding16 = emb16.data_ptr()
-            for c16, cell in zip((S.cell1_16, S.cell2_16), twins):
+            S.att_word_w1_16, S.att_word_w1t_16 = twins[2][0][0].data_ptr(), twins[2][0][1].data_ptr()
+            for c16, cell in zip((S.cell1_16, S.cell2_16), twins[:2]):
                 for name, (w16, wt16) in zip(_CELL_W, cell):
                     setattr(c16, name, w16.data_ptr())
                     setattr(c16, "wt" + name[1:], wt16.data_ptr())
@@ -403,6 +406,11 @@ class _GetFused(torch.autograd.Function):
         obs = torch.empty(int(plan.obs_floats), device=dev, dtype=torch.float32)
         main = _lib.stream()
         side_raw = side.cuda_stream if side is not None else main
+        # split-K scratch of the few-row products and the per-block head-score partials of wide hidden layers (one per stream)
+        _lib.ensure_workspace(dev)
+        if side is not None and not _lib.has_workspace(dev, side_raw):
+            with torch.cuda.stream(side):
+                _lib.ensure_workspace(dev)
         if side is not None:
             if pool is None:
                 arena.record_stream(side)      # (pooled arenas never go back to the allocator while work is in flight)

@@ -81,11 +81,17 @@ int gh_adj_pack_f32(const float* adj, int n, int r, uint64_t* bits, float* vals,
  * (b, n_max, r, r) float64, `[:evd_count]` sliced claim by claim with two host syncs each) in one launch:
  * pair p = sum(counts[:c]) + j for every slot j < counts[c] (counts clamped to [0, n_max]) gets its ids narrowed to int32
  * (d_ids [b*n_max][r], rows [0, pairs) written), its adjacency packed as gh_adj_pack_f64 does (bits [b*n_max][r][W],
- * vals [b*n_max][r][r]) and its number of real nodes (id >= 1) in n_nodes [b*n_max].
- * stats[3] (device, int64): {pairs, real nodes over all pairs, pairs whose ids are not prefix-shaped or whose padding
- * nodes carry edges} -- the last must be 0 for the node-compact layout (gh_ragged_plan) to apply. */
+ * vals [b*n_max][r][r] -- see below) and its number of real nodes (id >= 1) in n_nodes [b*n_max].
+ * The adjacency convert_text produces (interactions.py:11-18: D^-1/2 A D^-1/2 of a binary graph) is RECOGNISED: for such a
+ * pair only bits and dinv [b*n_max][r] (= 1 / sqrt(row degree), exactly as gh_graph_build writes it) are written -- the
+ * kernels' "normalised" mode -- and vals stays untouched, unless force_vals != 0.
+ * stats[5] (device, int64): {pairs, real nodes over all pairs, pairs whose ids are not prefix-shaped or whose padding
+ * nodes carry edges -- must be 0 for the node-compact layout (gh_ragged_plan) to apply --, pairs whose values are NOT the
+ * normalised graph (0: hand bits + dinv to the kernels; > 0: the batch needs the weighted mode -- call again with
+ * force_vals = 1 so that vals is complete), reserved}. */
 int gh_ref_depad(const int64_t* counts, int b, int n_max, int r, const void* ids, int ids_i64, const double* adj,
-                 int32_t* d_ids, uint64_t* bits, float* vals, int32_t* n_nodes, int64_t* stats, gh_stream_t stream);
+                 int32_t* d_ids, uint64_t* bits, float* vals, float* dinv, int32_t* n_nodes, int64_t* stats, int force_vals,
+                 gh_stream_t stream);
 
 /* Node-compact layout plan from the node counts of gh_graph_build (device arrays):
  *   goff[n+1] (see above); rowg[n*r] graph of every compact row; src[n*r] padded row index g*r+j of every compact
@@ -374,6 +380,8 @@ typedef struct gh_get_model {
   int storage;
   const void* embedding16;                          /* bf16 copy of the word table (storage 1) */
   gh_cell_bf16 cell1_16, cell2_16;                  /* bf16 twins of cell1 / cell2 (storage 1) */
+  const void *att_word_w1_16, *att_word_w1t_16;     /* bf16 twins of self_att_word.linear1.weight and of its transpose (storage 1; NULL ok:
+                                                       the word attention's projections then round fp32 fragments in registers instead) */
 } gh_get_model;
 typedef struct gh_get_batch {
   int b, b1, l, r, n_max;                           /* claims, pairs, claim length, evidence length, evidence slots per claim */

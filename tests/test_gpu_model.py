@@ -514,7 +514,10 @@ def test_batch_shim_matches_fitter_depadding():
                                       T(inp["evd_counts"]), T(inp["doc_sources"]), T(inp["query_sources"]))
     assert isinstance(kf["docs_adj"], PackedAdj) and kf["docs_adj"].plan is not None
     assert np.array_equal(kf["doc_content_without_padding_evidences"].cpu().numpy(), inp["doc_ids"])
-    assert np.array_equal(kf["docs_adj"].to_dense().cpu().numpy(), inp["doc_adj"].astype(np.float32))
+    # convert_text's D^-1/2 A D^-1/2 is recognised: bit rows + dinv (the normalised mode of the native batches), no dense values
+    assert kf["docs_adj"].vals is None and kf["docs_adj"].dinv is not None
+    assert np.abs(kf["docs_adj"].to_dense().cpu().numpy() - inp["doc_adj"]).max() <= 2e-7
+    assert np.array_equal(kf["docs_adj"].to_dense().cpu().numpy() != 0, inp["doc_adj"] != 0)
     n_nodes = (inp["doc_ids"] >= 1).sum(1)
     assert kf["docs_adj"].plan.m_real == int(n_nodes.sum())
     assert np.array_equal(kf["docs_adj"].plan.goff.cpu().numpy(), np.concatenate([[0], np.cumsum(n_nodes)]))
@@ -525,12 +528,33 @@ def test_batch_shim_matches_fitter_depadding():
                                       T(inp["doc_sources"]), T(inp["query_sources"]))
     valid = np.arange(n)[None, :] < cnt0[:, None]
     assert np.array_equal(k0["doc_content_without_padding_evidences"].cpu().numpy(), doc0[valid])
-    assert np.array_equal(k0["docs_adj"].to_dense().cpu().numpy(), adj0[valid].astype(np.float32))
+    assert np.abs(k0["docs_adj"].to_dense().cpu().numpy() - adj0[valid]).max() <= 2e-7
+    # a hand-crafted adjacency that is NOT the normalised graph of its pattern (one real edge scaled): the whole batch takes the
+    # weighted mode with the exact fp32 values of every graph (second launch with force_vals), the node-compact plan stays
+    adjw = adj0.copy()
+    i1, j1 = np.argwhere(adjw[0, 0] != 0)[1]
+    adjw[0, 0, i1, j1] *= 1.01
+    kw = kargs_from_reference_tensors(T(inp["query_lens"]), T(doc0), T(adjw), T(inp["query_adj"]), T(cnt0),
+                                      T(inp["doc_sources"]), T(inp["query_sources"]))
+    assert kw["docs_adj"].vals is not None and kw["docs_adj"].plan is not None
+    assert np.array_equal(kw["docs_adj"].to_dense().cpu().numpy(), adjw[valid].astype(np.float32))
     adj0[0, 0, R - 1, 0] = 0.5      # (position R - 1 of this evidence is a padding node)
     assert doc0[0, 0, R - 1] == 0
     k1 = kargs_from_reference_tensors(T(inp["query_lens"]), T(doc0), T(adj0), T(inp["query_adj"]), T(cnt0),
                                       T(inp["doc_sources"]), T(inp["query_sources"]))
     assert k1["docs_adj"].plan is None and float(k1["docs_adj"].to_dense()[0, R - 1, 0]) == 0.5
+    assert k1["docs_adj"].vals is not None and np.array_equal(k1["docs_adj"].to_dense().cpu().numpy(), adj0[valid].astype(np.float32))
+    # one batch ahead on a side stream (batch.prefetch_reference): same kargs, in order
+    from get_amd.batch import prefetch_reference
+    items = [(T(inp["query_lens"]), T(inp["document"]), T(adj_padded), T(inp["query_adj"]), T(inp["evd_counts"]), T(inp["doc_sources"]),
+              T(inp["query_sources"])), (T(inp["query_lens"]), T(doc0), T(adjw), T(inp["query_adj"]), T(cnt0), T(inp["doc_sources"]),
+                                         T(inp["query_sources"]))] * 2
+    got = list(prefetch_reference(items))
+    assert len(got) == 4
+    for kk, ref_k in zip(got, [kf, kw, kf, kw]):
+        assert torch.equal(kk["doc_content_without_padding_evidences"], ref_k["doc_content_without_padding_evidences"])
+        assert torch.equal(kk["docs_adj"].to_dense(), ref_k["docs_adj"].to_dense())
+        assert (kk["docs_adj"].plan is None) == (ref_k["docs_adj"].plan is None)
     nb = NativeBatch(raw["claim_tokens"], raw["claim_len"], raw["evd_tokens"], raw["evd_len"], raw["evd_counts"],
                      raw["doc_sources"], raw["query_sources"], raw["labels"], window=cfg.window, device=DEV)
     q_ids, document, k2 = nb.inputs()

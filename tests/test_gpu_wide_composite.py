@@ -178,3 +178,44 @@ def test_clamped_labels_and_source_ids_are_counted():
     assert torch.isfinite(phi1).all() and torch.isfinite(model.article_source_embs.weight.grad).all()
     assert events(reset=True) == [0, 1, 2, 0]
     assert phi0.shape == phi1.shape
+
+
+def test_grad_mode_observables_release_the_arena_when_detached():
+    """in grad mode the attention weights carry the fused forward's grad_fn, whose context owns the multi-GB
+    activation arena until a backward runs.  A caller that keeps observables past the step without running a backward
+    (error analysis in grad mode) must detach() them: the detached copies pin nothing, while an un-detached weight tensor
+    keeps the arena alive (documented in INTEGRATION.md).  After a backward the arena goes back to the model's pool, which
+    a second model-less reference does not leak."""
+    import gc
+    from bench import build_workload
+    wl = build_workload(batch=16, n_evd=30, seed=92, device=DEV)
+    model, nb = wl["model"].train(False), wl["batches"][0]
+    q, d, k = nb.inputs()
+    torch.cuda.synchronize()
+    gc.collect()
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated()
+    phi, (ww, ew) = model(q, d, **dict(k, output_ranking=True))
+    torch.cuda.synchronize()
+    held_graph = torch.cuda.memory_allocated() - base
+    assert held_graph > 256 << 20, "the grad-mode forward should hold its activation arena"
+    kept = (phi.detach().clone(), ww.detach().clone(), ew.detach().clone())
+    del phi, ww, ew
+    gc.collect()
+    torch.cuda.synchronize()
+    held = torch.cuda.memory_allocated() - base
+    assert held < 64 << 20, f"detached observables still pin {held / 2**20:.0f} MiB"
+    # with a backward the arena returns to the model's pool (persistent across steps) and is reused by the next step
+    phi, (ww, ew) = model(q, d, **dict(k, output_ranking=True))
+    torch.nn.functional.cross_entropy(phi, nb.labels).backward()
+    del phi, ww, ew
+    gc.collect()
+    torch.cuda.synchronize()
+    pooled = torch.cuda.memory_allocated() - base
+    phi2 = model(q, d, **k)
+    torch.nn.functional.cross_entropy(phi2, nb.labels).backward()
+    del phi2
+    gc.collect()
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() - base <= pooled + (8 << 20), "the second step allocated new arenas instead of reusing the pool"
+    assert len(kept) == 3
