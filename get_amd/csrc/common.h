@@ -66,6 +66,10 @@ bool prof_enabled();
 void prof_begin(hipStream_t s, int tag);   // events are recorded only for tags selected by gh_profile_select
 void prof_end(int tag, double work, hipStream_t s);
 
+// gh_scorer_gsl with the projection arriving as score_parts partial tensors, score_stride floats apart (wide cell outputs)
+int scorer_gsl_impl(const uint64_t* bits, const float* dinv, const float* vals, const int32_t* goff, int pads_collapsed, const float* feat,
+                    const float* score_x, int score_parts, long long score_stride, const float* w_p, const float* gate, int n, int r, int h,
+                    int k, float* score, uint64_t* keep, float drop_p, uint32_t drop_seed, hipStream_t stream);
 int launch_ragged_plan(const int32_t* n_nodes, const int32_t* node_ids, int n, int r, int32_t* goff, int32_t* rowg, int32_t* src,
                        int32_t* cids, float* maskf, const int64_t* slot, int32_t* document, hipStream_t s, bool* scattered);   // *scattered: the document scatter rode along
 int launch_graph_build2(const int32_t* ta, const int32_t* la, int na, int ra, int32_t* ida, int32_t* nna, uint64_t* ba, float* da,
@@ -102,11 +106,13 @@ int launch_att_softmax_fwd(float* e, const float* mask, const float* right, cons
 int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w,
                            const int32_t* goff, int m_real, int b, int l, int dr, int heads, float* de, float* dright,
                            hipStream_t s, const int32_t* rowg = nullptr, float* dw_tmp = nullptr, int* dw_written = nullptr);
-// (rowg + dw_tmp [rows][heads] + dw_written: many-pair launches may take the row-balanced kernel, which leaves the raw
-//  dw in dw_tmp instead of de -- *dw_written says so -- and launch_att_dpre(dw_in = dw_tmp, weights, de_out = de) finishes de)
+// (rowg + dw_tmp [2][rows][heads] + dw_written: many-pair launches may take the row-balanced kernel, which leaves the raw
+//  dw in dw_tmp instead of de -- *dw_written = 1, or 2 when rows wider than 512 floats were split into two column ranges whose
+//  partial dw sit rows * heads floats apart -- and launch_att_dpre(dw_in = dw_tmp, weights, de_out = de, .., stride) finishes de)
 int launch_att_dpre(const float* de, const float* w2, const float* t, const int32_t* goff, int m_real, int b, int l,
                     int ha, int heads, float* dpre, float* du, float* dw2_part, hipStream_t s, const float* dw_in = nullptr,
-                    const float* weights = nullptr, float* de_out = nullptr, void* dpre16 = nullptr);      // dpre16: dpre as bf16 there instead
+                    const float* weights = nullptr, float* de_out = nullptr, void* dpre16 = nullptr,       // dpre16: dpre as bf16 there instead
+                    long long dw_range_stride = 0);      // > 0: dw_in = two column-range partials of att_rows_bwd (rows wider than 512 floats)
 
 // Where the gradient w.r.t. a GGNN cell's output goes when the GEMM that produces it applies that cell's gate head in its
 // epilogue (EPI_GATE_PRE): the cell's saved z / hh / xp and its dhp / dzp / dxp scratch (all [rows][h] fp32).
@@ -120,7 +126,11 @@ int cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* dinv,
                   const float* w_h1, const float* b_z0, const float* b_z1, const float* b_r0, const float* b_r1, const float* b_h0,
                   const float* b_h1, float* xp, float* a, float* z, float* rr, float* rx, float* hh, float* out, float drop_p,
                   uint32_t drop_seed, const float* score_w, float* score_x, float score_drop_p, uint32_t score_drop_seed,
-                  void* stream, int pad_out_dead = 0);      // pad_out_dead: nobody reads `out` of the padding rows (fused scorer only)
+                  void* stream, int pad_out_dead = 0,       // pad_out_dead: nobody reads `out` of the padding rows (fused scorer only)
+                  int* score_parts = nullptr,    // non-NULL: score_x holds ceil(h / block) x m_rows floats and a wide row's projection may
+                                                 // arrive as per-block partials; *score_parts = how many (1 = plain)
+                  float* xdrop = nullptr);       // bf16 storage, drop_p > 0: scratch [m_rows][din] bf16 that receives the masked (gathered) operand
+                                                 // rows of the projection; hand the same buffer to cell_bwd_impl
 int cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep, const int32_t* goff,
                   int m_real, const float* x, const int32_t* ids, int n, int r, int din, int h, const float* wt_p,
                   const float* wt_z0, const float* wt_z1, const float* wt_r0, const float* wt_r1, const float* wt_h0,
@@ -129,8 +139,9 @@ int cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const float* 
                   float* dw_p, float* dw_z0, float* dw_z1, float* dw_r0, float* dw_r1, float* dw_h0, float* dw_h1, float* db_z,
                   float* db_r, float* db_h, float* db_z1, float* db_r1, float* db_h1, float drop_p, uint32_t drop_seed, void* stream,
                   void* wstream, hipEvent_t ev_l1, hipEvent_t ev_agg,       // wstream: weight-gradient stream (NULL = stream)
-                  int pre_done, const GateFuse* next);   // pre_done: dhp / dzp / dxp already hold the gate head (skip gate_bwd_pre);
+                  int pre_done, const GateFuse* next,    // pre_done: dhp / dzp / dxp already hold the gate head (skip gate_bwd_pre);
                                                          // next: write the dX product into the previous cell's gate head instead of dx
+                  const float* xdrop = nullptr);         // the forward's masked operand rows (cell_fwd_impl xdrop), or NULL
 int att_fwd_impl(const float* left, int nl, const int32_t* rowu, const float* right, const float* mask, const int32_t* goff,
                  const int32_t* rowg, int m_real, int b, int l, int xl, int dr, int ha, int heads, const float* w1, const float* w2,
                  float* u, float* t, float* e, float* weights, float* attended, hipStream_t s, int u_mode = 0,

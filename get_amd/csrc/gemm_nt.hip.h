@@ -60,7 +60,9 @@ __device__ __forceinline__ unsigned nt_pack_bf16(float a, float b) {
 //         opt-in and experimental.  Upper bound with the weight pieces pre-split once per optimiser step (measured by feeding the
 //         raw fragment bits as "pieces", results invalid): 130.8 / 151.0 / 184.3 TF at K = 300 / 600 / 1200.
 template <int WM, int WN, int NI, int MI = 2, int MODE = 0>
-__global__ void __launch_bounds__(WM * WN * 64, (MI == 4 && NI == 4) ? 3 : (MI == 4 || MODE == 3 || MODE == 4) ? 2 : (WM == 2 && WN == 2 && NI == 5 && MODE == 0) ? 4 : 3)
+// (second argument = waves per SIMD the register budget must allow: 256-thread workgroups put one wave on every SIMD, so it is also
+//  the workgroups per CU; the 512-thread 128 x 256 tile puts two, and wants two workgroups = four waves per SIMD)
+__global__ void __launch_bounds__(WM * WN * 64, (MI == 4 && NI == 4 && WN == 4) ? 4 : (MI == 4 && NI == 4) ? 3 : (MI == 4 || MODE == 3 || MODE == 4) ? 2 : (WM == 2 && WN == 2 && NI == 5 && MODE == 0) ? 4 : 3)
 gemm_nt_kernel(const Launch L_byval) {
   (void)L_byval;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -470,12 +472,18 @@ gemm_nt_kernel(const Launch L_byval) {
     if constexpr (NST >= 3) {
       // NST stages, DMA prefetch distance NST - 1.  vmcnt counts DMA instructions: VM per K tile and wave, so "at most n
       // tiles still in flight" is vmcnt(n * VM); the barriers are bare (a __syncthreads() would drain the newest tiles too).
-      static_assert(SA * NW == NAI && SB * NW == NBI && (SA + SB == 6 || SA + SB == 4) && NST <= 4, "vmcnt immediates below");
+      static_assert(SA * NW == NAI && SB * NW == NBI && (SA + SB == 6 || SA + SB == 4 || SA + SB == 3) && NST <= 4, "vmcnt immediates below");
       constexpr int VM = SA + SB;
       auto wait_inflight = [&](int n) __attribute__((always_inline)) {      // n = tiles allowed to stay in flight (0..2)
-        if (n >= 2) { if constexpr (VM == 6) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); }
-        else if (n == 1) { if constexpr (VM == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (n >= 2) {
+          if constexpr (VM == 6) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+          else if constexpr (VM == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        } else if (n == 1) {
+          if constexpr (VM == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+          else if constexpr (VM == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       };
 #pragma unroll
       for (int i = 0; i < NST - 1; ++i)
@@ -821,6 +829,16 @@ gemm_nt_kernel(const Launch L_byval) {
             st8(C, o, ha, hb, io & 1);
             st8(out1, o, ya, yb, io & 2);
             if (c32) { *reinterpret_cast<float4*>(c32 + o) = ya; *reinterpret_cast<float4*>(c32 + o + 4) = yb; }
+            if (scorer) {    // the word scorer sees dropout(out) in fp32 (its own input dropout, wrapper.py:189-190): staged for the row reduction
+              float4 sa = ya, sb = yb;
+              if (drop_mode == 2) {
+                const unsigned idx = (unsigned)row * (unsigned)drop_ld + (unsigned)(P.drop_col0 + col);
+                sa = drop4(sa, drop_seed, idx, drop_thresh, drop_scale);
+                sb = drop4(sb, drop_seed, idx + 4u, drop_thresh, drop_scale);
+              }
+              *reinterpret_cast<float4*>(sp) = sa;
+              *reinterpret_cast<float4*>(sp + 4) = sb;
+            }
           } else if (E == EPI_BWD_DRX) {
             st8(C, o, drx4(wa, xa[j].a, xb[j].a), drx4(wb, xa[j].b, xb[j].b), io & 1);
             st8(out1, o, add4(xc[j].a, mul4(wa, xb[j].a)), add4(xc[j].b, mul4(wb, xb[j].b)), io & 2);
@@ -848,18 +866,21 @@ gemm_nt_kernel(const Launch L_byval) {
       }
     };
     constexpr bool WIDE8 = (MODE == 2) && (BN % 8 == 0);
+    bool done8 = false;
     if constexpr (WIDE8) {
-      if (!rowred && epi != EPI_ATT) {
+      if (epi != EPI_ATT) {      // (the fused scorer projection -- EPI_TANH_H with w2 -- stages its rows here and reduces them below)
         if (epi == EPI_STORE) pass8(std::integral_constant<int, EPI_STORE>{});
         else if (epi == EPI_GATE_PRE) pass8(std::integral_constant<int, EPI_GATE_PRE>{});
         else if (epi == EPI_SIGMOID_Z) pass8(std::integral_constant<int, EPI_SIGMOID_Z>{});
         else if (epi == EPI_SIGMOID_R) pass8(std::integral_constant<int, EPI_SIGMOID_R>{});
         else if (epi == EPI_TANH_H) pass8(std::integral_constant<int, EPI_TANH_H>{});
         else if (epi == EPI_BWD_DRX) pass8(std::integral_constant<int, EPI_BWD_DRX>{});
-        return;
+        if (!rowred) return;
+        done8 = true;
       }
     }
-    if (epi == EPI_STORE) pass(std::integral_constant<int, EPI_STORE>{});
+    if (done8) { /* rows staged by pass8 */ }
+    else if (epi == EPI_STORE) pass(std::integral_constant<int, EPI_STORE>{});
     else if (epi == EPI_SIGMOID_Z) pass(std::integral_constant<int, EPI_SIGMOID_Z>{});
     else if (epi == EPI_SIGMOID_R) pass(std::integral_constant<int, EPI_SIGMOID_R>{});
     else if (epi == EPI_TANH_H) pass(std::integral_constant<int, EPI_TANH_H>{});

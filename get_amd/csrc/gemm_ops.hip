@@ -506,6 +506,8 @@ struct Batch {
   bool wide = false;      // 128 x 256 bf16 tile (launch_cfg<2, 2, 8, 4>)
   bool wide256 = false;   // 256 x 256 bf16 tile, 8 waves (launch_cfg<4, 2, 8, 4>)
   bool wide128 = false;   // 128 x 128 bf16 tile, three workgroups per CU (launch_cfg<2, 2, 4, 4>; tool build: GH_BF16_TILE=128)
+  // (round 5: the same 128 x 256 tile on EIGHT waves -- 64 x 64 per wave, two workgroups = four waves per SIMD -- needs 146 VGPRs
+  //  for its 128-register budget: 82 spills, 16 instead of 12 ds_read_b128 per 32 MFMAs; configs[4] bf16 115.3 -> 99.6 K pairs/s. Removed.)
   // wide_bf16: every problem of this batch is a bf16-storage NT problem whose widths are multiples of 256 (h = 768)
   // site: 0 = never narrow; 1.. = call site id, narrow when the site's bit is set in the mask (tool build: GH_NT_NARROW)
   // n_hint: output width of the site's problems -- widths that 160-column blocks cover with less padding than 320-column
@@ -551,7 +553,9 @@ struct Batch {
     // row reductions need whole rows -- except the scorer's single dot product, which two column blocks may add up (e_atomic)
     const bool scorer_blocks = p.epi == EPI_TANH_H && p.w2 && p.N > bn && narrow && p.N <= 2 * bn;
     const bool att_blocks = p.epi == EPI_ATT && p.N > bn && e_block_stride > 0;
-    if ((p.epi == EPI_ATT || (p.epi == EPI_TANH_H && p.w2)) && p.N > bn && !scorer_blocks && !att_blocks) { err = hipErrorInvalidValue; return; }
+    // ... or, with a partial buffer per block (e_block_stride), any number of them: the scorer kernel adds the partials in block order
+    const bool scorer_parts = p.epi == EPI_TANH_H && p.w2 && p.N > bn && !scorer_blocks && e_block_stride > 0;
+    if ((p.epi == EPI_ATT || (p.epi == EPI_TANH_H && p.w2)) && p.N > bn && !scorer_blocks && !att_blocks && !scorer_parts) { err = hipErrorInvalidValue; return; }
     for (int n0 = 0; n0 < p.N; n0 += bn) {
       Problem q = p;
       q.N = (p.N - n0 < bn) ? p.N - n0 : bn;
@@ -577,6 +581,7 @@ struct Batch {
       if (q.in2) q.in2 = adv(q.in2, (size_t)n0, q.io & 16);
       if (q.out2) q.out2 = (float*)adv(q.out2, (size_t)n0, q.io & 32);
       if (scorer_blocks) { q.w2 += n0; q.e_atomic = 1; }
+      if (scorer_parts) { q.w2 += n0; q.e = p.e + (size_t)(n0 / bn) * (size_t)e_block_stride; q.e_atomic = 2; }
       if (att_blocks) { q.w2 += n0; q.u += n0; q.e = p.e + (size_t)(n0 / bn) * (size_t)e_block_stride; q.e_atomic = 2; }      // (2: own partial buffer, plain stores)
       if (L.nprob == GH_MAX_PROBLEMS) flush();
       L.p[L.nprob++] = q;
@@ -797,10 +802,12 @@ int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* d
                                 float* xp, float* a, float* z, float* rr, float* rx, float* hh, float* out,
                                 float drop_p, uint32_t drop_seed,
                                 const float* score_w, float* score_x, float score_drop_p, uint32_t score_drop_seed,
-                                gh_stream_t stream, int pad_out_dead) {
+                                gh_stream_t stream, int pad_out_dead, int* score_parts, float* xdrop) {
   hipStream_t s = (hipStream_t)stream;
+  if (score_parts) *score_parts = 1;
   GH_REQUIRE(n > 0 && r > 0 && din > 0 && h > 0, "ggnn_cell_fwd: bad sizes n=%d r=%d din=%d h=%d", n, r, din, h);
-  GH_REQUIRE(!bf || (din % 8 == 0 && h % 8 == 0 && out32), "ggnn_cell_fwd_bf16: needs din %% 8 == 0, h %% 8 == 0 (din=%d h=%d) and out32", din, h);
+  // (out32 may be NULL when the fused scorer projection is the only fp32 consumer of the cell output: composite forward, first cell)
+  GH_REQUIRE(!bf || (din % 8 == 0 && h % 8 == 0 && (out32 || score_w)), "ggnn_cell_fwd_bf16: needs din %% 8 == 0, h %% 8 == 0 (din=%d h=%d) and out32", din, h);
   if (!goff) { m_real = n * r; m_rows = n * r; }
   GH_REQUIRE(m_real >= 0 && m_real <= m_rows && m_rows <= n * r, "ggnn_cell_fwd: node-compact rows %d/%d do not fit n*r=%d", m_real, m_rows, n * r);
   const int M = m_rows;
@@ -809,11 +816,21 @@ int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* d
   GH_REQUIRE((score_w == nullptr) == (score_x == nullptr), "ggnn_cell_fwd: score_w and score_x come together");
   GH_REQUIRE(score_drop_p >= 0.f && score_drop_p < 1.f, "ggnn_cell_fwd: scorer dropout p=%f not in [0,1)", score_drop_p);
   const bool wide = bf && h % 256 == 0;      // 128 x 256 bf16 tiles cover the width exactly (h = 768)
+  // bf16 storage with dropout: masking the A fragments costs ~100 VALU instructions per 16-row tile and K tile (eight hashes on
+  // packed bf16 pairs) against 8 MFMAs -- the projection ran at half the rate of the same product without a mask (configs[4]:
+  // 376 us against ~190).  With a scratch row buffer from the caller (xdrop [m_rows][din] bf16) the masked operand -- gathered
+  // embedding rows included -- is materialised once by the streaming kernel the backward used anyway (launch_gather_rows), the
+  // projection reads it as a plain operand, and the backward's dW_proj re-uses it instead of gathering again.
+  const bool pre_drop = bf && xdrop && drop_p > 0.f && din <= h;
+  if (pre_drop) {
+    if (int e = launch_gather_rows(x, ids, xdrop, M, din, s, drop_p, drop_seed, 1)) return e;
+  }
   {  // xp = dropout(x) Wp^T   (wrapper.py:189-191); embedding rows gathered by the loader, the dropout mask applied to the fragments
     Batch b(false, M, s, wide, 7, h);
-    Problem p = gemm_problem(M, h, EPI_STORE, xp, h, x, din, w_p, din, din, ids, bf);
+    Problem p = pre_drop ? gemm_problem(M, h, EPI_STORE, xp, h, xdrop, din, w_p, din, din, nullptr, bf)
+                         : gemm_problem(M, h, EPI_STORE, xp, h, x, din, w_p, din, din, ids, bf);
     p.io = bf ? 1 : 0;
-    set_dropout(p, 1, din, drop_p, drop_seed);
+    if (!pre_drop) set_dropout(p, 1, din, drop_p, drop_seed);
     b.add(p);
     b.flush();
     GH_REQUIRE(b.err != hipErrorInvalidValue || drop_p == 0.f, "ggnn_cell_fwd: fused dropout needs float4-shaped rows (din=%d, h=%d)", din, h);
@@ -868,8 +885,14 @@ int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* d
     GH_CHECK_HIP(b.err);
   }
   {  // h gate and the convex update (:202-206); optionally the GSL word scorer's projection of the result (:167)
-    Batch b(false, M, s, wide && !score_w, 2, h);
-    if (score_w && b.narrow) {
+    // score_parts (caller provides score_x for ceil(h / column block) x M floats): rows wider than two column blocks keep their
+    // tile and every block writes its share of the projection to a partial of its own ([block][M]; gh_scorer_gsl score_parts)
+    const bool parts_ok = score_w && score_parts != nullptr;
+    Batch b(false, M, s, wide && (!score_w || parts_ok), 2, h);
+    if (parts_ok && h > b.bn && !(b.narrow && h <= 2 * b.bn)) {
+      b.e_block_stride = M;
+      *score_parts = (h + b.bn - 1) / b.bn;
+    } else if (score_w && b.narrow) {
       if (h > 2 * b.bn) { b.narrow = false; b.bn = 320; }      // more than two column blocks: whole rows on the 320-wide tile
       else if (h > b.bn && !(zf_done && zf.p1 == score_x)) GH_CHECK_HIP(hipMemsetAsync(score_x, 0, sizeof(float) * (size_t)M, s));   // two blocks add their partial dot products
     }
@@ -906,7 +929,7 @@ extern "C" int gh_ggnn_cell_fwd(const uint64_t* bits, const float* dinv, const f
                                 gh_stream_t stream) {
   return cell_fwd_impl(0, nullptr, bits, dinv, vals, keep, goff, m_real, m_rows, x, ids, n, r, din, h, w_p, w_z0, w_z1, w_r0, w_r1,
                        w_h0, w_h1, b_z0, b_z1, b_r0, b_r1, b_h0, b_h1, xp, a, z, rr, rx, hh, out, drop_p, drop_seed, score_w,
-                       score_x, score_drop_p, score_drop_seed, stream);
+                       score_x, score_drop_p, score_drop_seed, stream, 0, nullptr, nullptr);
 }
 
 extern "C" int gh_ggnn_cell_fwd_bf16(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
@@ -924,7 +947,7 @@ extern "C" int gh_ggnn_cell_fwd_bf16(const uint64_t* bits, const float* dinv, co
   typedef float* mf;
   return cell_fwd_impl(1, out32, bits, dinv, vals, keep, goff, m_real, m_rows, (cf)x, ids, n, r, din, h, (cf)w_p, (cf)w_z0, (cf)w_z1,
                        (cf)w_r0, (cf)w_r1, (cf)w_h0, (cf)w_h1, b_z0, b_z1, b_r0, b_r1, b_h0, b_h1, (mf)xp, (mf)a, (mf)z, (mf)rr,
-                       (mf)rx, (mf)hh, (mf)out, drop_p, drop_seed, score_w, score_x, score_drop_p, score_drop_seed, stream);
+                       (mf)rx, (mf)hh, (mf)out, drop_p, drop_seed, score_w, score_x, score_drop_p, score_drop_seed, stream, 0, nullptr, nullptr);
 }
 
 // bf: bf16 storage pipeline -- x / table, wt_*, the saved xp..hh and the scratch dhp..da hold bf16; g, dx and every weight /
@@ -941,7 +964,7 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
                                 float* dw_h0, float* dw_h1, float* db_z, float* db_r, float* db_h,
                                 float* db_z1, float* db_r1, float* db_h1, float drop_p, uint32_t drop_seed,
                                 gh_stream_t stream, gh_stream_t wstream, hipEvent_t ev_l1, hipEvent_t ev_agg,
-                                int pre_done, const GateFuse* next) {
+                                int pre_done, const GateFuse* next, const float* xdrop) {
   hipStream_t s = (hipStream_t)stream;
   // Weight-gradient stream (composite backward, model_ops.hip): the split-K weight-gradient GEMMs only need dzp / drp / dhp
   // (final after the first dX launch) and, for dW_proj, dxp (final after the aggregation).  On their own stream they run
@@ -1035,7 +1058,10 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
       b.add(tn_problem(h, h, dw_h0, h, dhp, h, a, h, M, nullptr, bf));  if (cs) b.want_colsum(db_h, db_h1);
       b.add(tn_problem(h, h, dw_h1, h, dhp, h, rx, h, M, nullptr, bf));
     }
-    if ((ids || drop_p > 0.f || bf) && din <= h) {
+    if (bf && xdrop && drop_p > 0.f && din <= h) {
+      // the forward left the masked (and gathered) operand rows in xdrop (cell_fwd_impl pre_drop): no second gather pass
+      b.add(tn_problem(h, din, dw_p, din, dxp, h, xdrop, din, M, nullptr, bf));
+    } else if ((ids || drop_p > 0.f || bf) && din <= h) {
       // operand rows materialised once into the (now free) `da` scratch -- embedding gather and/or the forward's
       // dropout mask applied in that one streaming pass -- so the split-K GEMM loader stays a plain copy
       if (int e = launch_gather_rows(x, ids, da, M, din, sw, drop_p, drop_seed, bf)) return e;
@@ -1066,7 +1092,7 @@ extern "C" int gh_ggnn_cell_bwd(const uint64_t* bits, const float* dinv, const f
                                 gh_stream_t stream) {
   return cell_bwd_impl(0, bits, dinv, vals, keep, goff, m_real, x, ids, n, r, din, h, wt_p, wt_z0, wt_z1, wt_r0, wt_r1, wt_h0, wt_h1,
                        xp, a, z, rr, rx, hh, g, dhp, dzp, drp, dxp, da, dx, dw_p, dw_z0, dw_z1, dw_r0, dw_r1, dw_h0, dw_h1,
-                       db_z, db_r, db_h, db_z1, db_r1, db_h1, drop_p, drop_seed, stream, nullptr, nullptr, nullptr, 0, nullptr);
+                       db_z, db_r, db_h, db_z1, db_r1, db_h1, drop_p, drop_seed, stream, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
 }
 
 extern "C" int gh_ggnn_cell_bwd_bf16(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
@@ -1086,7 +1112,7 @@ extern "C" int gh_ggnn_cell_bwd_bf16(const uint64_t* bits, const float* dinv, co
   return cell_bwd_impl(1, bits, dinv, vals, keep, goff, m_real, (cf)x, ids, n, r, din, h, (cf)wt_p, (cf)wt_z0, (cf)wt_z1, (cf)wt_r0,
                        (cf)wt_r1, (cf)wt_h0, (cf)wt_h1, (cf)xp, (cf)a, (cf)z, (cf)rr, (cf)rx, (cf)hh, g, (mf)dhp, (mf)dzp, (mf)drp,
                        (mf)dxp, (mf)da, dx, dw_p, dw_z0, dw_z1, dw_r0, dw_r1, dw_h0, dw_h1, db_z, db_r, db_h, db_z1, db_r1,
-                       db_h1, drop_p, drop_seed, stream, nullptr, nullptr, nullptr, 0, nullptr);
+                       db_h1, drop_p, drop_seed, stream, nullptr, nullptr, nullptr, 0, nullptr, nullptr);
 }
 
 // Concat attention, generalised for the composite model entry points (model_ops.hip):
@@ -1213,7 +1239,8 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
   const bool late = dleft_late && dw2_buf && ha % 4 == 0;      // partials in the caller's buffer, reduced by the second call
   dw2_part = late ? dw2_buf : ((wsp.p && dw2_bytes <= wsp.bytes && ha % 4 == 0) ? wsp.p : nullptr);
   if (int e = launch_att_dpre(de, w2, t, goff, m_real, b, l, ha, heads, dpre, du, dw2_part, s, dw_written ? dw_tmp : nullptr,
-                              dw_written ? weights : nullptr, dw_written ? de : nullptr, dpre16)) return e;
+                              dw_written ? weights : nullptr, dw_written ? de : nullptr, dpre16,
+                              dw_written == 2 ? (long long)m_real * heads : 0)) return e;
   if (dw2_part && !late) {
     ReduceArgs R;
     R.n = 1;

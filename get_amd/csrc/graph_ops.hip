@@ -1015,7 +1015,7 @@ __global__ void __launch_bounds__(256)
 scorer_gsl_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
                   const int32_t* __restrict__ goff, const float* __restrict__ feat, const float* __restrict__ xs_in,
                   const float* __restrict__ w_p, const float* __restrict__ gate, int R, int H, int k, int pads_collapsed, float* __restrict__ score, uint64_t* __restrict__ keep, unsigned drop_thresh,
-                  float drop_scale, unsigned drop_seed) {
+                  float drop_scale, unsigned drop_seed, int xs_parts, long long xs_stride) {
   __shared__ float xs[MAX_R];
   __shared__ float ss[MAX_R];
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1031,7 +1031,12 @@ scorer_gsl_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ d
   // x_j = feat_j . w_p   (proj, no bias)
   const bool v4 = (H % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat) & 15) == 0) && ((reinterpret_cast<uintptr_t>(w_p) & 15) == 0);
   if (xs_in) {      // projection already done by the producing cell's epilogue (gh_ggnn_cell_fwd score_x): one float per node
-    if (tid < R) xs[tid] = xs_in[(unsigned)(tid < NR ? row0 + tid : (pads_collapsed ? pad0 : pad0 + tid))];
+    if (tid < R) {      // (xs_parts > 1: one partial per column block of a wide cell output, added in block order)
+      const unsigned xr = (unsigned)(tid < NR ? row0 + tid : (pads_collapsed ? pad0 : pad0 + tid));
+      float v = xs_in[xr];
+      for (int pp = 1; pp < xs_parts; ++pp) v += xs_in[(size_t)pp * xs_stride + xr];
+      xs[tid] = v;
+    }
   } else {
   for (int j = wave; j < R; j += 4) {
     float acc = 0.f;
@@ -1201,7 +1206,15 @@ extern "C" int gh_spmm(const uint64_t* bits, const float* dinv, const float* val
 extern "C" int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const int32_t* goff,
                              int pads_collapsed, const float* feat, const float* score_x, const float* w_p, const float* gate, int n, int r, int h, int k, float* score,
                              uint64_t* keep, float drop_p, uint32_t drop_seed, gh_stream_t stream) {
+  return scorer_gsl_impl(bits, dinv, vals, goff, pads_collapsed, feat, score_x, 1, 0, w_p, gate, n, r, h, k, score, keep, drop_p, drop_seed,
+                         (hipStream_t)stream);
+}
+
+int gh::scorer_gsl_impl(const uint64_t* bits, const float* dinv, const float* vals, const int32_t* goff, int pads_collapsed, const float* feat,
+                        const float* score_x, int score_parts, long long score_stride, const float* w_p, const float* gate, int n, int r, int h,
+                        int k, float* score, uint64_t* keep, float drop_p, uint32_t drop_seed, hipStream_t stream) {
   GH_REQUIRE(r > 0 && r <= MAX_R, "scorer_gsl: r=%d not in [1,%d]", r, MAX_R);
+  GH_REQUIRE(score_parts >= 1 && score_parts <= 16, "scorer_gsl: %d score partials", score_parts);
   GH_REQUIRE(vals || dinv, "scorer_gsl: need dinv or vals");
   if (n <= 0) return 0;
   prof_begin((hipStream_t)stream, PROF_SCORER_GSL);
@@ -1211,7 +1224,8 @@ extern "C" int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const floa
   const unsigned thresh = drop_p > 0.f ? (th >= 4294967295.0 ? 4294967295u : (unsigned)th) : 0u;
   GH_REQUIRE((feat != nullptr) != (score_x != nullptr), "scorer_gsl: exactly one of feat / score_x");
   hipLaunchKernelGGL(scorer_gsl_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, bits, dinv, vals, goff, feat, score_x,
-                     w_p, gate, r, h, k, (goff && pads_collapsed) ? 1 : 0, score, keep, thresh, 1.0f / (1.0f - drop_p), drop_seed);
+                     w_p, gate, r, h, k, (goff && pads_collapsed) ? 1 : 0, score, keep, thresh, 1.0f / (1.0f - drop_p), drop_seed,
+                     score_parts, score_stride);
   prof_end(PROF_SCORER_GSL, (double)n * ((feat ? 4.0 * r * h : 4.0 * r) + 8.0 * r * words_for(r) + 8.0 * r + 8.0 * words_for(r)),
            (hipStream_t)stream);
   GH_LAUNCH_CHECK();

@@ -221,14 +221,15 @@ colsum_kernel(const float* __restrict__ a, const float* __restrict__ b, const fl
   }
 }
 // workspace variant: float4 columns x RL row lanes per block, partial sums to scratch, one final pass.
-constexpr int CS2_ROWS = 128;
+constexpr int CS2_ROWS = 128;      // rows per block of activation-sized inputs; few-row inputs (claim cell at h = 768: 960 rows x 192 float4
+                                   // columns, ONE row lane per block) take 16 -- eight blocks walked 128 rows each in 125 us
 __global__ void colsum_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
-                                      float* __restrict__ ws, int m, int h, int RL) {
+                                      float* __restrict__ ws, int m, int h, int RL, int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   float4* red = reinterpret_cast<float4*>(dsm);          // [3][RL][h/4]
   const int n4 = h / 4;
   const int c4 = threadIdx.x % n4, rl = threadIdx.x / n4;
-  const int r0 = blockIdx.x * CS2_ROWS, r1 = min(m, r0 + CS2_ROWS);
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(m, r0 + rows_per_block);
   float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa, sc = sa;
   if (rl < RL) {
 #pragma unroll 4
@@ -283,7 +284,8 @@ int launch_colsum3(const float* a, const float* b, const float* c, float* oa, fl
                    hipStream_t s, float* oa2, float* ob2, float* oc2) {
   if (m <= 0) return 0;
   const uintptr_t al = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c;
-  const int nblk = (m + CS2_ROWS - 1) / CS2_ROWS;
+  const int rpb = m <= 8192 ? 16 : CS2_ROWS;
+  const int nblk = (m + rpb - 1) / rpb;
   const size_t need = (size_t)nblk * 3 * h * sizeof(float);
   const double bytes = 4.0 * (double)m * h * (1 + (b != nullptr) + (c != nullptr));
   const Workspace wsp = workspace_for(s);
@@ -294,7 +296,7 @@ int launch_colsum3(const float* a, const float* b, const float* c, float* oa, fl
     const int threads = ((n4 * RL + 63) / 64) * 64;
     prof_begin(s, PROF_COLSUM);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(threads), (size_t)3 * RL * h * sizeof(float), s, a, b, c,
-                       g_cs_ws, m, h, RL);
+                       g_cs_ws, m, h, RL, rpb);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((3 * h + 63) / 64), dim3(256), 0, s, g_cs_ws, nblk, h, oa, ob, oc, oa2, ob2, oc2);
     prof_end(PROF_COLSUM, bytes, s);
     GH_LAUNCH_CHECK();
@@ -694,16 +696,22 @@ template <int CT>      // exact number of heads
 __global__ void __launch_bounds__(256, CT <= 5 ? 4 : 3)
 att_rows_bwd_kernel(const float* __restrict__ right, const float* __restrict__ weights, const float* __restrict__ g_att,
                     const float* __restrict__ g_w, const int32_t* __restrict__ rowg, int Lmax, int Dr, int C, int M,
-                    int rows_per_wave, float* __restrict__ dw_out, float* __restrict__ dright) {
+                    int rows_per_wave, float* __restrict__ dw_out, float* __restrict__ dright, int D4h) {
+  // Rows wider than 512 floats (h = 768): blockIdx.y selects a column range of D4h float4 columns; every range writes its dright
+  // columns and its PARTIAL dw (dw_out + range * M * C; att_dpre's prologue adds the ranges in order), g_w rides with range 0.
   constexpr int NCH = 2;
   const int lane = threadIdx.x & 63;
   const int gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int r0 = gw * rows_per_wave, r1 = min(M, r0 + rows_per_wave);
   if (r0 >= r1) return;
   const int D4 = Dr / 4;
+  const int col0 = blockIdx.y * D4h;
+  const int ncol = min(D4h, D4 - col0);           // float4 columns of this range
+  dw_out += (size_t)blockIdx.y * (size_t)M * CT;
+  if (blockIdx.y > 0) g_w = nullptr;
   int dcl[NCH];
 #pragma unroll
-  for (int h = 0; h < NCH; ++h) dcl[h] = min(lane + 64 * h, D4 - 1);
+  for (int h = 0; h < NCH; ++h) dcl[h] = col0 + min(lane + 64 * h, ncol - 1);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4* rp = reinterpret_cast<const float4*>(right);
   // this wave's softmax weights and pair ids, staged once into its private LDS region: a per-row global load in the
@@ -742,7 +750,7 @@ att_rows_bwd_kernel(const float* __restrict__ right, const float* __restrict__ w
           const float4 v = gp[(size_t)dcl[h] * CT + j];
           G[4 * j] = v.x; G[4 * j + 1] = v.y; G[4 * j + 2] = v.z; G[4 * j + 3] = v.w;
         }
-        const bool live = lane + 64 * h < D4;
+        const bool live = lane + 64 * h < ncol;
 #pragma unroll
         for (int c = 0; c < CT; ++c)
           // element (d = 4 d4 + k, c) sits at G[k * C + c] (the kernel is instantiated for the exact head count: C == CT)
@@ -774,7 +782,7 @@ att_rows_bwd_kernel(const float* __restrict__ right, const float* __restrict__ w
     float4* dp = reinterpret_cast<float4*>(dright + (size_t)l * Dr);
 #pragma unroll
     for (int h = 0; h < NCH; ++h)
-      if (lane + 64 * h < D4) dp[lane + 64 * h] = aa[h];
+      if (lane + 64 * h < ncol) dp[col0 + lane + 64 * h] = aa[h];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       const float v = wave_sum_dpp(pa[c]);
@@ -800,7 +808,8 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
   if (dw_written) *dw_written = 0;
   // many pairs, rows that fit two float4 chunks per lane, 16-byte aligned g_att rows: the row-balanced kernel; de is then
   // finished by att_dpre's prologue (launch_att_dpre with dw_in)
-  if (dw_tmp && dw_written && dr / 4 <= 128 && (goff == nullptr || rowg != nullptr) &&
+  // (rows of up to 1024 floats: two column ranges, each a grid row of its own; *dw_written = the number of ranges)
+  if (dw_tmp && dw_written && dr / 4 <= 256 && (goff == nullptr || rowg != nullptr) &&
       (reinterpret_cast<uintptr_t>(g_att) & 15) == 0 && heads >= 1 && heads <= 8) {
     const int M = goff ? m_real : b * l;
     if (M <= 0) return 0;
@@ -817,12 +826,14 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
                                        (const void*)att_rows_bwd_kernel<7>, (const void*)att_rows_bwd_kernel<8>};
     const void* fn = fns[heads - 1];
     int Mv = M, rpwv = rpw;
+    const int ranges = dr / 4 > 128 ? 2 : 1;
+    int d4h = (dr / 4 + ranges - 1) / ranges;
     void* args[] = {(void*)&right, (void*)&weights, (void*)&g_att, (void*)&g_w, (void*)&rowg, (void*)&l, (void*)&dr, (void*)&heads,
-                    (void*)&Mv, (void*)&rpwv, (void*)&dw_tmp, (void*)&dright};
-    (void)hipLaunchKernel(fn, dim3(nwg), dim3(256), args, lds_rows, s);
+                    (void*)&Mv, (void*)&rpwv, (void*)&dw_tmp, (void*)&dright, (void*)&d4h};
+    (void)hipLaunchKernel(fn, dim3(nwg, ranges), dim3(256), args, lds_rows, s);
     prof_end(ptag, 4.0 * (2.0 * M * dr + 3.0 * M * heads + (double)b * dr * heads), s);
     GH_LAUNCH_CHECK();
-    *dw_written = 1;
+    *dw_written = ranges;
     return 0;
   }
   const size_t lds = ((size_t)dr * heads + 2 * (size_t)l * heads) * 4;
@@ -853,7 +864,8 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
                                 const int32_t* __restrict__ goff, int Lmax, int Ha, int C, int RL, int S4,
                                 float* __restrict__ dpre, float* __restrict__ du, float* __restrict__ dw2_part,
                                 const float* __restrict__ dw_in, const float* __restrict__ wts, float* __restrict__ de_out,
-                                unsigned short* __restrict__ dpre16) {      // dpre16 != NULL: dpre is written THERE as bf16 (RNE) instead
+                                unsigned short* __restrict__ dpre16,        // dpre16 != NULL: dpre is written THERE as bf16 (RNE) instead
+                                long long dw_range_stride) {                // > 0: dw_in holds two column-range partials, this many floats apart
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   float4* red = reinterpret_cast<float4*>(dsm);           // [RL][1 + C][S4]
   const int b = blockIdx.x;
@@ -882,7 +894,11 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
   if (dw_in) {
     // second half of the softmax backward, per pair (att_rows_bwd_kernel left the raw dw): de = w (dw - sum_l w dw)
     float* wl = des + (size_t)Lmax * C;                    // [L][C] softmax weights
-    for (int i = threadIdx.x; i < L * C; i += blockDim.x) { des[i] = dw_in[(size_t)row0 * C + i]; wl[i] = wts[(size_t)row0 * C + i]; }
+    for (int i = threadIdx.x; i < L * C; i += blockDim.x) {
+      float v = dw_in[(size_t)row0 * C + i];
+      if (dw_range_stride > 0) v += dw_in[(size_t)dw_range_stride + (size_t)row0 * C + i];
+      des[i] = v; wl[i] = wts[(size_t)row0 * C + i];
+    }
     __syncthreads();
     float* sums = wl + (size_t)Lmax * C;                   // [C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
@@ -971,7 +987,7 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
 
 int launch_att_dpre(const float* de, const float* w2, const float* t, const int32_t* goff, int m_real, int b, int l,
                     int ha, int heads, float* dpre, float* du, float* dw2_part, hipStream_t s, const float* dw_in,
-                    const float* weights, float* de_out, void* dpre16) {
+                    const float* weights, float* de_out, void* dpre16, long long dw_range_stride) {
   GH_REQUIRE(ha % 4 == 0 && ha / 4 <= 256, "att_dpre: attention hidden %d must be a multiple of 4 and <= 1024", ha);
   const int n4 = ha / 4;
   // column slabs of <= 32 float4 (512 B of a row per lane group: whole 128-byte lines), ~3 slabs at ha = 300; few pairs
@@ -989,7 +1005,7 @@ int launch_att_dpre(const float* de, const float* w2, const float* t, const int3
   const size_t lds = (size_t)RL * (1 + heads) * S4 * 16 + (size_t)l * heads * 4 * (dw_in ? 2 : 1) + (dw_in ? 64 : 0);
   prof_begin(s, b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_DPRE);
   hipLaunchKernelGGL(att_dpre_kernel, dim3(b, nsl), dim3(threads), lds, s, de, w2, t, goff, l, ha, heads, RL, S4, dpre, du, dw2_part,
-                     dw_in, weights, de_out, (unsigned short*)dpre16);
+                     dw_in, weights, de_out, (unsigned short*)dpre16, dw_range_stride);
   const double rows = goff ? (double)m_real : (double)b * l;
   prof_end(b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_DPRE, 4.0 * (2.0 * rows * ha + rows * heads + (double)b * ha), s);
   GH_LAUNCH_CHECK();

@@ -21,7 +21,7 @@ struct Dims {
   bool fuse_scorer;   // the GSL scorer's projection rides in the first cell's last epilogue (whole rows in <= 2 column blocks: h <= 320)
 };
 // out32: the fp32 cell output (== out in fp32 storage; a buffer of its own beside the bf16 twin `out` in bf16 storage)
-struct CellBuf { int64_t xp, a, z, rr, rx, hh, out, out32; };
+struct CellBuf { int64_t xp, a, z, rr, rx, hh, out, out32, xdrop; };      // xdrop: bf16 storage + dropout: the projection's masked operand rows (-1: none)
 struct FwdBuf {
   int64_t offsets, pair2claim, has, lens_eff, rowc, maskf_p;
   CellBuf q, c1, c2;
@@ -80,11 +80,12 @@ static int make_dims(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d) {
   return 0;
 }
 
-static void cell_buf(Bump& b, CellBuf& c, int64_t rows, int H, bool bf = false) {
+static void cell_buf(Bump& b, CellBuf& c, int64_t rows, int H, bool bf = false, bool need32 = true, int64_t drop_din = 0) {
+  c.xdrop = (bf && drop_din > 0) ? b.take(rows * drop_din / 2) : -1;
   const int64_t e = bf ? rows * H / 2 : rows * H;      // floats per saved tensor (bf16 storage: two values per float slot)
   c.xp = b.take(e); c.a = b.take(e); c.z = b.take(e); c.rr = b.take(e);
   c.rx = b.take(e); c.hh = b.take(e); c.out = b.take(e);
-  c.out32 = bf ? b.take(rows * H) : c.out;
+  c.out32 = bf ? (need32 ? b.take(rows * H) : -1) : c.out;      // (-1: no fp32 consumer -- the first cell when its scorer projection is fused)
 }
 
 static int layout(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d, FwdBuf& f, BwdBuf& w) {
@@ -106,9 +107,12 @@ static int layout(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d, FwdBu
   }
   cell_buf(b, f.q, d.Mq, d.H);
   f.q_repr = b.take((int64_t)d.B * d.H);
-  cell_buf(b, f.c1, d.M1, d.H, d.bf);
-  f.score_x = b.take(d.M1);
-  cell_buf(b, f.c2, d.Mr, d.H, d.bf);
+  // bf16 storage: the first cell's fp32 output would feed the scorer's projection only, which the cell's last epilogue computes
+  // itself (per column block when h > 320: up to 8 partials) -- no fp32 copy of that output exists then
+  const bool pre_drop = d.bf && Ba->drop_gnn > 0.f;
+  cell_buf(b, f.c1, d.M1, d.H, d.bf, !d.bf, pre_drop ? d.D : 0);
+  f.score_x = b.take((int64_t)d.M1 * ((d.fuse_scorer || !d.bf) ? 1 : 8));
+  cell_buf(b, f.c2, d.Mr, d.H, d.bf, true, pre_drop ? d.H : 0);
   f.uw = b.take((int64_t)d.B * d.H); f.tw = b.take((int64_t)d.Mr * d.H); f.ew = b.take((int64_t)d.Mr * d.hw);
   f.avg = b.take((int64_t)d.B1 * d.Xa);
   f.new_left = d.cs > 0 ? b.take((int64_t)d.B * d.Xl) : f.q_repr;
@@ -122,7 +126,7 @@ static int layout(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d, FwdBu
   w.de_e = c.take((int64_t)d.B * d.n * d.he); w.dpre_e = c.take((int64_t)d.B * d.n * d.H); w.du_e = c.take((int64_t)d.B * d.H);
   w.dright_e = c.take((int64_t)d.B * d.n * d.Dre);
   w.d_avg = c.take((int64_t)d.B1 * d.Xa);
-  w.de_w = c.take((int64_t)d.Mr * d.hw); w.dw_w = c.take((int64_t)d.Mr * d.hw); w.dpre_w = c.take((int64_t)d.Mr * d.H); w.du_w = c.take((int64_t)d.B1 * d.H);
+  w.de_w = c.take((int64_t)d.Mr * d.hw); w.dw_w = c.take((int64_t)2 * d.Mr * d.hw); w.dpre_w = c.take((int64_t)d.Mr * d.H); w.du_w = c.take((int64_t)d.B1 * d.H);
   w.du_c = c.take((int64_t)d.B * d.H);
   w.d_q = d.cs > 0 ? c.take((int64_t)d.B * d.H) : w.d_new_left;
   w.g2 = c.take((int64_t)d.Mr * d.H);
@@ -341,13 +345,13 @@ static inline int32_t* I32(float* A, int64_t off) { return reinterpret_cast<int3
 static int cell_fwd(const gh_cell_params& c, const gh_cell_bf16* c16, const CellBuf& cb, float* A, const uint64_t* bits, const float* dinv,
                     const float* vals, const uint64_t* keep, const int32_t* goff, int m_real, int m_rows, const float* x, const int32_t* ids,
                     int n, int r, int din, int h, float drop_p, uint32_t seed, const float* score_w, float* score_x, float sdrop,
-                    uint32_t sseed, hipStream_t s, int pad_out_dead = 0) {
+                    uint32_t sseed, hipStream_t s, int pad_out_dead = 0, int* score_parts = nullptr) {
   typedef const float* cf;
   if (c16)
-    return cell_fwd_impl(1, A + cb.out32, bits, dinv, vals, keep, goff, m_real, m_rows, x, ids, n, r, din, h, (cf)c16->w_p, (cf)c16->w_z0,
+    return cell_fwd_impl(1, cb.out32 >= 0 ? A + cb.out32 : nullptr, bits, dinv, vals, keep, goff, m_real, m_rows, x, ids, n, r, din, h, (cf)c16->w_p, (cf)c16->w_z0,
                          (cf)c16->w_z1, (cf)c16->w_r0, (cf)c16->w_r1, (cf)c16->w_h0, (cf)c16->w_h1, c.b_z0, c.b_z1, c.b_r0, c.b_r1, c.b_h0,
                          c.b_h1, A + cb.xp, A + cb.a, A + cb.z, A + cb.rr, A + cb.rx, A + cb.hh, A + cb.out, drop_p, seed, score_w, score_x,
-                         sdrop, sseed, (void*)s, 0);
+                         sdrop, sseed, (void*)s, 0, score_parts, cb.xdrop >= 0 ? A + cb.xdrop : nullptr);
   return cell_fwd_impl(0, nullptr, bits, dinv, vals, keep, goff, m_real, m_rows, x, ids, n, r, din, h, c.w_p, c.w_z0, c.w_z1, c.w_r0,
                        c.w_r1, c.w_h0, c.w_h1, c.b_z0, c.b_z1, c.b_r0, c.b_r1, c.b_h0, c.b_h1, A + cb.xp, A + cb.a, A + cb.z,
                        A + cb.rr, A + cb.rx, A + cb.hh, A + cb.out, drop_p, seed, score_w, score_x, sdrop, sseed, (void*)s, pad_out_dead);
@@ -365,7 +369,7 @@ static int cell_bwd(const gh_cell_params& c, const gh_cell_bf16* c16, const Cell
                          (cf)c16->wt_r0, (cf)c16->wt_r1, (cf)c16->wt_h0, (cf)c16->wt_h1, A + cb.xp, A + cb.a, A + cb.z, A + cb.rr,
                          A + cb.rx, A + cb.hh, g, W + sc[0], W + sc[1], W + sc[2], W + sc[3], W + sc[4], dx, c.dw_p, c.dw_z0, c.dw_z1,
                          c.dw_r0, c.dw_r1, c.dw_h0, c.dw_h1, c.db_z0, c.db_r0, c.db_h0, c.db_z1, c.db_r1, c.db_h1, drop_p, seed, (void*)s,
-                         nullptr, nullptr, nullptr, pre_done, next);
+                         nullptr, nullptr, nullptr, pre_done, next, cb.xdrop >= 0 ? A + cb.xdrop : nullptr);
   }
   GH_REQUIRE(c.wt_p, "get_backward: a cell's transposes are missing");
   return cell_bwd_impl(0, bits, dinv, vals, keep, goff, m_real, x, ids, n, r, din, h, c.wt_p, c.wt_z0, c.wt_z1, c.wt_r0, c.wt_r1,
@@ -455,7 +459,14 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
                     Ba->drop_gnn, Ba->seed_cell1, Mo->scorer_w, A + f.score_x, Ba->drop_gnn, Ba->seed_scorer, s, 1));
     GH_TRY(gh_scorer_gsl(Ba->d_bits, Ba->d_dinv, Ba->d_vals, goff, (d.compact && Ba->collapsed) ? 1 : 0, nullptr, A + f.score_x, Mo->scorer_w,
                          Mo->scorer_gate, d.B1, d.R, H, Ba->k_keep, O + f.score, keep, 0.f, 0, (void*)s));
-  } else {                  // wide hidden layer (h = 768): a row spans more column blocks than an epilogue can reduce -- the scorer kernel projects
+  } else if (d.bf) {        // wide hidden layer, bf16 storage: every column block of the last epilogue reduces its share of the projection
+    int parts = 1;          // into a partial of its own; the scorer kernel adds them in block order (no fp32 copy of the cell output at all)
+    GH_TRY(cell_fwd(Mo->cell1, c16_1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, d.M1, table1, ids1, d.B1, d.R, d.D, H,
+                    Ba->drop_gnn, Ba->seed_cell1, Mo->scorer_w, A + f.score_x, Ba->drop_gnn, Ba->seed_scorer, s, 0, &parts));
+    GH_REQUIRE(parts >= 1 && parts <= 8, "get_forward: internal -- %d scorer partials", parts);
+    GH_TRY(scorer_gsl_impl(Ba->d_bits, Ba->d_dinv, Ba->d_vals, goff, (d.compact && Ba->collapsed) ? 1 : 0, nullptr, A + f.score_x, parts, d.M1,
+                           Mo->scorer_w, Mo->scorer_gate, d.B1, d.R, H, Ba->k_keep, O + f.score, keep, 0.f, 0, s));
+  } else {                  // wide hidden layer (h = 768), fp32: a row spans more column blocks than an epilogue can reduce -- the scorer kernel projects
     GH_TRY(cell_fwd(Mo->cell1, c16_1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, d.M1, table1, ids1, d.B1, d.R, d.D, H,
                     Ba->drop_gnn, Ba->seed_cell1, nullptr, nullptr, 0.f, 0, s, 0));
     GH_TRY(gh_scorer_gsl(Ba->d_bits, Ba->d_dinv, Ba->d_vals, goff, (d.compact && Ba->collapsed) ? 1 : 0, A + f.c1.out32, nullptr, Mo->scorer_w,

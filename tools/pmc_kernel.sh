@@ -2,7 +2,7 @@
 # SQ counter passes over a micro-benchmark command, aggregated per kernel.  usage: tools/pmc_kernel.sh TAG FILTER -- cmd...
 TAG=$1; FILTER=$2; shift 3
 cd /tmp && export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r2; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r5; mkdir -p $O
 i=0
 for c in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
          "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU" \
