@@ -312,20 +312,27 @@ gemm_tn_bf16_kernel(const Launch L_byval) {
   const rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, kend * lda * 2, 0x00020000);
   const rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, kend * ldb * 2, 0x00020000);
 
-  // DMA: linear 16-byte chunk c of the A image = (k-row c / (BM/8), 8 columns starting at 8 (c % (BM/8)))
+  // DMA: linear 16-byte chunk c of the A image = k-row c / (BM/8), slot c % (BM/8).
+  // Bank swizzle (round 5): a 32-lane group of ds_read_b64_tr_b16 reads two 16-byte chunks of each of the k-rows
+  // {0,1,2,3,8,9,10,11} (+4 for the second read, +16 for the other group); with the natural row pitches (128 B and 640 B, both
+  // = 128 mod 256) rows {0,2,8,10} and {1,3,9,11} each fall on the same 8 banks: a 4-way conflict on every read (PMC on
+  // configs[4]: SQ_LDS_BANK_CONFLICT = 75 % of SQ_LDS_IDX_ACTIVE, LDS issue stalls 25 % of the wave cycles).  The DMA writes LDS
+  // linearly, so the fix is on the SOURCE side, as in the NT kernel: slot s of k-row r holds logical column chunk s ^ f(r),
+  // f(r) = 2 ((r >> 1) & 1) + 4 ((r >> 3) & 1) -- the four rows that share a bank range then sit at four different chunk pairs.
+  auto fswz = [](int r) { return (((r >> 1) & 1) << 1) | (((r >> 3) & 1) << 2); };
   unsigned a_vo[SA], b_vo[SB];
 #pragma unroll
   for (int j = 0; j < SA; ++j) {
     const int ia = wave + NW * j;
     const int c = ia * 64 + lane;
-    const int krow = c / (BM / 8), col = m0 + 8 * (c % (BM / 8));
+    const int krow = c / (BM / 8), col = m0 + 8 * ((c % (BM / 8)) ^ fswz(krow));
     a_vo[j] = ((NW * (j + 1) <= NAI || ia < NAI) && col < M) ? ((unsigned)krow * (unsigned)lda + (unsigned)col) * 2u : OOB;
   }
 #pragma unroll
   for (int j = 0; j < SB; ++j) {
     const int ib = wave + NW * j;
     const int c = ib * 64 + lane;
-    const int krow = c / (BN / 8), col = 8 * (c % (BN / 8));
+    const int krow = c / (BN / 8), col = 8 * ((c % (BN / 8)) ^ fswz(krow));
     b_vo[j] = ((NW * (j + 1) <= NBI || ib < NBI) && col < N) ? ((unsigned)krow * (unsigned)ldb + (unsigned)col) * 2u : OOB;
   }
   auto dma_tile = [&](int t, int st) __attribute__((always_inline)) {
@@ -348,9 +355,18 @@ gemm_tn_bf16_kernel(const Launch L_byval) {
   };
 
   // transpose-read addresses: lane (p = l15, g = q) points at k-row 8 g + (p >> 2) (+4 for the second read), 4 columns at 4 (p & 3)
+  // (the swizzle XORs bits 5-6 of the byte offset inside a row; the k-row of the second read, +4, has the same f)
+  static_assert(BM % 64 == 0 && BN % 64 == 0, "column chunks are swizzled inside aligned groups of eight");
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
-  const unsigned a_ad = lds0 + (unsigned)(8 * q + (l15 >> 2)) * (BM * 2) + (unsigned)(wrow + 4 * (l15 & 3)) * 2u;
-  const unsigned b_ad = lds0 + (unsigned)A_BYTES + (unsigned)(8 * q + (l15 >> 2)) * (BN * 2) + (unsigned)(wcol + 4 * (l15 & 3)) * 2u;
+  const int trow = 8 * q + (l15 >> 2);
+  const unsigned fz = (unsigned)fswz(trow) << 4;
+  unsigned a_ad[MI], b_ad[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+    a_ad[mi] = lds0 + (unsigned)trow * (BM * 2) + (((unsigned)(wrow + 16 * mi + 4 * (l15 & 3)) * 2u) ^ fz);
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+    b_ad[ni] = lds0 + (unsigned)A_BYTES + (unsigned)trow * (BN * 2) + (((unsigned)(wcol + 16 * ni + 4 * (l15 & 3)) * 2u) ^ fz);
   auto tr_read = [&](unsigned addr) __attribute__((always_inline)) {
     uint2 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
@@ -374,9 +390,9 @@ gemm_tn_bf16_kernel(const Launch L_byval) {
     const unsigned so = (unsigned)st * STAGE;
     uint2 alo[MI], ahi[MI], blo[NI], bhi[NI];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) { alo[mi] = tr_read(a_ad + so + mi * 32); ahi[mi] = tr_read(a_ad + so + mi * 32 + 4 * (BM * 2)); }
+    for (int mi = 0; mi < MI; ++mi) { alo[mi] = tr_read(a_ad[mi] + so); ahi[mi] = tr_read(a_ad[mi] + so + 4 * (BM * 2)); }
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) { blo[ni] = tr_read(b_ad + so + ni * 32); bhi[ni] = tr_read(b_ad + so + ni * 32 + 4 * (BN * 2)); }
+    for (int ni = 0; ni < NI; ++ni) { blo[ni] = tr_read(b_ad[ni] + so); bhi[ni] = tr_read(b_ad[ni] + so + 4 * (BN * 2)); }
     // the reads are invisible to the compiler's counters: wait here, and make every destination an in/out operand of the
     // wait so that no copy of a not-yet-landed register can be scheduled above it (cdna_hip_programming.md, inline-asm form ii)
     static_assert(MI == 2 && NI == 10, "operand lists below");
