@@ -265,6 +265,10 @@ gemm_tn_kernel(const Launch L_byval) {
 // output lane i receives element (i & 3) of lanes (i >> 2) + 4 j, j = 0..3.  With lane p pointing at
 // X[k0 + (p >> 2)][c0 + 4 (p & 3) ..+3] the group reads a 4(k) x 16(c) block and lane i gets X[k0..k0+3][c0 + i]: four
 // consecutive k of ITS column.  Two such reads (k0 = 8 g, 8 g + 4 for lane group g) make one MFMA operand.
+// (Round 5, measured and removed: THREE stages -- prefetch distance 2 on 72 KB of dynamic LDS, vmcnt-counted waits, bare barriers, two
+//  workgroups per CU instead of three -- because a K tile is only 20 MFMAs = 320 matrix cycles per wave and PMC had the waves parked
+//  41 % of their cycles: gemm_big_tn 1.75 -> 2.01 ms per step on configs[4].  As for the fp32 tiles, the third resident workgroup is
+//  worth more than the deeper prefetch.)
 template <int WM, int WN, int NI>
 __global__ void __launch_bounds__(WM * WN * 64, 3)
 gemm_tn_bf16_kernel(const Launch L_byval) {
