@@ -363,7 +363,9 @@ class _ArenaPool:
         self.free = {}          # device index -> list of tensors
 
     def _list(self, dev):
-        return self.free.setdefault(dev.index if dev.index is not None else torch.cuda.current_device(), [])
+        dev = torch.device(dev)
+        idx = dev.index if (dev.index is not None or dev.type != "cuda") else torch.cuda.current_device()
+        return self.free.setdefault((dev.type, idx), [])
 
     def take(self, n: int, dev) -> torch.Tensor:
         lst = self._list(dev)
@@ -400,6 +402,8 @@ class _GetFused(torch.autograd.Function):
         plan = GetPlan()
         _lib.call("gh_get_plan_buffers", ctypes.addressof(M), ctypes.addressof(prep.struct), ctypes.addressof(plan))
         pool = binding.pool if (POOL_ARENAS and any(ctx.needs_input_grad)) else None
+        if pool is None and binding.pool.free:
+            binding.pool.clear()          # a no-grad forward (validation pass): the training arenas go back to the allocator
         arena = pool.take(plan.fwd_floats, dev) if pool is not None else torch.empty(_arena_floats(plan.fwd_floats), device=dev, dtype=torch.float32)
         # the observables (logits, attention weights, scores, keep-sets: a few MB) get a buffer of their own: whoever keeps
         # them -- the model's last_score / last_keep, batched_predict's per-chunk lists -- does not pin the activation arena

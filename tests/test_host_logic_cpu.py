@@ -51,3 +51,55 @@ def test_reference_tensor_shim_depads_like_the_fitter_on_cpu():
     assert np.array_equal(k["doc_content_without_padding_evidences"].numpy(), inp["doc_ids"])
     assert np.array_equal(k["docs_adj"].numpy(), inp["doc_adj"])
     assert k["fixed_num_evidences"] == n and k["docs_adj"].shape[0] == int(np.sum(inp["evd_counts"]))
+
+
+def test_arena_pool_converges_to_one_buffer_per_kind():
+    """get_amd.fused._ArenaPool (persistent activation arenas of the composite path): a returned buffer is re-used for requests
+    it holds with at most 30 % slack, a larger request supersedes (drops) the free buffers it makes redundant, and two kinds of
+    arenas whose sizes are far apart (forward / backward) never take each other's buffers."""
+    import torch
+    from get_amd.fused import _ArenaPool, _arena_floats
+    pool, dev = _ArenaPool(), torch.device("cpu")
+    fwd, bwd = 40 << 20, 24 << 20            # floats
+    a = pool.take(fwd, dev)
+    b = pool.take(bwd, dev)
+    assert a.numel() == _arena_floats(fwd) and b.numel() == _arena_floats(bwd) and a.data_ptr() != b.data_ptr()
+    pool.give(a); pool.give(b)
+    a2, b2 = pool.take(fwd - 1000, dev), pool.take(bwd, dev)
+    assert a2.data_ptr() == a.data_ptr() and b2.data_ptr() == b.data_ptr()       # re-used, each by its own kind
+    pool.give(a2); pool.give(b2)
+    big = pool.take(int(fwd * 1.1), dev)      # a batch with more nodes: new buffer, the superseded forward arena is dropped
+    assert big.numel() >= int(fwd * 1.1) and big.data_ptr() != a.data_ptr()
+    sizes = sorted(t.numel() for t in pool._list(dev))
+    assert sizes == [b.numel()], sizes
+    pool.give(big)
+    again = pool.take(fwd, dev)               # the smaller batch now fits the larger arena (within the slack): no allocation
+    assert again.data_ptr() == big.data_ptr()
+    for _ in range(10):                       # never more than MAX_FREE buffers held
+        pool.give(torch.empty(1 << 22))
+    assert len(pool._list(dev)) <= _ArenaPool.MAX_FREE
+    pool.clear()
+    assert not pool.free
+
+
+def test_prefetch_reference_yields_in_order_on_plain_tensors():
+    """get_amd.batch.prefetch_reference on CPU tensors (no HIP library: every item takes kargs_from_reference_tensors' plain form):
+    one kargs dict per hand-over, in order, equal to the direct call -- the generator's look-ahead must not reorder or drop."""
+    import numpy as np
+    import torch
+    from get_amd.batch import kargs_from_reference_tensors, prefetch_reference
+    rng = np.random.default_rng(3)
+    items = []
+    for i in range(3):
+        b, n, r, l = 2 + i, 4, 6, 5
+        counts = torch.tensor(rng.integers(0, n + 1, size=b))
+        items.append((torch.ones(b), torch.tensor(rng.integers(0, 9, size=(b, n, r))), torch.tensor(rng.random((b, n, r, r))),
+                      torch.tensor(rng.random((b, l, l))), counts, torch.zeros((b, n), dtype=torch.int64), None))
+    got = list(prefetch_reference(items, n_max=4))
+    assert len(got) == 3
+    for item, k in zip(items, got):
+        ref = kargs_from_reference_tensors(*item, n_max=4)
+        assert set(k) == set(ref)
+        assert torch.equal(k["doc_content_without_padding_evidences"], ref["doc_content_without_padding_evidences"])
+        assert torch.equal(k["docs_adj"], ref["docs_adj"])
+        assert k["doc_content_without_padding_evidences"].shape[0] == int(item[4].sum())
