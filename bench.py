@@ -555,7 +555,10 @@ def other_config_leg(args, name, overrides, mode, steps, device, dist, seed):
                                "measured": f"HIP events around every {DOMINANT} launch of the first {pd['steps']} timed steps"}
         leg["parity"] = parity_check(wl, k=2)
         if mode == "bf16":
-            leg["parity"]["note"] = "bf16 storage inside the cells: stated bounds are logits 2e-3, keep-set flips <= 0.5 % of the real nodes"
+            leg["parity"]["note"] = ("bf16 storage inside the cells is NOT the 1e-4 fp32 contract: against the fp32 oracle the logits of this batch "
+                                     "sit at the 1e-3 .. 1e-2 level, GSL keep decisions of nodes whose scores tie within bf16 noise may flip "
+                                     "(counted above); the asserted bf16 bounds (logits 2e-3, weights 5e-3, gradients 6e-2 on its batch) are "
+                                     "tests/test_gpu_model.py::test_h768_bf16_storage_vs_the_cpu_oracle")
         fl = flops_per_pair(cfg, wl["nnz_per_graph"], wl["m_real"] / max(wl["b1"], 1) if wl["compact"] else None)
         fl_run = fl.get("executed", fl["fwd_bwd"])
         leg["path_tflops"] = fl_run * s["value"] / 1e12
