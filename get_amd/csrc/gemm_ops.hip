@@ -49,6 +49,12 @@ static bool fast_ok(const Launch& L, bool tn) {
   }
   return true;
 }
+// bf16 weight-gradient GEMM on 128 x 320 tiles (gemm_tn_bf16_kernel<2, 2, 10, 4>; tool build: GH_TN16_TALL=0 restores 64 x 320)
+static bool tn16_tall() {
+  static int v = -1;
+  if (v < 0) v = measure_env("GH_TN16_TALL", 1);
+  return v != 0;
+}
 static bool wants_dropout(const Launch& L) {
   for (int i = 0; i < L.nprob; ++i)
     if (L.p[i].drop_mode) return true;
@@ -109,7 +115,10 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
   if (any_elt) {      // bf16 storage pipeline: only on the 64x320 fast kernels, never mixed with fp32 problems
     if (!fast || !all_elt) return hipErrorInvalidValue;
     if constexpr (WM == 2 && WN == 2 && NI == 10) {
-      if (tn) hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 2, 10>), dim3(grid), dim3(256), 0, s, L);
+      if (tn) {
+        if (tn16_tall()) hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 2, 10, 4>), dim3(grid), dim3(256), 0, s, L);
+        else hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 2, 10>), dim3(grid), dim3(256), 0, s, L);
+      }
       else hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 10, 2, 2>), dim3(grid), dim3(256), 0, s, L);
       launched = true;
     } else if constexpr (WM == 2 && WN == 2 && NI == 8 && MI == 4) {      // 128 x 256 tile (NT only)
@@ -585,7 +594,8 @@ struct Batch {
       if (att_blocks) { q.w2 += n0; q.u += n0; q.e = p.e + (size_t)(n0 / bn) * (size_t)e_block_stride; q.e_atomic = 2; }      // (2: own partial buffer, plain stores)
       if (L.nprob == GH_MAX_PROBLEMS) flush();
       L.p[L.nprob++] = q;
-      const int mt = (q.M + bm - 1) / bm;
+      const int bm_eff = (tn && q.elt && tn16_tall()) ? 128 : bm;      // (all problems of a TN launch share the storage mode)
+      const int mt = (q.M + bm_eff - 1) / bm_eff;
       if (mt > L.m_tiles) L.m_tiles = mt;
       if (q.seg[0].K > k_total) k_total = q.seg[0].K;
     }

@@ -269,15 +269,15 @@ gemm_tn_kernel(const Launch L_byval) {
 //  workgroups per CU instead of three -- because a K tile is only 20 MFMAs = 320 matrix cycles per wave and PMC had the waves parked
 //  41 % of their cycles: gemm_big_tn 1.75 -> 2.01 ms per step on configs[4].  As for the fp32 tiles, the third resident workgroup is
 //  worth more than the deeper prefetch.)
-template <int WM, int WN, int NI>
-__global__ void __launch_bounds__(WM * WN * 64, 3)
+// MI = 4 (a 128 x 320 tile, two workgroups per CU): 28 instead of 24 LDS-DMA instructions for twice the MFMAs of a K tile.
+template <int WM, int WN, int NI, int MI = 2>
+__global__ void __launch_bounds__(WM * WN * 64, MI == 4 ? 2 : 3)
 gemm_tn_bf16_kernel(const Launch L_byval) {
   (void)L_byval;
 #if defined(__HIP_DEVICE_COMPILE__)
   const GH_KARG Launch& L = *(const GH_KARG Launch*)__builtin_amdgcn_kernarg_segment_ptr();
   typedef __amdgpu_buffer_rsrc_t rsrc_t;
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-  constexpr int MI = 2;
   constexpr int NW = WM * WN;
   constexpr int BM = 16 * MI * WM, BN = 16 * NI * WN, BK = 32;
   constexpr int A_BYTES = BK * BM * 2, B_BYTES = BK * BN * 2;
@@ -324,12 +324,15 @@ gemm_tn_bf16_kernel(const Launch L_byval) {
   // linearly, so the fix is on the SOURCE side, as in the NT kernel: slot s of k-row r holds logical column chunk s ^ f(r),
   // f(r) = 2 ((r >> 1) & 1) + 4 ((r >> 3) & 1) -- the four rows that share a bank range then sit at four different chunk pairs.
   auto fswz = [](int r) { return (((r >> 1) & 1) << 1) | (((r >> 3) & 1) << 2); };
+  // (the A image of the 128-row tile has a 256-byte pitch: ALL its k-rows start on the same bank, so the eight rows of a read
+  //  need eight different chunk pairs -- three swizzle bits: r & 3 and bit 3 of r)
+  auto fswzA = [&](int r) { return BM == 128 ? (((r & 3) << 1) | (((r >> 3) & 1) << 3)) : fswz(r); };
   unsigned a_vo[SA], b_vo[SB];
 #pragma unroll
   for (int j = 0; j < SA; ++j) {
     const int ia = wave + NW * j;
     const int c = ia * 64 + lane;
-    const int krow = c / (BM / 8), col = m0 + 8 * ((c % (BM / 8)) ^ fswz(krow));
+    const int krow = c / (BM / 8), col = m0 + 8 * ((c % (BM / 8)) ^ fswzA(krow));
     a_vo[j] = ((NW * (j + 1) <= NAI || ia < NAI) && col < M) ? ((unsigned)krow * (unsigned)lda + (unsigned)col) * 2u : OOB;
   }
 #pragma unroll
@@ -360,14 +363,14 @@ gemm_tn_bf16_kernel(const Launch L_byval) {
 
   // transpose-read addresses: lane (p = l15, g = q) points at k-row 8 g + (p >> 2) (+4 for the second read), 4 columns at 4 (p & 3)
   // (the swizzle XORs bits 5-6 of the byte offset inside a row; the k-row of the second read, +4, has the same f)
-  static_assert(BM % 64 == 0 && BN % 64 == 0, "column chunks are swizzled inside aligned groups of eight");
+  static_assert((BM == 64 || BM == 128) && BN % 64 == 0, "column chunks are swizzled inside aligned groups of eight (sixteen: BM = 128)");
   const unsigned lds0 = (unsigned)(uintptr_t)smem;
   const int trow = 8 * q + (l15 >> 2);
-  const unsigned fz = (unsigned)fswz(trow) << 4;
+  const unsigned fz = (unsigned)fswz(trow) << 4, fzA = (unsigned)fswzA(trow) << 4;
   unsigned a_ad[MI], b_ad[NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
-    a_ad[mi] = lds0 + (unsigned)trow * (BM * 2) + (((unsigned)(wrow + 16 * mi + 4 * (l15 & 3)) * 2u) ^ fz);
+    a_ad[mi] = lds0 + (unsigned)trow * (BM * 2) + (((unsigned)(wrow + 16 * mi + 4 * (l15 & 3)) * 2u) ^ fzA);
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni)
     b_ad[ni] = lds0 + (unsigned)A_BYTES + (unsigned)trow * (BN * 2) + (((unsigned)(wcol + 16 * ni + 4 * (l15 & 3)) * 2u) ^ fz);
@@ -382,7 +385,9 @@ gemm_tn_bf16_kernel(const Launch L_byval) {
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float csum[MI] = {0.f, 0.f};
+  float csum[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) csum[mi] = 0.f;
   float* const colsum = P.colsum;
 
   dma_tile(0, 0);
@@ -399,11 +404,13 @@ gemm_tn_bf16_kernel(const Launch L_byval) {
     for (int ni = 0; ni < NI; ++ni) { blo[ni] = tr_read(b_ad[ni] + so); bhi[ni] = tr_read(b_ad[ni] + so + 4 * (BN * 2)); }
     // the reads are invisible to the compiler's counters: wait here, and make every destination an in/out operand of the
     // wait so that no copy of a not-yet-landed register can be scheduled above it (cdna_hip_programming.md, inline-asm form ii)
-    static_assert(MI == 2 && NI == 10, "operand lists below");
+    static_assert((MI == 2 || MI == 4) && NI == 10, "operand lists below");
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(alo[0]), "+v"(alo[1]), "+v"(ahi[0]), "+v"(ahi[1]), "+v"(blo[0]), "+v"(blo[1]), "+v"(blo[2]), "+v"(blo[3]),
                    "+v"(blo[4]), "+v"(blo[5]), "+v"(blo[6]), "+v"(blo[7]), "+v"(blo[8]), "+v"(blo[9])
                  :: "memory");
+    if constexpr (MI == 4)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(alo[2]), "+v"(alo[3]), "+v"(ahi[2]), "+v"(ahi[3]) :: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(bhi[0]), "+v"(bhi[1]), "+v"(bhi[2]), "+v"(bhi[3]), "+v"(bhi[4]), "+v"(bhi[5]), "+v"(bhi[6]), "+v"(bhi[7]),
                    "+v"(bhi[8]), "+v"(bhi[9])

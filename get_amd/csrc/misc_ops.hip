@@ -339,6 +339,21 @@ gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ 
 __global__ void __launch_bounds__(256)
 gather_rows_bf16_kernel(const unsigned short* __restrict__ table, const int32_t* __restrict__ ids, unsigned short* __restrict__ dst,
                         int m, int d, unsigned drop_thresh, float drop_scale, unsigned drop_seed) {
+  if (d % 8 == 0 && ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {      // 16-byte items (8 values)
+    const int per8 = d / 8;
+    for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < (size_t)m * per8; it += (size_t)gridDim.x * blockDim.x) {
+      const int r = (int)(it / per8), c = 8 * (int)(it % per8);
+      const uint4 u = *reinterpret_cast<const uint4*>(table + (size_t)(ids ? ids[r] : r) * d + c);
+      float4 va = mbf4_to_f4(make_uint2(u.x, u.y)), vb = mbf4_to_f4(make_uint2(u.z, u.w));
+      if (drop_thresh) {
+        const unsigned idx = (unsigned)r * (unsigned)d + (unsigned)c;
+        va = drop4(va, drop_seed, idx, drop_thresh, drop_scale);
+        vb = drop4(vb, drop_seed, idx + 4u, drop_thresh, drop_scale);
+      }
+      *reinterpret_cast<uint4*>(dst + (size_t)r * d + c) = make_uint4(mpack_bf2(va.x, va.y), mpack_bf2(va.z, va.w), mpack_bf2(vb.x, vb.y), mpack_bf2(vb.z, vb.w));
+    }
+    return;
+  }
   const int per = d / 4;
   for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < (size_t)m * per; it += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(it / per), c = 4 * (int)(it % per);
@@ -417,7 +432,7 @@ att_softmax_fwd_kernel(float* __restrict__ e, const float* __restrict__ mask, co
   }
   // scores staged in LDS (read twice below).  n_parts > 0: the producing GEMM left one partial per column block of the hidden
   // layer (wide rows, h = 768): summed here in block order, and the sum is written back as the layer's `e` output
-  float* eb = ws + (size_t)Lmax * C + (size_t)NWV * 64 * 4 * C;      // [Lmax][C], behind the weights and the reduce partials
+  float* eb = ws + (size_t)Lmax * C + (size_t)NWV * 64 * (4 * C + 1);      // [Lmax][C], behind the weights and the reduce partials
   for (int i = tid; i < L * C; i += NT) {
     float v;
     if (n_parts > 0) {
@@ -450,7 +465,11 @@ att_softmax_fwd_kernel(float* __restrict__ e, const float* __restrict__ mask, co
     for (int i = tid; i < L * C; i += NT) weights[(size_t)row0 * C + i] = ws[i];
   // attended[d][c] = sum_l right[l][d] w[l][c]: the waves take every NWV-th row (16-byte coalesced reads), partial sums
   // meet in LDS, one column chunk after the other
-  float* part = ws + Lmax * C;                   // [NWV][64][4][C] floats
+  // [NWV][64 lanes][4 C + 1] floats.  The odd pitch keeps the 4 C partial stores of a wave conflict-free (at the pitch 4 C the
+  // 64 lanes of a store sat 4 C floats apart: 32-way bank conflicts at C = 8, 4-way at C = 5 -- PMC on configs[4]:
+  // SQ_LDS_BANK_CONFLICT 87 % of the kernel's LDS cycles) and the reduce below still reads consecutive words
+  float* part = ws + Lmax * C;
+  const int PP = 4 * C + 1;
   float acc[NCH][4][CT];
 #pragma unroll
   for (int h = 0; h < NCH; ++h)
@@ -489,14 +508,14 @@ att_softmax_fwd_kernel(float* __restrict__ e, const float* __restrict__ mask, co
     for (int k = 0; k < 4; ++k)
 #pragma unroll
       for (int c = 0; c < CT; ++c)
-        if (c < C) part[((wave * 64 + lane) * 4 + k) * C + c] = acc[h][k][c];
+        if (c < C) part[(wave * 64 + lane) * PP + k * C + c] = acc[h][k][c];
     __syncthreads();
     for (int i = tid; i < 64 * 4 * C; i += NT) {
       const int ln = i / (4 * C), rem = i % (4 * C);     // rem = k*C + c -> output offset within the float4 column group
       const int dd = (blockIdx.y * (64 * NCH) + 64 * h + ln) * 4 + rem / C;
       if (dd < Dr) {
         float v = 0.f;
-        for (int w = 0; w < NWV; ++w) v += part[((w * 64 + ln) * 4) * C + rem];
+        for (int w = 0; w < NWV; ++w) v += part[(w * 64 + ln) * PP + rem];
         if (L == 0) v = NAN;                      // no rows at all: the reference's softmax over an all -inf column
         attended[((size_t)b * Dr + dd) * C + rem % C] = v;
       }
@@ -509,7 +528,7 @@ int launch_att_softmax_fwd(float* e, const float* mask, const float* right, cons
                            const float* e_parts, int n_parts, long long part_stride) {
   GH_REQUIRE(dr % 4 == 0 && (reinterpret_cast<uintptr_t>(right) & 15) == 0, "att_softmax_fwd: right rows must be float4-shaped (dr=%d)", dr);
   const int nthr = 256;      // (8 waves per pair measured no faster: the kernel is not parallelism-bound)
-  const size_t lds = ((size_t)2 * l * heads + (nthr / 64) * 64 * 4 * heads) * 4;
+  const size_t lds = ((size_t)2 * l * heads + (nthr / 64) * 64 * (4 * heads + 1)) * 4;
   GH_REQUIRE(lds <= 64 * 1024, "att_softmax_fwd: sequence %d x heads %d too large", l, heads);
   prof_begin(s, b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_SOFTMAX_FWD);
   GH_REQUIRE(heads >= 1 && heads <= 8, "att_softmax_fwd: %d heads (1..8 supported)", heads);
