@@ -106,13 +106,13 @@ int launch_att_softmax_fwd(float* e, const float* mask, const float* right, cons
 int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w,
                            const int32_t* goff, int m_real, int b, int l, int dr, int heads, float* de, float* dright,
                            hipStream_t s, const int32_t* rowg = nullptr, float* dw_tmp = nullptr, int* dw_written = nullptr);
-// (rowg + dw_tmp [2][rows][heads] + dw_written: many-pair launches may take the row-balanced kernel, which leaves the raw
-//  dw in dw_tmp instead of de -- *dw_written = 1, or 2 when rows wider than 512 floats were split into two column ranges whose
-//  partial dw sit rows * heads floats apart -- and launch_att_dpre(dw_in = dw_tmp, weights, de_out = de, .., stride) finishes de)
+// (rowg + dw_tmp [ceil(dr / 512)][rows][heads] + dw_written: many-pair launches may take the row-balanced kernel, which leaves the raw
+//  dw in dw_tmp instead of de -- *dw_written = the number of column ranges (<= 16) rows wider than 512 floats were split into, whose
+//  partial dw sit rows * heads floats apart -- and launch_att_dpre(dw_in = dw_tmp, weights, de_out = de, .., stride, ranges) finishes de)
 int launch_att_dpre(const float* de, const float* w2, const float* t, const int32_t* goff, int m_real, int b, int l,
                     int ha, int heads, float* dpre, float* du, float* dw2_part, hipStream_t s, const float* dw_in = nullptr,
                     const float* weights = nullptr, float* de_out = nullptr, void* dpre16 = nullptr,       // dpre16: dpre as bf16 there instead
-                    long long dw_range_stride = 0);      // > 0: dw_in = two column-range partials of att_rows_bwd (rows wider than 512 floats)
+                    long long dw_range_stride = 0, int dw_ranges = 1);      // dw_ranges > 1: dw_in = that many column-range partials of att_rows_bwd (rows wider than 512 floats)
 
 // Where the gradient w.r.t. a GGNN cell's output goes when the GEMM that produces it applies that cell's gate head in its
 // epilogue (EPI_GATE_PRE): the cell's saved z / hh / xp and its dhp / dzp / dxp scratch (all [rows][h] fp32).

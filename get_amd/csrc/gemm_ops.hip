@@ -1250,7 +1250,7 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
   dw2_part = late ? dw2_buf : ((wsp.p && dw2_bytes <= wsp.bytes && ha % 4 == 0) ? wsp.p : nullptr);
   if (int e = launch_att_dpre(de, w2, t, goff, m_real, b, l, ha, heads, dpre, du, dw2_part, s, dw_written ? dw_tmp : nullptr,
                               dw_written ? weights : nullptr, dw_written ? de : nullptr, dpre16,
-                              dw_written == 2 ? (long long)m_real * heads : 0)) return e;
+                              (long long)m_real * heads, dw_written > 1 ? dw_written : 1)) return e;
   if (dw2_part && !late) {
     ReduceArgs R;
     R.n = 1;

@@ -872,8 +872,10 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
   if (dw_written) *dw_written = 0;
   // many pairs, rows that fit two float4 chunks per lane, 16-byte aligned g_att rows: the row-balanced kernel; de is then
   // finished by att_dpre's prologue (launch_att_dpre with dw_in)
-  // (rows of up to 1024 floats: two column ranges, each a grid row of its own; *dw_written = the number of ranges)
-  if (dw_tmp && dw_written && dr / 4 <= 256 && (goff == nullptr || rowg != nullptr) &&
+  // (rows wider than 512 floats: ceil(dr / 512) column ranges, each a grid row of its own; *dw_written = the number of ranges.
+  //  Up to 16 ranges: the evidence level at h = 768 has 6272-float rows over only 32 claims -- the per-pair kernel below, one workgroup
+  //  per claim, streamed 1.5 MB per workgroup in 90 us)
+  if (dw_tmp && dw_written && dr / 4 <= 16 * 128 && (goff == nullptr || rowg != nullptr) &&
       (reinterpret_cast<uintptr_t>(g_att) & 15) == 0 && heads >= 1 && heads <= 8) {
     const int M = goff ? m_real : b * l;
     if (M <= 0) return 0;
@@ -890,7 +892,7 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
                                        (const void*)att_rows_bwd_kernel<7>, (const void*)att_rows_bwd_kernel<8>};
     const void* fn = fns[heads - 1];
     int Mv = M, rpwv = rpw;
-    const int ranges = dr / 4 > 128 ? 2 : 1;
+    const int ranges = (dr / 4 + 127) / 128;
     int d4h = (dr / 4 + ranges - 1) / ranges;
     void* args[] = {(void*)&right, (void*)&weights, (void*)&g_att, (void*)&g_w, (void*)&rowg, (void*)&l, (void*)&dr, (void*)&heads,
                     (void*)&Mv, (void*)&rpwv, (void*)&dw_tmp, (void*)&dright, (void*)&d4h};
@@ -929,7 +931,7 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
                                 float* __restrict__ dpre, float* __restrict__ du, float* __restrict__ dw2_part,
                                 const float* __restrict__ dw_in, const float* __restrict__ wts, float* __restrict__ de_out,
                                 unsigned short* __restrict__ dpre16,        // dpre16 != NULL: dpre is written THERE as bf16 (RNE) instead
-                                long long dw_range_stride) {                // > 0: dw_in holds two column-range partials, this many floats apart
+                                long long dw_range_stride, int dw_ranges) { // dw_ranges > 1: dw_in holds that many column-range partials, dw_range_stride floats apart
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
   float4* red = reinterpret_cast<float4*>(dsm);           // [RL][1 + C][S4]
   const int b = blockIdx.x;
@@ -960,7 +962,7 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
     float* wl = des + (size_t)Lmax * C;                    // [L][C] softmax weights
     for (int i = threadIdx.x; i < L * C; i += blockDim.x) {
       float v = dw_in[(size_t)row0 * C + i];
-      if (dw_range_stride > 0) v += dw_in[(size_t)dw_range_stride + (size_t)row0 * C + i];
+      for (int rg = 1; rg < dw_ranges; ++rg) v += dw_in[(size_t)rg * (size_t)dw_range_stride + (size_t)row0 * C + i];
       des[i] = v; wl[i] = wts[(size_t)row0 * C + i];
     }
     __syncthreads();
@@ -1051,7 +1053,7 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
 
 int launch_att_dpre(const float* de, const float* w2, const float* t, const int32_t* goff, int m_real, int b, int l,
                     int ha, int heads, float* dpre, float* du, float* dw2_part, hipStream_t s, const float* dw_in,
-                    const float* weights, float* de_out, void* dpre16, long long dw_range_stride) {
+                    const float* weights, float* de_out, void* dpre16, long long dw_range_stride, int dw_ranges) {
   GH_REQUIRE(ha % 4 == 0 && ha / 4 <= 256, "att_dpre: attention hidden %d must be a multiple of 4 and <= 1024", ha);
   const int n4 = ha / 4;
   // column slabs of <= 32 float4 (512 B of a row per lane group: whole 128-byte lines), ~3 slabs at ha = 300; few pairs
@@ -1069,7 +1071,7 @@ int launch_att_dpre(const float* de, const float* w2, const float* t, const int3
   const size_t lds = (size_t)RL * (1 + heads) * S4 * 16 + (size_t)l * heads * 4 * (dw_in ? 2 : 1) + (dw_in ? 64 : 0);
   prof_begin(s, b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_DPRE);
   hipLaunchKernelGGL(att_dpre_kernel, dim3(b, nsl), dim3(threads), lds, s, de, w2, t, goff, l, ha, heads, RL, S4, dpre, du, dw2_part,
-                     dw_in, weights, de_out, (unsigned short*)dpre16, dw_range_stride);
+                     dw_in, weights, de_out, (unsigned short*)dpre16, dw_range_stride, dw_ranges);
   const double rows = goff ? (double)m_real : (double)b * l;
   prof_end(b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_DPRE, 4.0 * (2.0 * rows * ha + rows * heads + (double)b * ha), s);
   GH_LAUNCH_CHECK();

@@ -33,7 +33,7 @@ struct FwdBuf {
 };
 struct BwdBuf {
   int64_t d_y0, d_new_left, d_att_e, de_e, dpre_e, du_e, dright_e, d_avg;
-  int64_t de_w, dw_w, dpre_w, du_w, du_c, d_q, g2, d_qhid, qs[5], sc2[5], sc1[5], dx2, dw2p_e, dw2p_w;
+  int64_t de_w, dw_w, dpre_w, du_w, du_c, d_q, g2, d_qhid, qs[5], sc2[5], sc1[5], dx2, dw2p_e, dw2p_w, dw_e;
   int64_t total;
 };
 struct Bump {
@@ -126,7 +126,8 @@ static int layout(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d, FwdBu
   w.de_e = c.take((int64_t)d.B * d.n * d.he); w.dpre_e = c.take((int64_t)d.B * d.n * d.H); w.du_e = c.take((int64_t)d.B * d.H);
   w.dright_e = c.take((int64_t)d.B * d.n * d.Dre);
   w.d_avg = c.take((int64_t)d.B1 * d.Xa);
-  w.de_w = c.take((int64_t)d.Mr * d.hw); w.dw_w = c.take((int64_t)2 * d.Mr * d.hw); w.dpre_w = c.take((int64_t)d.Mr * d.H); w.du_w = c.take((int64_t)d.B1 * d.H);
+  w.de_w = c.take((int64_t)d.Mr * d.hw); w.dw_w = c.take((int64_t)((d.H + 511) / 512) * d.Mr * d.hw);      // (one partial dw per 512-float column range of a row)
+  w.dw_e = c.take((int64_t)((d.Dre + 511) / 512) * d.B * d.n * d.he); w.dpre_w = c.take((int64_t)d.Mr * d.H); w.du_w = c.take((int64_t)d.B1 * d.H);
   w.du_c = c.take((int64_t)d.B * d.H);
   w.d_q = d.cs > 0 ? c.take((int64_t)d.B * d.H) : w.d_new_left;
   w.g2 = c.take((int64_t)d.Mr * d.H);
@@ -536,7 +537,8 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
     //       gradients on the side stream, `dleft_late`, and so does the split of d_new_left into d_q + claim-source table gradient)
     GH_TRY(att_bwd_impl(A + f.new_left, A + f.right_e, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he, Mo->att_evd.w1t, Mo->att_evd.w2, A + f.te,
                         O + f.we, Wb + w.d_att_e, g_evd_w, Wb + w.de_e, Wb + w.dpre_e, Wb + w.du_e, Wb + w.d_new_left, Wb + w.dright_e,
-                        nullptr, Mo->att_evd.dw2, nullptr, d.B, nullptr, 1, s, nullptr, nullptr, nullptr, 1, Wb + w.dw2p_e));
+                        nullptr, Mo->att_evd.dw2, nullptr, d.B, nullptr, 1, s, nullptr, (d.Dre + 511) / 512 <= 16 ? Wb + w.dw_e : nullptr, nullptr, 1,
+                        Wb + w.dw2p_e));
     GH_TRY(stream_after(ss, s, ev.ev[3]));
     GH_TRY(att_bwd_impl(A + f.new_left, A + f.right_e, nullptr, 0, d.B, d.n, d.Xl, d.Dre, H, d.he, Mo->att_evd.w1t, Mo->att_evd.w2, A + f.te,
                         O + f.we, Wb + w.d_att_e, g_evd_w, Wb + w.de_e, Wb + w.dpre_e, Wb + w.du_e, Wb + w.d_new_left, nullptr, Mo->att_evd.dw1,
