@@ -498,6 +498,7 @@ struct Batch {
   float* cs_out[GH_MAX_PROBLEMS] = {nullptr};
   float* cs_out2[GH_MAX_PROBLEMS] = {nullptr};
   bool colsum_fused = false;
+  bool colsum_missed = false;   // a requested column sum could be produced neither by the launch nor by the fallback kernel (bf16 operands without workspace)
   bool split_done = false;      // the last flush took the few-row split-K plan (its finish kernel applied the problems' row epilogues)
   void want_colsum(float* o, float* o2) { if (L.nprob > 0) { cs_out[L.nprob - 1] = o; cs_out2[L.nprob - 1] = o2; } }
 
@@ -642,7 +643,21 @@ struct Batch {
         need += (size_t)L.ksplit * L.p[i].M * L.p[i].N * sizeof(float);
         if (cs_out[i]) { need += (size_t)L.ksplit * L.p[i].M * sizeof(float); any_cs = true; }
       }
-      if (any_cs && !(ws_ok && need <= g_ws_bytes && fast_ok(L, true) && (g_gemm_mode != 1 || L.p[0].elt))) any_cs = false;   // caller runs the column-sum kernels
+      bool want_cs = false;
+      for (int i = 0; i < L.nprob; ++i) want_cs = want_cs || cs_out[i] != nullptr;
+      if (any_cs && !(ws_ok && need <= g_ws_bytes && fast_ok(L, true) && (g_gemm_mode != 1 || L.p[0].elt))) any_cs = false;
+      if (want_cs && !any_cs) {
+        // this launch cannot carry its column sums (no workspace, generic kernel): fp32 operands get them from the streaming
+        // kernel right here, so that a Batch whose problems span several launches (h = 768: 21 column-block problems) never ends
+        // up with some bias gradients fused and others missing; bf16 operands have no such kernel -- the caller is told
+        for (int i = 0; i < L.nprob; ++i) {
+          if (!cs_out[i]) continue;
+          const Seg& sg = L.p[i].seg[0];
+          if (L.p[i].elt || sg.lda != L.p[i].M) { colsum_missed = true; continue; }
+          if (launch_colsum3(sg.A, nullptr, nullptr, cs_out[i], nullptr, nullptr, sg.K, L.p[i].M, s, cs_out2[i], nullptr, nullptr)) colsum_missed = true;
+          else colsum_fused = true;
+        }
+      }
       if (ws_ok && need <= g_ws_bytes) {
         ReduceArgs R;
         R.n = L.nprob;
@@ -1005,7 +1020,7 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
     b.flush();
     GH_CHECK_HIP(b.err);
   }
-  const bool cs = bf ? true : ((h % 4 == 0) && (h <= 320));
+  const bool cs = bf ? true : (h % 4 == 0);      // (any float4-shaped width since round 5: Batch::flush satisfies every request itself)
   bool colsum_done = false;
   if (two) {  // six of the seven weight gradients start here, on the weight-gradient stream
     GH_CHECK_HIP(hipEventRecord(ev_l1, s));
@@ -1019,7 +1034,7 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
     b.add(tn_problem(h, h, dw_h1, h, dhp, h, rx, h, M, nullptr, bf));
     b.flush();
     GH_CHECK_HIP(b.err);
-    colsum_done = b.colsum_fused;
+    colsum_done = b.colsum_fused && !b.colsum_missed;
     if (!colsum_done) {
       GH_REQUIRE(!bf, "ggnn_cell_bwd_bf16: the bias gradients need the split-K workspace (gh_set_workspace)");
       if (int e = launch_colsum3(dzp, drp, dhp, db_z, db_r, db_h, M, h, sw, db_z1, db_r1, db_h1)) return e;
@@ -1082,7 +1097,7 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
     }
     b.flush();
     GH_CHECK_HIP(b.err);
-    if (two || b.colsum_fused) return 0;
+    if (two || (b.colsum_fused && !b.colsum_missed)) return 0;
   }
   GH_REQUIRE(!bf, "ggnn_cell_bwd_bf16: the bias gradients need the split-K workspace (gh_set_workspace)");
   return launch_colsum3(dzp, drp, dhp, db_z, db_r, db_h, M, h, s, db_z1, db_r1, db_h1);
