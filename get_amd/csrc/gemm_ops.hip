@@ -70,6 +70,12 @@ static int g_gemm_mode = 0;       // 0: fp32 MFMA everywhere (default); 1: bf16 
 // operand could be served, the launch runs the in-register split (MODE 3) instead
 static bool x3p_substitute(Launch& L, hipStream_t s);
 
+static bool few_row_bf16() {
+  static int v = -1;
+  if (v < 0) v = measure_env("GH_FEW_BF16", 1);
+  return v != 0;
+}
+
 template <int WM, int WN, int NI, int MI = 2>
 static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
   const bool fast = fast_ok(L, tn);
@@ -150,6 +156,11 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
     if (g_gemm_mode == 1 && WM == 2 && WN == 2 && NI == 10) {
       if constexpr (WM == 2 && WN == 2 && NI == 10)
         hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 10, 2, true>), dim3(grid), dim3(256), 0, s, L);
+    } else if (g_gemm_mode == 1 && WM == 1 && WN == 4 && NI == 5 && few_row_bf16()) {
+      // ... and in the few-row launches (32 x 320 tile): at h = 768 the evidence-level products (960 rows against 22 / 41 MB
+      // weights) and the claim cell are 0.5 ms of fp32 MFMA time per step
+      if constexpr (WM == 1 && WN == 4 && NI == 5)
+        hipLaunchKernelGGL((gemm_nt_kernel<1, 4, 5, 2, true>), dim3(grid), dim3(256), 0, s, L);
     } else if (g_gemm_mode == 2 || g_gemm_mode == 3) {      // fp32x3 (experimental): fp32 values and results, products from 3-way bf16 splits on the bf16 MFMA
       Launch L2;
       bool pre = false;
@@ -728,7 +739,9 @@ struct Batch {
   // workgroups, keep the partial tiles in the workspace and finish with nt_finish_kernel.
   bool nt_split_plan() {
     const int blocks = L.m_tiles * L.nprob;
-    if (g_ws == nullptr || blocks >= 96 || !fast_ok(L, false)) return false;
+    static int max_blocks = -1;
+    if (max_blocks < 0) max_blocks = measure_env("GH_NT_SPLIT_BLOCKS", 96);
+    if (g_ws == nullptr || blocks >= max_blocks || !fast_ok(L, false)) return false;
     int tmax = 0;          // K tiles over the concatenated segments (every problem of a launch is split alike)
     for (int i = 0; i < L.nprob; ++i) {
       const Problem& q = L.p[i];
