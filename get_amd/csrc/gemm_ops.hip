@@ -549,7 +549,9 @@ struct Batch {
     // per CU nothing runs underneath its epilogue.  Kept for the tool build only (GH_BF16_TILE=256).
     static int tile256 = -1;
     if (tile256 < 0) tile256 = measure_env("GH_BF16_TILE", 0) == 256 ? 1 : 0;
-    if (wide && tile256 && rows_hint >= 32768) { wide256 = true; bm = 256; }
+    static int tile256_sites = -1;
+    if (tile256_sites < 0) tile256_sites = measure_env("GH_BF16_TILE256_SITES", 0);      // (per call site, tool build)
+    if (wide && rows_hint >= 32768 && (tile256 || (site > 0 && ((tile256_sites >> (site - 1)) & 1)))) { wide256 = true; bm = 256; }
     static int tile128 = -1;
     if (tile128 < 0) tile128 = measure_env("GH_BF16_TILE", 0) == 128 ? 1 : 0;
     if (wide && tile128) { wide128 = true; bn = 128; }
@@ -560,6 +562,9 @@ struct Batch {
     // row tiles) get twice the workgroups on 1024 slots: 99.0 -> 102.0 K pairs/s on the Snopes-histogram step at B = 32
     const bool thin = rows_hint <= 24576;
     if (site > 0 && big && !tn_ && !wide && g_gemm_mode == 0 && narrow_mask != 0 && (((narrow_mask >> (site - 1)) & 1) || less_pad || thin)) { narrow = true; bn = 160; }
+    // (round 5: thin launches on 32 x 160 tiles -- one 16-row MFMA tile per wave, 80 - 96 VGPRs, five or six workgroups per CU, twice
+    //  the waves for grids that fill less than one round -- measured on the Snopes-count step: 109.4 K -> 108.2 - 109.4 K pairs/s
+    //  at every site mask.  Removed.)
     reset();
   }
   void reset() {
