@@ -100,12 +100,15 @@ int launch_tiny_linear_bwd(const float* x, const float* w, const float* g, float
                            hipStream_t s);
 int launch_att_softmax_fwd(float* e, const float* mask, const float* right, const int32_t* goff, int m_real,
                            int b, int l, int dr, int heads, float* weights, float* attended, hipStream_t s,
-                           const float* e_parts = nullptr, int n_parts = 0, long long part_stride = 0);
+                           const float* e_parts = nullptr, int n_parts = 0, long long part_stride = 0, const void* right16 = nullptr);
 // (e_parts: n_parts partial score tensors [rows][heads], part_stride floats apart -- one per column block of a wide hidden
 //  layer; the kernel sums them in block order and writes the sum to e)
 int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w,
                            const int32_t* goff, int m_real, int b, int l, int dr, int heads, float* de, float* dright,
-                           hipStream_t s, const int32_t* rowg = nullptr, float* dw_tmp = nullptr, int* dw_written = nullptr);
+                           hipStream_t s, const int32_t* rowg = nullptr, float* dw_tmp = nullptr, int* dw_written = nullptr,
+                           const void* right16 = nullptr);
+// (right16: the right operand as bf16 rows -- bf16 storage mode; `right` may then be NULL on the row-balanced / forward kernels)
+int gemm_mode();      // gh_set_gemm_mode's current value
 // (rowg + dw_tmp [ceil(dr / 512)][rows][heads] + dw_written: many-pair launches may take the row-balanced kernel, which leaves the raw
 //  dw in dw_tmp instead of de -- *dw_written = the number of column ranges (<= 16) rows wider than 512 floats were split into, whose
 //  partial dw sit rows * heads floats apart -- and launch_att_dpre(dw_in = dw_tmp, weights, de_out = de, .., stride, ranges) finishes de)

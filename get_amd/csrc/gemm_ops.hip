@@ -70,6 +70,8 @@ static int g_gemm_mode = 0;       // 0: fp32 MFMA everywhere (default); 1: bf16 
 // operand could be served, the launch runs the in-register split (MODE 3) instead
 static bool x3p_substitute(Launch& L, hipStream_t s);
 
+int gemm_mode() { return g_gemm_mode; }
+
 static bool few_row_bf16() {
   static int v = -1;
   if (v < 0) v = measure_env("GH_FEW_BF16", 1);
@@ -849,8 +851,9 @@ int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* d
   hipStream_t s = (hipStream_t)stream;
   if (score_parts) *score_parts = 1;
   GH_REQUIRE(n > 0 && r > 0 && din > 0 && h > 0, "ggnn_cell_fwd: bad sizes n=%d r=%d din=%d h=%d", n, r, din, h);
-  // (out32 may be NULL when the fused scorer projection is the only fp32 consumer of the cell output: composite forward, first cell)
-  GH_REQUIRE(!bf || (din % 8 == 0 && h % 8 == 0 && (out32 || score_w)), "ggnn_cell_fwd_bf16: needs din %% 8 == 0, h %% 8 == 0 (din=%d h=%d) and out32", din, h);
+  // (out32 may be NULL when no consumer reads the cell output as fp32: composite forward -- the first cell's scorer projection is fused,
+  //  the second cell's word attention reads the bf16 rows)
+  GH_REQUIRE(!bf || (din % 8 == 0 && h % 8 == 0), "ggnn_cell_fwd_bf16: needs din %% 8 == 0, h %% 8 == 0 (din=%d h=%d)", din, h);
   if (!goff) { m_real = n * r; m_rows = n * r; }
   GH_REQUIRE(m_real >= 0 && m_real <= m_rows && m_rows <= n * r, "ggnn_cell_fwd: node-compact rows %d/%d do not fit n*r=%d", m_real, m_rows, n * r);
   const int M = m_rows;
@@ -1193,11 +1196,14 @@ int gh::att_fwd_impl(const float* left, int nl, const int32_t* rowu, const float
   const int32_t* urow = rowu ? rowu : rowg;
   const float* e_parts = nullptr;
   int n_parts = 0;
+  bool right_is16 = false;
   if (M > 0) {  // t = tanh(W1[:, xl:] . right_t + u) ; e = W2 t  (:140-141)
     // bf16 storage mode with the twins at hand (right16 = the producing cell's bf16 output, w1_16 = bf16(linear1.weight)): the
     // product runs on the bf16-storage kernel (v_mfma_f32_16x16x32_bf16 from bf16 LDS images, half the operand bytes) instead of
     // rounding fp32 fragments in registers (MODE 1) -- the same bf16 operand values, fp32 accumulation and fp32 t either way
     const bool use16 = right16 && w1_16 && g_gemm_mode == 1 && M >= 8192 && dr % 8 == 0 && (xl_in + dr) % 8 == 0 && xl_in % 8 == 0 && ha % 8 == 0;
+    GH_REQUIRE(use16 || right, "concat_att_fwd: no fp32 right operand and the bf16 twins do not apply");
+    right_is16 = use16;
     Batch bt(false, M, s, use16 && ha % 256 == 0);
     Problem p = use16 ? gemm_problem(M, ha, EPI_ATT, t, ha, (const float*)right16, dr,
                                      (const float*)((const unsigned short*)w1_16 + xl_in), xl_in + dr, dr, nullptr, 1)
@@ -1232,8 +1238,9 @@ int gh::att_fwd_impl(const float* left, int nl, const int32_t* rowu, const float
       GH_LAUNCH_CHECK();
     }
   }
+  // (bf16 storage mode: the weighted sum reads the bf16 rows the product above read -- the caller need not keep an fp32 copy)
   return launch_att_softmax_fwd(e, mask, right, goff, m_real, b, l, dr, heads, weights, attended, s, e_parts, n_parts,
-                                (long long)M * heads);   // (:142-147)
+                                (long long)M * heads, right_is16 ? right16 : nullptr);   // (:142-147)
 }
 
 extern "C" int gh_concat_att_fwd(const float* left, const float* right, const float* mask, const int32_t* goff,
@@ -1275,7 +1282,8 @@ int gh::att_bwd_impl(const float* left, const float* right, const int32_t* goff,
   float* dw2_part = nullptr;
   if (!weights_only) {
   int dw_written = 0;
-  if (int e = launch_att_softmax_bwd(right, weights, g_att, g_w, goff, m_real, b, l, dr, heads, de, dright, s, rowg, dw_tmp, &dw_written)) return e;
+  if (int e = launch_att_softmax_bwd(right, weights, g_att, g_w, goff, m_real, b, l, dr, heads, de, dright, s, rowg, dw_tmp, &dw_written,
+                                     use16 ? right16 : nullptr)) return e;
   // dW2 = de^T t rides along with the dpre pass (per-pair partials in the workspace, one reduce)
   const size_t dw2_bytes = (size_t)b * heads * ha * sizeof(float);
   const Workspace wsp = workspace_for(s);

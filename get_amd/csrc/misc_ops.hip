@@ -457,8 +457,16 @@ int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m
 }
 
 // ---------------------------------------------------------------------------- concat attention: masked softmax + weighted reduce
+// bf16 storage mode (R16): `right` is the producing cell's bf16 output (four values per 8-byte load, widened at the point of use --
+// the loads stay in flight as raw words), so that no fp32 copy of that output has to exist
+template <bool R16> struct RightVec { typedef float4 T; };
+template <> struct RightVec<true> { typedef uint2 T; };
+__device__ __forceinline__ float4 right_widen(const float4 v) { return v; }
+__device__ __forceinline__ float4 right_widen(const uint2 v) {
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
 // e [b][l][C] -> weights = softmax over l (two_branches_attention.py:142-146), attended[b][d][c] = sum_l right[b][l][d] w[l][c] (:147)
-template <int CT>     // compile-time bound on the number of heads (accumulator registers)
+template <int CT, bool R16 = false>     // compile-time bound on the number of heads (accumulator registers); R16: right holds bf16
 __global__ void __launch_bounds__(256, 4)
 att_softmax_fwd_kernel(float* __restrict__ e, const float* __restrict__ mask, const float* __restrict__ right,
                        const int32_t* __restrict__ goff, int Lmax, int Dr, int C, float* __restrict__ weights,
@@ -485,11 +493,14 @@ att_softmax_fwd_kernel(float* __restrict__ e, const float* __restrict__ mask, co
   int dcl[NCH];
 #pragma unroll
   for (int h = 0; h < NCH; ++h) dcl[h] = min(blockIdx.y * (64 * NCH) + lane + 64 * h, D4 - 1);
-  const float4* rb = reinterpret_cast<const float4*>(right + (size_t)row0 * Dr);
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  typedef typename RightVec<R16>::T RV;
+  const RV* rb = R16 ? reinterpret_cast<const RV*>(reinterpret_cast<const unsigned short*>(right) + (size_t)row0 * Dr)
+                     : reinterpret_cast<const RV*>(right + (size_t)row0 * Dr);
+  RV zero4;
+  __builtin_memset(&zero4, 0, sizeof(RV));
   // (unconditional loads from clamped rows / columns: a `cond ? load : 0` select makes the compiler route the load
   // through a flat pointer to a zero in scratch; clamped duplicates are loaded twice and never consumed)
-  float4 rv[RB][NCH];
+  RV rv[RB][NCH];
   if (L > 0) {
 #pragma unroll
     for (int u = 0; u < RB; ++u)
@@ -565,7 +576,7 @@ att_softmax_fwd_kernel(float* __restrict__ e, const float* __restrict__ mask, co
             const float w = ws[l * C + c];
 #pragma unroll
             for (int h = 0; h < NCH; ++h) {
-              const float4 r4 = rv[u][h];
+              const float4 r4 = right_widen(rv[u][h]);
               acc[h][0][c] += r4.x * w; acc[h][1][c] += r4.y * w; acc[h][2][c] += r4.z * w; acc[h][3][c] += r4.w * w;
             }
           }
@@ -596,19 +607,29 @@ att_softmax_fwd_kernel(float* __restrict__ e, const float* __restrict__ mask, co
 
 int launch_att_softmax_fwd(float* e, const float* mask, const float* right, const int32_t* goff, int m_real,
                            int b, int l, int dr, int heads, float* weights, float* attended, hipStream_t s,
-                           const float* e_parts, int n_parts, long long part_stride) {
-  GH_REQUIRE(dr % 4 == 0 && (reinterpret_cast<uintptr_t>(right) & 15) == 0, "att_softmax_fwd: right rows must be float4-shaped (dr=%d)", dr);
+                           const float* e_parts, int n_parts, long long part_stride, const void* right16) {
+  GH_REQUIRE(right || right16, "att_softmax_fwd: no right operand");
+  if (right16) {
+    GH_REQUIRE(dr % 4 == 0 && (reinterpret_cast<uintptr_t>(right16) & 7) == 0, "att_softmax_fwd: bf16 right rows must be 8-byte shaped (dr=%d)", dr);
+    right = reinterpret_cast<const float*>(right16);
+  }
+  GH_REQUIRE(dr % 4 == 0 && (right16 || (reinterpret_cast<uintptr_t>(right) & 15) == 0), "att_softmax_fwd: right rows must be float4-shaped (dr=%d)", dr);
   const int nthr = 256;      // (8 waves per pair measured no faster: the kernel is not parallelism-bound)
   const size_t lds = ((size_t)2 * l * heads + (nthr / 64) * 64 * (4 * heads + 1)) * 4;
   GH_REQUIRE(lds <= 64 * 1024, "att_softmax_fwd: sequence %d x heads %d too large", l, heads);
   prof_begin(s, b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_SOFTMAX_FWD);
   GH_REQUIRE(heads >= 1 && heads <= 8, "att_softmax_fwd: %d heads (1..8 supported)", heads);
   const dim3 grid(b, (dr / 4 + 127) / 128);
-  if (heads <= 2) hipLaunchKernelGGL(att_softmax_fwd_kernel<2>, grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended, e_parts, n_parts, part_stride);
+  if (right16) {
+    if (heads <= 2) hipLaunchKernelGGL((att_softmax_fwd_kernel<2, true>), grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended, e_parts, n_parts, part_stride);
+    else if (heads <= 5) hipLaunchKernelGGL((att_softmax_fwd_kernel<5, true>), grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended, e_parts, n_parts, part_stride);
+    else hipLaunchKernelGGL((att_softmax_fwd_kernel<8, true>), grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended, e_parts, n_parts, part_stride);
+  }
+  else if (heads <= 2) hipLaunchKernelGGL(att_softmax_fwd_kernel<2>, grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended, e_parts, n_parts, part_stride);
   else if (heads <= 5) hipLaunchKernelGGL(att_softmax_fwd_kernel<5>, grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended, e_parts, n_parts, part_stride);
   else hipLaunchKernelGGL(att_softmax_fwd_kernel<8>, grid, dim3(nthr), lds, s, e, mask, right, goff, l, dr, heads, weights, attended, e_parts, n_parts, part_stride);
   const double rows = goff ? (double)m_real : (double)b * l;
-  prof_end(b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_SOFTMAX_FWD, 4.0 * (rows * dr + 2.0 * rows * heads + rows + (double)b * dr * heads), s);
+  prof_end(b < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_ATT_SOFTMAX_FWD, (right16 ? 2.0 : 4.0) * rows * dr + 4.0 * (2.0 * rows * heads + rows + (double)b * dr * heads), s);
   GH_LAUNCH_CHECK();
   return 0;
 }
@@ -782,7 +803,7 @@ att_softmax_bwd_kernel(const float* __restrict__ right, const float* __restrict_
 // contiguous in g_att's [Dr][C] layout), writes dright rows and the raw dw[row][c] = right[row] . g_att[pair][:, c] (+ g_w);
 // the per-pair part of the softmax backward (de = w (dw - sum_l w dw)) moves into att_dpre_kernel's prologue, which
 // stages those few values per pair anyway.  <= 128 VGPRs: 16 waves per CU, three rows in flight per wave.
-template <int CT>      // exact number of heads
+template <int CT, bool R16 = false>      // exact number of heads; R16: right holds bf16
 __global__ void __launch_bounds__(256, CT <= 5 ? 4 : 3)
 att_rows_bwd_kernel(const float* __restrict__ right, const float* __restrict__ weights, const float* __restrict__ g_att,
                     const float* __restrict__ g_w, const int32_t* __restrict__ rowg, int Lmax, int Dr, int C, int M,
@@ -803,7 +824,8 @@ att_rows_bwd_kernel(const float* __restrict__ right, const float* __restrict__ w
 #pragma unroll
   for (int h = 0; h < NCH; ++h) dcl[h] = col0 + min(lane + 64 * h, ncol - 1);
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4* rp = reinterpret_cast<const float4*>(right);
+  typedef typename RightVec<R16>::T RV;
+  const RV* rp = reinterpret_cast<const RV*>(right);
   // this wave's softmax weights and pair ids, staged once into its private LDS region: a per-row global load in the
   // loop (weights[l][c], rowg[l]) put one unhidden memory latency into every iteration
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
@@ -814,7 +836,7 @@ att_rows_bwd_kernel(const float* __restrict__ right, const float* __restrict__ w
   for (int i = lane; i < nr * CT; i += 64) wl[i] = weights[(size_t)r0 * CT + i];
   for (int i = lane; i < nr; i += 64) pl[i] = rowg ? rowg[r0 + i] : (r0 + i) / Lmax;
   // three rows in flight (loads unconditional from clamped rows; duplicates are never consumed)
-  float4 ra[NCH], rb[NCH], rc[NCH];
+  RV ra[NCH], rb[NCH], rc[NCH];
 #pragma unroll
   for (int h = 0; h < NCH; ++h) {
     ra[h] = rp[(size_t)r0 * D4 + dcl[h]];
@@ -826,7 +848,7 @@ att_rows_bwd_kernel(const float* __restrict__ right, const float* __restrict__ w
   // one row: `buf` holds it (requested three rows ago); its slot is re-requested for row l + 3 right away.  The three slots
   // keep their roles (the loop is unrolled by three): rotating them through register moves would make every iteration wait
   // for ALL outstanding loads -- a move out of a register that a load is still filling waits for that load.
-  auto step = [&](int l, float4 (&buf)[NCH]) __attribute__((always_inline)) {
+  auto step = [&](int l, RV (&buf)[NCH]) __attribute__((always_inline)) {
     if (l >= r1) return;
     const int pair = pl[l - r0];
     if (pair != cur) {          // wave-uniform: this pair's g_att columns, 4 C consecutive floats per lane and chunk
@@ -849,7 +871,7 @@ att_rows_bwd_kernel(const float* __restrict__ right, const float* __restrict__ w
     }
     float4 cu[NCH];
 #pragma unroll
-    for (int h = 0; h < NCH; ++h) cu[h] = buf[h];
+    for (int h = 0; h < NCH; ++h) cu[h] = right_widen(buf[h]);
     if (l + 3 < r1) {
 #pragma unroll
       for (int h = 0; h < NCH; ++h) buf[h] = rp[(size_t)(l + 3) * D4 + dcl[h]];
@@ -892,9 +914,10 @@ att_rows_bwd_kernel(const float* __restrict__ right, const float* __restrict__ w
 }
 int launch_att_softmax_bwd(const float* right, const float* weights, const float* g_att, const float* g_w,
                            const int32_t* goff, int m_real, int b, int l, int dr, int heads, float* de, float* dright,
-                           hipStream_t s, const int32_t* rowg, float* dw_tmp, int* dw_written) {
-  GH_REQUIRE(dr % 4 == 0 && (reinterpret_cast<uintptr_t>(right) & 15) == 0 && (reinterpret_cast<uintptr_t>(dright) & 15) == 0,
-             "att_softmax_bwd: right rows must be float4-shaped (dr=%d)", dr);
+                           hipStream_t s, const int32_t* rowg, float* dw_tmp, int* dw_written, const void* right16) {
+  GH_REQUIRE(right || right16, "att_softmax_bwd: no right operand");
+  GH_REQUIRE(dr % 4 == 0 && (reinterpret_cast<uintptr_t>(right) & 15) == 0 && (reinterpret_cast<uintptr_t>(right16) & 7) == 0 &&
+             (reinterpret_cast<uintptr_t>(dright) & 15) == 0, "att_softmax_bwd: right rows must be float4-shaped (dr=%d)", dr);
   if (dw_written) *dw_written = 0;
   // many pairs, rows that fit two float4 chunks per lane, 16-byte aligned g_att rows: the row-balanced kernel; de is then
   // finished by att_dpre's prologue (launch_att_dpre with dw_in)
@@ -916,18 +939,24 @@ int launch_att_softmax_bwd(const float* right, const float* weights, const float
                                        (const void*)att_rows_bwd_kernel<3>, (const void*)att_rows_bwd_kernel<4>,
                                        (const void*)att_rows_bwd_kernel<5>, (const void*)att_rows_bwd_kernel<6>,
                                        (const void*)att_rows_bwd_kernel<7>, (const void*)att_rows_bwd_kernel<8>};
-    const void* fn = fns[heads - 1];
+    static const void* const fns16[8] = {(const void*)att_rows_bwd_kernel<1, true>, (const void*)att_rows_bwd_kernel<2, true>,
+                                         (const void*)att_rows_bwd_kernel<3, true>, (const void*)att_rows_bwd_kernel<4, true>,
+                                         (const void*)att_rows_bwd_kernel<5, true>, (const void*)att_rows_bwd_kernel<6, true>,
+                                         (const void*)att_rows_bwd_kernel<7, true>, (const void*)att_rows_bwd_kernel<8, true>};
+    const void* fn = right16 ? fns16[heads - 1] : fns[heads - 1];
+    if (right16) right = reinterpret_cast<const float*>(right16);
     int Mv = M, rpwv = rpw;
     const int ranges = (dr / 4 + 127) / 128;
     int d4h = (dr / 4 + ranges - 1) / ranges;
     void* args[] = {(void*)&right, (void*)&weights, (void*)&g_att, (void*)&g_w, (void*)&rowg, (void*)&l, (void*)&dr, (void*)&heads,
                     (void*)&Mv, (void*)&rpwv, (void*)&dw_tmp, (void*)&dright, (void*)&d4h};
     (void)hipLaunchKernel(fn, dim3(nwg, ranges), dim3(256), args, lds_rows, s);
-    prof_end(ptag, 4.0 * (2.0 * M * dr + 3.0 * M * heads + (double)b * dr * heads), s);
+    prof_end(ptag, (right16 ? 6.0 : 8.0) * M * dr + 4.0 * (3.0 * M * heads + (double)b * dr * heads), s);
     GH_LAUNCH_CHECK();
     *dw_written = ranges;
     return 0;
   }
+  GH_REQUIRE(right, "att_softmax_bwd: the per-pair kernel (few pairs / no row map) reads an fp32 right operand");
   const size_t lds = ((size_t)dr * heads + 2 * (size_t)l * heads) * 4;
   GH_REQUIRE(lds <= 160 * 1024, "att_softmax_bwd: %zu B of LDS needed", lds);
   GH_REQUIRE(heads >= 1 && heads <= 8, "att_softmax_bwd: %d heads (1..8 supported)", heads);

@@ -18,6 +18,8 @@ struct Dims {
   bool compact;
   int Mr, Mt, M1, Mq;
   bool bf;            // the two evidence cells run the bf16 storage pipeline (model->storage = 1 and the shapes qualify)
+  bool att16;         // bf16 storage and the word attention runs on the bf16 twins (gemm mode 1, twins of linear1.weight at hand): the second
+                      // cell's output exists as bf16 rows only -- no fp32 copy (190 MB at h = 768), the attention's streaming kernels read the bf16 rows
   bool fuse_scorer;   // the GSL scorer's projection rides in the first cell's last epilogue (whole rows in <= 2 column blocks: h <= 320)
 };
 // out32: the fp32 cell output (== out in fp32 storage; a buffer of its own beside the bf16 twin `out` in bf16 storage)
@@ -77,6 +79,9 @@ static int make_dims(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d) {
                  "get: storage = 1 needs the bf16 twins of both evidence cells' weights (gh_weights_refresh)");
     GH_REQUIRE(Mo->embedding16, "get: storage = 1 needs the bf16 copy of the word table (embedding16)");
   }
+  static int att16_on = -1;
+  if (att16_on < 0) att16_on = measure_env("GH_ATT16", 1);
+  d.att16 = d.bf && gemm_mode() == 1 && Mo->att_word_w1_16 && Mo->att_word_w1t_16 && att16_on;
   return 0;
 }
 
@@ -112,7 +117,7 @@ static int layout(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d, FwdBu
   const bool pre_drop = d.bf && Ba->drop_gnn > 0.f;
   cell_buf(b, f.c1, d.M1, d.H, d.bf, !d.bf, pre_drop ? d.D : 0);
   f.score_x = b.take((int64_t)d.M1 * ((d.fuse_scorer || !d.bf) ? 1 : 8));
-  cell_buf(b, f.c2, d.Mr, d.H, d.bf, true, pre_drop ? d.H : 0);
+  cell_buf(b, f.c2, d.Mr, d.H, d.bf, !d.att16, pre_drop ? d.H : 0);
   f.uw = b.take((int64_t)d.B * d.H); f.tw = b.take((int64_t)d.Mr * d.H); f.ew = b.take((int64_t)d.Mr * d.hw);
   f.avg = b.take((int64_t)d.B1 * d.Xa);
   f.new_left = d.cs > 0 ? b.take((int64_t)d.B * d.Xl) : f.q_repr;
@@ -477,7 +482,7 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
                   Ba->drop_gnn, Ba->seed_cell2, nullptr, nullptr, 0.f, 0, s));
   GH_TRY(stream_after(s, ss, ev.ev[1]));
   // ---- word-level attention (:173-193): the left input is the claim vector -> ONE u row per claim
-  GH_TRY(att_fwd_impl(A + f.q_repr, d.B, I32(A, f.rowc), A + f.c2.out32, d.compact ? Ba->maskf : A + f.maskf_p, goff,
+  GH_TRY(att_fwd_impl(A + f.q_repr, d.B, I32(A, f.rowc), f.c2.out32 >= 0 ? A + f.c2.out32 : nullptr, d.compact ? Ba->maskf : A + f.maskf_p, goff,
                       d.compact ? Ba->rowg : nullptr, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1, Mo->att_word.w2, A + f.uw, A + f.tw,
                       A + f.ew, O + f.ww, A + f.avg, s, 2, d.bf ? (const void*)(A + f.c2.out) : nullptr, d.bf ? Mo->att_word_w1_16 : nullptr));
   // ---- evidence-level assembly + attention (:157-171, :195-221)
@@ -561,14 +566,14 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
     // ---- word-level attention: per-pair du summed per claim; d(claim vector) accumulates on top of the head / evidence part.
     //      Its dright GEMM produces the gradient of the second evidence cell's output and nothing else reads it: the GEMM's
     //      epilogue applies that cell's gate head (gf2); likewise the second cell's dX GEMM feeds the first cell's (gf1).
-    GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out32, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
+    GH_TRY(att_bwd_impl(A + f.q_repr, f.c2.out32 >= 0 ? A + f.c2.out32 : nullptr, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
                         O + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, Wb + w.g2, nullptr,
                         Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, s, d.compact ? Ba->rowg : nullptr, Wb + w.dw_w,
                         fuse_gate ? &gf2 : nullptr, 1, Wb + w.dw2p_w, att_r16, att_w1t16));
     // ---- side stream: linear1's weight gradient of the word attention, then the claim branch's backward -- underneath
     //      the evidence cells' chain on the main stream
     GH_TRY(stream_after(ss, s, ev.ev[4]));
-    GH_TRY(att_bwd_impl(A + f.q_repr, A + f.c2.out32, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
+    GH_TRY(att_bwd_impl(A + f.q_repr, f.c2.out32 >= 0 ? A + f.c2.out32 : nullptr, goff, d.Mr, d.B1, d.R, H, H, H, d.hw, Mo->att_word.w1t, Mo->att_word.w2, A + f.tw,
                         O + f.ww, Wb + w.d_avg, g_word_w, Wb + w.de_w, Wb + w.dpre_w, Wb + w.du_w, Wb + w.d_q, nullptr, Mo->att_word.dw1,
                         Mo->att_word.dw2, I32(A, f.offsets), d.B, Wb + w.du_c, 1, ss, nullptr, nullptr, nullptr, 1, Wb + w.dw2p_w, att_r16,
                         att_w1t16));
