@@ -418,13 +418,16 @@ def test_adam_flat_matches_torch():
 
 
 # ---------------------------------------------------------------- fused (in-kernel) dropout
-def test_fused_dropout_matches_masked_oracle():
+@pytest.mark.parametrize("n", [6, 90])
+def test_fused_dropout_matches_masked_oracle(n):
     """Training-mode input dropout of the GGNN cell is applied inside the GEMM loaders with a stateless
     hash mask: replaying the same mask on the host, output and every gradient must equal the oracle cell
-    run on x * mask / (1 - p) (so forward, dW_proj and dX all use one consistent mask)."""
+    run on x * mask / (1 - p) (so forward, dW_proj and dX all use one consistent mask).
+    n = 90: 9000 rows -- the activation-sized launches, whose weight-gradient kernel gathers the embedding rows and masks
+    its B fragments itself (no materialised masked operand)."""
     from get_amd import modules, ops
     rng = np.random.default_rng(31)
-    n, r, d, h, p_drop, seed = 6, 100, 48, 64, 0.25, 123457
+    r, d, h, p_drop, seed = 100, 48, 64, 0.25, 123457
     toks, lens, ids, adj = cases.graphs(rng, n, r, 3, O.convert_text, vocab=80)
     x = rng.standard_normal((n, r, d)).astype(np.float32)
     prm = cases.cell_params(rng, d, h)
@@ -455,6 +458,15 @@ def test_fused_dropout_matches_masked_oracle():
     oo2 = O.ggnn_cell(torch.from_numpy(adj).float(), xe * torch.from_numpy(keep).float() / (1 - p_drop),
                       {k: v.detach() for k, v in po.items()})
     assert maxerr(out2.detach().cpu(), oo2) <= 2e-5
+    # ... and so does the projection's weight gradient on that path (ids + mask inside the weight-gradient kernel's loader)
+    mod.zero_grad()
+    (out2 * T(gw)).sum().backward()
+    po2 = {k: v.detach().clone().requires_grad_(True) for k, v in po.items()}
+    oo2g = O.ggnn_cell(torch.from_numpy(adj).float(), xe * torch.from_numpy(keep).float() / (1 - p_drop), po2)
+    (oo2g * torch.from_numpy(gw)).sum().backward()
+    for name, q in mod.named_parameters():
+        go = po2[name].grad
+        assert maxerr(q.grad.cpu(), go) <= 1e-3 * float(go.abs().max()) + 1e-5, name
     # module-level: train mode draws a fresh seed per call, eval mode is deterministic
     mod.train(True)
     a1, a2 = mod(padj, T(x)), mod(padj, T(x))
