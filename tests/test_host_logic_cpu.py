@@ -103,3 +103,17 @@ def test_prefetch_reference_yields_in_order_on_plain_tensors():
         assert torch.equal(k["doc_content_without_padding_evidences"], ref["doc_content_without_padding_evidences"])
         assert torch.equal(k["docs_adj"], ref["docs_adj"])
         assert k["doc_content_without_padding_evidences"].shape[0] == int(item[4].sum())
+
+
+def test_bench_block_statistics_tolerate_one_hiccup_block():
+    """bench.summarize_blocks: the value is the median block; ONE block far off the median is counted (`outlier_blocks`, both spreads
+    printed) without condemning the leg, several such blocks flag it `unstable`."""
+    import bench
+    one = bench.summarize_blocks({"blocks_s": [0.063] * 7 + [0.095], "settle_s": [0.063, 0.0631]}, 10, [9600] * 8)
+    assert "unstable" not in one["timed"] and one["timed"]["outlier_blocks"] == 1
+    assert one["timed"]["spread_rel"] > 0.3 and one["timed"]["spread_rel_without_outliers"] == 0.0
+    assert abs(one["value"] - 9600 / 0.063) < 1e-6
+    many = bench.summarize_blocks({"blocks_s": [0.063] * 5 + [0.095] * 3, "settle_s": []}, 10, [9600] * 8)
+    assert many["timed"]["unstable"] and many["timed"]["outlier_blocks"] == 3
+    calm = bench.summarize_blocks({"blocks_s": [0.063, 0.0632, 0.0629, 0.0631, 0.063], "settle_s": []}, 10, [9600] * 5)
+    assert "unstable" not in calm["timed"] and calm["timed"]["outlier_blocks"] == 0 and "spread_rel_without_outliers" not in calm["timed"]
