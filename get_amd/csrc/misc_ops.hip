@@ -1291,6 +1291,12 @@ evd_assemble_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__
     float* d = d_avg + (size_t)(lo + slot) * Xa;
     for (int i = threadIdx.x; i < Xa; i += blockDim.x) d[i] = gp[i];
   }
+  // pairs beyond the claim's n_max-th evidence have no slot: their gradient rows are zeros, written by the claim's last slot (the
+  // caller's d_avg needs no fill in front of this kernel)
+  if (slot == n_max - 1 && d_avg) {
+    const size_t z0 = (size_t)(lo + n_max) * Xa, z1 = (size_t)offsets[b + 1] * Xa;
+    for (size_t i = z0 + threadIdx.x; i < z1; i += blockDim.x) d_avg[i] = 0.f;
+  }
   if (Ds <= 0 || !d_table) return;
   // Padding slots (slot >= the claim's evidence count) are masked out of the evidence-level softmax, so their gradient
   // rows are exact zeros: they neither own nor join a source row (-1 never matches).  Without this every padding slot

@@ -558,9 +558,8 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
       GH_LAUNCH_CHECK();
     }
     // ---- evidence-level assembly: d_avg (rows of claims with more than n_max evidences stay zero), article-source table
-    // (always: rows of claims with more than n_max evidences are never written by the assembly's backward.  `counts_fit` used to
-    //  skip these 3 us on the caller's word; a wrong promise fed uninitialised memory into the gradients -- ADVICE r3)
-    GH_CHECK_HIP(hipMemsetAsync(Wb + w.d_avg, 0, sizeof(float) * (size_t)d.B1 * d.Xa, s));
+    // (rows of claims with more than n_max evidences have no slot in the assembly: its backward writes their zeros itself -- the
+    //  claim's last slot does -- so no fill of d_avg runs in front of it; ADVICE r3's uninitialised-memory case stays covered)
     GH_TRY(gh_evd_assemble_bwd(Wb + w.dright_e, I32(A, f.offsets), d.as > 0 ? Ba->doc_sources : nullptr, Ba->doc_sources_i64, Mo->article_src_rows, d.B, d.n, d.Xa,
                                d.as, Wb + w.d_avg, d.as > 0 ? Mo->d_article_src_table : nullptr, (void*)s));
     // ---- word-level attention: per-pair du summed per claim; d(claim vector) accumulates on top of the head / evidence part.

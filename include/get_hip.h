@@ -297,7 +297,8 @@ int gh_evd_assemble_fwd(const float* avg, const int32_t* offsets, const float* t
                         float* right, float* mask, gh_stream_t stream);
 /* Backward: d_avg[b1][xa] (NULL ok) = unpad(g[:, :, :xa]); d_table[s][ds] += the g[:, :, xa:] rows of the slots with source s,
  * summed in slot order (deterministic).  g [b][n_max][xa+ds] -- ds is g's row pitch as well: pass the real width even
- * when d_table is NULL (a frozen table just skips the table part).  At most 38 000 slots (b * n_max) per call. */
+ * when d_table is NULL (a frozen table just skips the table part).  At most 38 000 slots (b * n_max) per call.
+ * EVERY row of d_avg is written (rows of a claim's evidences beyond its n_max-th receive zeros): the caller need not clear it. */
 int gh_evd_assemble_bwd(const float* g, const int32_t* offsets, const void* sources, int sources_i64, int table_rows, int b, int n_max,
                         int xa, int ds, float* d_avg, float* d_table, gh_stream_t stream);
 /* Out-of-range inputs the kernels clamped for memory safety where the reference would have RAISED (nn.Embedding /

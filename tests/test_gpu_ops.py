@@ -727,3 +727,31 @@ def test_bf16_storage_cell_tracks_fp32(bf16_mode, compact, drop_p):
     assert float((dx16 - dx32).abs().max()) <= 5e-2 * float(dx32.abs().max())
     for k in g32:
         assert float((g16[k] - g32[k]).abs().max()) <= 5e-2 * float(g32[k].abs().max()) + 1e-6, k
+
+
+def test_evd_assemble_bwd_writes_every_row_of_d_avg():
+    """gh_evd_assemble_bwd needs no cleared d_avg: the rows of real (claim, slot) pairs receive their gradient, the rows of a claim's
+    evidences beyond its n_max-th (no slot in the padded tensor) receive zeros -- checked on a NaN-filled buffer with one claim over
+    n_max, one empty claim and one exactly at n_max."""
+    from get_amd import ops
+    from get_amd._lib import call, ptr, stream
+    rng = np.random.default_rng(5)
+    n_max, xa, ds = 4, 24, 8
+    counts = np.array([2, 7, 0, 4, 1], dtype=np.int64)            # 7 > n_max: pairs 4..6 of that claim have no slot
+    b, b1 = len(counts), int(counts.sum())
+    seg = ops.Segments(T(counts), b1, n_max)
+    g = rng.standard_normal((b, n_max, xa + ds)).astype(np.float32)
+    src = rng.integers(0, 6, size=(b, n_max)).astype(np.int32)
+    d_avg = torch.full((b1, xa), float("nan"), device=DEV)
+    d_table = torch.zeros((6, ds), device=DEV)
+    gt, st = T(g), T(src)
+    call("gh_evd_assemble_bwd", ptr(gt), ptr(seg.offsets), ptr(st), 0, 6, b, n_max, xa, ds, ptr(d_avg), ptr(d_table), stream())
+    torch.cuda.synchronize()
+    got = d_avg.cpu().numpy()
+    assert np.isfinite(got).all()
+    lo = 0
+    for c, n in enumerate(counts):
+        for j in range(int(n)):
+            want = g[c, j, :xa] if j < n_max else np.zeros(xa, np.float32)
+            assert np.array_equal(got[lo + j], want), (c, j)
+        lo += int(n)
