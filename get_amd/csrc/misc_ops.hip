@@ -1118,6 +1118,7 @@ int launch_att_dpre(const float* de, const float* w2, const float* t, const int3
   // 5 / 3 / 2 / 1 slabs (GH_DPRE_SLABS) once the row batches are prefetched
   static int nsl_env = -1;
   if (nsl_env < 0) nsl_env = measure_env("GH_DPRE_SLABS", 0);
+  // (round 5: 3 / 5 / 8 slabs for the few-pair launches -- evidence level, 32 workgroups of 30 rows -- measured: no effect on the step)
   const int nsl = nsl_env > 0 ? nsl_env : (n4 + 127) / 128;
   const int S4 = (n4 + nsl - 1) / nsl;
   const int RL = (256 / S4) > 0 ? (256 / S4) : 1;
@@ -1398,6 +1399,128 @@ tiny_linear_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
     for (int r = 0; r < m; ++r) acc += g[(size_t)r * n + threadIdx.x];
     db[threadIdx.x] += acc;
   }
+}
+
+// ---------------------------------------------------------------------------- head backward in ONE launch (composite path)
+// graph_based_semantic_structure.py:69-74: phi = out1(out0([left | att])) with no activation between.  Backward of both layers' inputs:
+//   d_y0[b][k]   = sum_c g_phi[b][c] w1[c][k]                       (H values per claim; tiny: every workgroup makes its own copy in LDS)
+//   d_in[b][j]   = sum_k d_y0[b][k] w0[k][j]                        (j < E = Xl + X1: the first Xl go to dx0, the rest to dx1)
+//   dw1[c][k]   += sum_b g_phi[b][c] y0[b][k],  db1[c] += sum_b g_phi[b][c]
+// It replaces tiny_linear_bwd (5 workgroups walking the claims serially), a 48-workgroup split-K GEMM and its finish kernel --
+// 33 us of launch latency for 0.07 GFLOP.  One workgroup per 64 columns j: wave kg takes the k range [kg H/4, (kg+1) H/4), a lane one
+// column, 32 claims at a time in registers; w0 is read once (coalesced along j), d_y0 comes from LDS as wave-uniform 16-byte reads.
+// The weight gradients of out0 (d_y0^T [left | att]) stay with the side stream's TN launch, which reads the d_y0 this kernel writes.
+__global__ void __launch_bounds__(256)
+head_bwd_kernel(const float* __restrict__ g_phi, const float* __restrict__ y0, const float* __restrict__ w1, const float* __restrict__ w0,
+                int B, int H, int C, int Xl, int E, float* __restrict__ d_y0, float* __restrict__ dw1, float* __restrict__ db1,
+                float* __restrict__ dx0, int dx0_accumulate, float* __restrict__ dx1, int dy_floats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  float* dy = reinterpret_cast<float*>(dsm);                 // [32][H]; re-used as the partials [16][32][17] after the K loop
+  float* w1s = dy + dy_floats;                               // [C][H]
+  float* gs = w1s + (size_t)C * H;                           // [B][C]
+  float* ys = gs + (size_t)B * C;                            // [nk][B]: y0 columns of this workgroup's share of dw1
+  const int tid = threadIdx.x, col = tid & 15, kg = tid >> 4;       // 16 columns x 16 k ranges per workgroup
+  const int j = blockIdx.x * 16 + col;
+  const int jc = min(j, E - 1);
+  const int H4 = H / 4;
+  const int kq0 = (kg * H4) / 16, kq1 = ((kg + 1) * H4) / 16;     // this thread's range of float4 k-groups
+  // everything small is staged once with independent loads (a per-element walk over g_phi / w1 / y0 in global memory put one
+  // memory latency into every iteration: 37 us for this kernel)
+  const int G = gridDim.x;
+  const int nk = dw1 ? max(0, (H - (int)blockIdx.x + G - 1) / G) : 0;      // workgroup w owns the k with k % G == w
+  for (int i = tid; i < C * H; i += 256) w1s[i] = w1[i];
+  for (int i = tid; i < B * C; i += 256) gs[i] = g_phi[i];
+  for (int i = tid; i < nk * B; i += 256) { const int kk = i / B, b = i - kk * B; ys[i] = y0[(size_t)b * H + blockIdx.x + kk * G]; }
+  __syncthreads();
+  for (int i = tid; i < nk * C; i += 256) {
+    const int kk = i / C, c = i - kk * C;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += gs[b * C + c] * ys[kk * B + b];
+    dw1[(size_t)c * H + blockIdx.x + kk * G] += acc;
+  }
+  if (db1 && blockIdx.x == 0 && tid < C) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += gs[b * C + tid];
+    db1[tid] += acc;
+  }
+  for (int b0 = 0; b0 < B; b0 += 32) {
+    const int nb = min(32, B - b0);
+    __syncthreads();                                         // (the previous chunk's partials are consumed)
+    for (int i = tid; i < 32 * H; i += 256) {
+      const int b = i / H, k = i - b * H;
+      float v = 0.f;
+      if (b < nb)
+        for (int c = 0; c < C; ++c) v += gs[(b0 + b) * C + c] * w1s[c * H + k];
+      dy[i] = v;
+      if (blockIdx.x == 0 && b < nb) d_y0[(size_t)(b0 + b) * H + k] = v;
+    }
+    __syncthreads();
+    float acc[32];
+#pragma unroll
+    for (int b = 0; b < 32; ++b) acc[b] = 0.f;
+    // eight k-groups (32 rows of w0) requested before any of them is used: one memory round trip per thread for H <= 512
+    for (int kq = kq0; kq < kq1; kq += 8) {
+      float wv[8][4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = 4 * min(kq + u, kq1 - 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wv[u][i] = w0[(size_t)(k + i) * E + jc];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (kq + u >= kq1) break;
+        const int k = 4 * (kq + u);
+#pragma unroll
+        for (int b = 0; b < 32; ++b) {
+          const float4 d4 = *reinterpret_cast<const float4*>(dy + b * H + k);
+          acc[b] += d4.x * wv[u][0] + d4.y * wv[u][1] + d4.z * wv[u][2] + d4.w * wv[u][3];
+        }
+      }
+    }
+    __syncthreads();                                         // every wave is done with dy: it becomes the partial buffer
+    float* red = dy;                                         // [16 k ranges][32][16 columns + 1]
+#pragma unroll
+    for (int b = 0; b < 32; ++b) red[(kg * 32 + b) * 17 + col] = acc[b];
+    __syncthreads();
+    for (int i = tid; i < 32 * 16; i += 256) {
+      const int b = i >> 4, l = i & 15, jj = blockIdx.x * 16 + l;
+      if (b >= nb || jj >= E) continue;
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v += red[(r * 32 + b) * 17 + l];
+      if (jj < Xl) {
+        if (dx0) { float* o = dx0 + (size_t)(b0 + b) * Xl + jj; *o = dx0_accumulate ? *o + v : v; }
+      } else if (dx1) {
+        dx1[(size_t)(b0 + b) * (E - Xl) + (jj - Xl)] = v;
+      }
+    }
+  }
+}
+
+// LDS bytes of head_bwd_kernel for these sizes (0: does not fit -- the caller keeps the three-launch path)
+size_t head_bwd_lds(int B, int H, int C, int E) {
+  const int G = (E + 15) / 16;
+  const size_t dyf = (size_t)32 * H > (size_t)16 * 32 * 17 ? (size_t)32 * H : (size_t)16 * 32 * 17;
+  const size_t fl = dyf + (size_t)C * H + (size_t)B * C + (size_t)((H + G - 1) / G) * B;
+  return fl * 4 <= 160 * 1024 ? fl * 4 : 0;
+}
+
+int launch_head_bwd(const float* g_phi, const float* y0, const float* w1, const float* w0, int B, int H, int C, int Xl, int E,
+                    float* d_y0, float* dw1, float* db1, float* dx0, int dx0_accumulate, float* dx1, hipStream_t s) {
+  GH_REQUIRE(B > 0 && H > 0 && H % 4 == 0, "head_bwd: hidden width %d must be a multiple of 4", H);
+  GH_REQUIRE(C >= 1 && C <= 8 && Xl >= 0 && Xl <= E && d_y0, "head_bwd: bad sizes (C=%d Xl=%d E=%d)", C, Xl, E);
+  const size_t lds = head_bwd_lds(B, H, C, E);
+  GH_REQUIRE(lds > 0, "head_bwd: B=%d, H=%d do not fit the kernel's LDS staging", B, H);
+  if (lds > 64 * 1024) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  }
+  const int dyf = 32 * H > 16 * 32 * 17 ? 32 * H : 16 * 32 * 17;
+  hipLaunchKernelGGL(head_bwd_kernel, dim3((E + 15) / 16), dim3(256), lds, s, g_phi, y0, w1, w0, B, H, C, Xl, E, d_y0, dw1, db1, dx0,
+                     dx0_accumulate, dx1, dyf);
+  GH_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_tiny_linear_fwd(const float* x, const float* w, const float* bias, float* y, int m, int k, int n, hipStream_t s) {

@@ -531,9 +531,17 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
   const float* table1 = d.bf ? (const float*)Mo->embedding16 : Mo->embedding;
   if (phase != 2) {
     // ---- head
-    GH_TRY(gh_linear_bwd(A + f.y0, Mo->out1_wt, Mo->out1_w, g_phi, d.B, H, d.C, Wb + w.d_y0, Mo->d_out1_w, Mo->d_out1_b, (void*)s));
-    GH_TRY(linear2_bwd(A + f.new_left, d.Xl, A + f.att_e, d.Dre * d.he, Mo->out0_wt, Wb + w.d_y0, d.B, H, Wb + w.d_new_left, 0,
-                       Wb + w.d_att_e, nullptr, nullptr, s));
+    static int head_fused = -1;
+    if (head_fused < 0) head_fused = measure_env("GH_HEAD_BWD", 1);
+    if (head_fused && d.C <= 8 && H % 4 == 0 && Mo->out0_w && Mo->out1_w && head_bwd_lds(d.B, H, d.C, d.E) > 0) {
+      // both layers' input gradients and the second layer's weight gradients in one launch (head_bwd_kernel)
+      GH_TRY(launch_head_bwd(g_phi, A + f.y0, Mo->out1_w, Mo->out0_w, d.B, H, d.C, d.Xl, d.E, Wb + w.d_y0, Mo->d_out1_w, Mo->d_out1_b,
+                             Wb + w.d_new_left, 0, Wb + w.d_att_e, s));
+    } else {
+      GH_TRY(gh_linear_bwd(A + f.y0, Mo->out1_wt, Mo->out1_w, g_phi, d.B, H, d.C, Wb + w.d_y0, Mo->d_out1_w, Mo->d_out1_b, (void*)s));
+      GH_TRY(linear2_bwd(A + f.new_left, d.Xl, A + f.att_e, d.Dre * d.he, Mo->out0_wt, Wb + w.d_y0, d.B, H, Wb + w.d_new_left, 0,
+                         Wb + w.d_att_e, nullptr, nullptr, s));
+    }
     GH_TRY(stream_after(ss, s, ev.ev[2]));          // few-row weight gradients leave the critical path
     GH_TRY(linear2_bwd(A + f.new_left, d.Xl, A + f.att_e, d.Dre * d.he, Mo->out0_wt, Wb + w.d_y0, d.B, H, nullptr, 0, nullptr,
                        Mo->d_out0_w, Mo->d_out0_b, ss));
