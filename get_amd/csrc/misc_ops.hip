@@ -1012,13 +1012,6 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
 #pragma unroll
     for (int u = 0; u < RB; ++u) nxt[u] = tb[(size_t)min(rl + u * RL, L - 1) * n4];
   }
-  // (this lane's w2 columns are requested here, in front of the staging phase and its barriers: one memory round trip less)
-  float4 wc[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    wc[c] = reinterpret_cast<const float4*>(w2 + (size_t)min(c, C - 1) * Ha)[c4c];
-    if (c >= C || !act) wc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
   if (dw_in) {
     // second half of the softmax backward, per pair (att_rows_bwd_kernel left the raw dw): de = w (dw - sum_l w dw)
     float* wl = des + (size_t)Lmax * C;                    // [L][C] softmax weights
@@ -1044,6 +1037,12 @@ __global__ void att_dpre_kernel(const float* __restrict__ de, const float* __res
     }
   } else {
     for (int i = threadIdx.x; i < L * C; i += blockDim.x) des[i] = de[(size_t)row0 * C + i];
+  }
+  float4 wc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    wc[c] = reinterpret_cast<const float4*>(w2 + (size_t)min(c, C - 1) * Ha)[c4c];
+    if (c >= C || !act) wc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
