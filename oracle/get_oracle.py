@@ -74,15 +74,19 @@ def pack_adjacency(adj: np.ndarray):
 # ---------------------------------------------------------------------------
 # a2  GGNN cell -- Models/BiDAF/wrapper.py:174-208
 # ---------------------------------------------------------------------------
-def ggnn_cell(adj: torch.Tensor, x: torch.Tensor, p: Dict[str, torch.Tensor], prefix: str = "", drop_p: float = 0.0):
+def ggnn_cell(adj: torch.Tensor, x: torch.Tensor, p: Dict[str, torch.Tensor], prefix: str = "", drop_p: float = 0.0, keep=None):
     """Gated graph cell.  wrapper.py:188-208.  drop_p > 0 = training mode: the cell's input dropout (:189-190) with
-    torch's own mask (used only to TIME a training step on the CPU; every parity check runs with drop_p = 0).
+    torch's own mask (used only to TIME a training step on the CPU).  keep = (mask, p): the same dropout with a GIVEN keep
+    mask (x * mask / (1 - p), what nn.Dropout computes for that draw) -- training-mode parity checks replay the product's
+    stateless mask through it.
 
     ``p`` holds the reference state_dict names below ``prefix``:
     proj.linear.weight, linear{z,r,h}{0,1}.linear.{weight,bias}.
     """
     g = lambda n: p[prefix + n]
-    if drop_p > 0.0:
+    if keep is not None:
+        x = x * keep[0].to(x.dtype) / (1.0 - float(keep[1]))
+    elif drop_p > 0.0:
         x = torch.nn.functional.dropout(x, drop_p, training=True)
     xp = x @ g("proj.linear.weight").t()
     a = adj @ xp
@@ -126,11 +130,12 @@ def gsl_refine(adj: torch.Tensor, score: torch.Tensor, rate: float, keep: Option
 # ---------------------------------------------------------------------------
 # a4  GGNN_with_GSL -- Models/BiDAF/wrapper.py:165-172
 # ---------------------------------------------------------------------------
-def ggnn_with_gsl(adj, feat, p, prefix, rate, keep_override=None, return_aux=False, drop_p: float = 0.0):
-    f1 = ggnn_cell(adj, feat, p, prefix + "feat_prop1.", drop_p)
-    score = ggnn_cell(adj, f1, p, prefix + "word_scorer1.", drop_p)
+def ggnn_with_gsl(adj, feat, p, prefix, rate, keep_override=None, return_aux=False, drop_p: float = 0.0, drop_keep=None):
+    dk = drop_keep or {}
+    f1 = ggnn_cell(adj, feat, p, prefix + "feat_prop1.", drop_p, dk.get("cell1"))
+    score = ggnn_cell(adj, f1, p, prefix + "word_scorer1.", drop_p, dk.get("scorer"))
     adj_r, keep = gsl_refine(adj, score, rate, keep_override)
-    out = ggnn_cell(adj_r, f1, p, prefix + "feat_prop2.", drop_p)
+    out = ggnn_cell(adj_r, f1, p, prefix + "feat_prop2.", drop_p, dk.get("cell2"))
     if return_aux:
         return out, dict(feat1=f1, score=score.squeeze(-1), keep=keep)
     return out
@@ -183,9 +188,10 @@ def pad_right(t: torch.Tensor, counts: Sequence[int], n_max: int):
 # ---------------------------------------------------------------------------
 def model_forward(p: Dict[str, torch.Tensor], cfg: dict, query, document, query_adj, doc_ids, doc_adj,
                   query_lens, evd_counts, doc_sources, query_sources=None, keep_override=None,
-                  return_aux=False, drop_p: float = 0.0):
+                  return_aux=False, drop_p: float = 0.0, drop_keep=None):
     """Forward of the GET model from a reference-named state dict ``p`` (evaluation mode; drop_p > 0 switches the
-    four cells' input dropout on -- dropout_gnn = 0.2 in the reference -- for TIMING a training step only).
+    four cells' input dropout on -- dropout_gnn = 0.2 in the reference -- for TIMING a training step only;
+    drop_keep = {"claim" | "cell1" | "scorer" | "cell2": (keep mask shaped like that cell's input, p)} replays GIVEN masks).
 
     query (B,L) node ids; document (B,n,R) ids (only its evidence-slot mask is
     used, :215); doc_ids (B1,R) de-padded evidence node ids; adjacencies dense;
@@ -197,13 +203,13 @@ def model_forward(p: Dict[str, torch.Tensor], cfg: dict, query, document, query_
     n_max = document.shape[1]
     # claim branch (:144-155)
     q_mask = (query > 0).to(emb.dtype)[:, :, None]
-    q_h = ggnn_cell(query_adj.to(emb.dtype), emb[query.long()], p, "ggnn4claim_1.", drop_p)
+    q_h = ggnn_cell(query_adj.to(emb.dtype), emb[query.long()], p, "ggnn4claim_1.", drop_p, (drop_keep or {}).get("claim"))
     q_repr = (q_h * q_mask).sum(1) / query_lens.to(emb.dtype)[:, None]
     q_rep_pairs = pad_left(q_repr, counts)
     # evidence branch (:107)
     aux = {}
     doc_out = ggnn_with_gsl(doc_adj.to(emb.dtype), emb[doc_ids.long()], p, "ggnn_with_gsl.",
-                            cfg["gsl_rate"], keep_override, return_aux=return_aux, drop_p=drop_p)
+                            cfg["gsl_rate"], keep_override, return_aux=return_aux, drop_p=drop_p, drop_keep=drop_keep)
     if return_aux:
         doc_out, aux = doc_out
     # word-level attention (:173-193); claim vector WITHOUT source embedding (:110)

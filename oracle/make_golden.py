@@ -140,7 +140,24 @@ def g2():
                 store[f"c{ci}_g::{name}"] = prm.grad.numpy()
             else:
                 put_summary(store, f"c{ci}_g::{name}", prm.grad)
-        meta.append(dict(n=n, r=r, din=din, dout=dout, window=window, seed=200 + ci, small=bool(small)))
+        if ci == 0:
+            # training mode (wrapper.py:189-190: nn.Dropout on the cell INPUT): the mask the reference drew is captured from its
+            # own dropout module, so that the oracle's mask-replay form (ggnn_cell keep=) is pinned without relying on RNG streams
+            mod.train(True)
+            mod.zero_grad()
+            cap = {}
+            hk = mod.dropout.register_forward_hook(lambda m, i, o: cap.update(keep=(o != 0) | (i[0] == 0)))
+            torch.manual_seed(4242 + ci)
+            xt2 = torch.from_numpy(x).requires_grad_(True)
+            out_t = mod(torch.from_numpy(adj).float(), xt2)
+            hk.remove()
+            (out_t * torch.from_numpy(gw)).sum().backward()
+            store[f"c{ci}_train_keep"] = np.packbits(cap["keep"].numpy().reshape(-1))
+            store[f"c{ci}_train_out"] = out_t.detach().numpy()
+            store[f"c{ci}_train_dx"] = xt2.grad.numpy()
+            store[f"c{ci}_train_g::proj.linear.weight"] = mod.proj.linear.weight.grad.numpy()
+            mod.train(False)
+        meta.append(dict(n=n, r=r, din=din, dout=dout, window=window, seed=200 + ci, small=bool(small), drop_p=0.2))
     store["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, "g2_ggnn.npz"), **store)
     print("G2 ok")

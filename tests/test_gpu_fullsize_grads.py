@@ -37,7 +37,7 @@ def _unpack_keep(words, r):
     return bits.reshape(w.shape[0], -1)[:, :r]
 
 
-def _oracle_full(wl, keep_override=None):
+def _oracle_full(wl, keep_override=None, drop_keep=None):
     """Oracle forward + CE + backward on the WHOLE batch 0 of the workload; returns results and gradients."""
     cfg = wl["cfg"]
     s = wl["oracle_slice"](cfg.batch)          # (runs an extra no-grad forward; cheap next to the autograd pass below)
@@ -47,7 +47,7 @@ def _oracle_full(wl, keep_override=None):
     phi, ww, ew, aux = O.model_forward(p, sub_cfg.__dict__, T(inp["query"]), T(inp["document"]), T(inp["query_adj"]),
                                        T(inp["doc_ids"]), T(inp["doc_adj"]), T(inp["query_lens"]), inp["evd_counts"],
                                        T(inp["doc_sources"]), T(inp["query_sources"]), keep_override=keep_override,
-                                       return_aux=True)
+                                       return_aux=True, drop_keep=drop_keep)
     loss = O.cross_entropy(phi, T(inp["labels"]))
     loss.backward()
     grads = {k: v.grad for k, v in p.items() if v.requires_grad}
@@ -55,13 +55,45 @@ def _oracle_full(wl, keep_override=None):
                 loss=float(loss.detach()), grads=grads, params={k: v.detach() for k, v in p.items()}, inp=inp)
 
 
-def _hip_vs_oracle(cfg, seed, compact, min_rows, with_trainer):
+def _dropout_keeps(wl, model, seeds, cfg, compact):
+    """The four cells' keep masks of one composite training-mode call (fused.prepare drew `seeds` = claim, cell1, scorer, cell2),
+    in the oracle's padded shapes: the stateless mask is indexed by the row the kernels see -- the node-compact row in the compact
+    layout (RaggedPlan.src maps it to the padded row)."""
+    from get_amd import ops
+    p_claim = float(model.ggnn4claim_1.dropout.p)
+    p_gnn = float(model.ggnn_with_gsl.feat_prop1.dropout.p)
+    B, L = wl["query"].shape
+    b1, R = int(wl["b1"]), cfg.len_right
+    D, H = cfg.emb_dim, cfg.hidden
+    src = None
+    if compact:
+        plan = wl["kargs"]["docs_adj"].plan
+        src = plan.src.cpu().numpy()
+        assert src.shape[0] == b1 * R
+
+    def rows_mask(sd, width):
+        kc = ops.dropout_mask_reference(sd, b1 * R, width, p_gnn)
+        if src is not None:
+            k = np.zeros_like(kc)
+            k[src] = kc
+            kc = k
+        return torch.from_numpy(kc.reshape(b1, R, width))
+    return {"claim": (torch.from_numpy(ops.dropout_mask_reference(seeds[0], B * L, D, p_claim).reshape(B, L, D)), p_claim),
+            "cell1": (rows_mask(seeds[1], D), p_gnn), "scorer": (rows_mask(seeds[2], H), p_gnn), "cell2": (rows_mask(seeds[3], H), p_gnn)}
+
+
+def _hip_vs_oracle(cfg, seed, compact, min_rows, with_trainer, train=False):
     from bench import build_workload
     from get_amd import _lib, ops
     from get_amd.dist import FlatTrainer
     wl = build_workload(seed=seed, device=DEV, cfg=cfg, compact=compact)
     assert wl["compact"] == compact
-    model = wl["model"].train(False)
+    model = wl["model"].train(train)
+    seeds = None
+    if train:      # the composite path draws its four dropout seeds from torch's CPU generator (fused.prepare)
+        torch.manual_seed(seed + 99)
+        seeds = torch.randint(0, 2 ** 31 - 1, (4,)).tolist()
+        torch.manual_seed(seed + 99)
     r = cfg.len_right
     rows = wl["m_real"] if compact else int(wl["b1"]) * r
     assert rows >= min_rows, "the shape must take the big-tile GEMM path"
@@ -81,7 +113,8 @@ def _hip_vs_oracle(cfg, seed, compact, min_rows, with_trainer):
     keep_hip = _unpack_keep(model.ggnn_with_gsl.last_keep, r)
     score_hip = model.ggnn_with_gsl.last_score.cpu()
 
-    ora = _oracle_full(wl)
+    drop_keep = _dropout_keeps(wl, model, seeds, cfg, compact) if train else None
+    ora = _oracle_full(wl, drop_keep=drop_keep)
     real = ora["inp"]["doc_ids"] > 0
     n_pairs = real.shape[0]
     assert keep_hip.shape[0] >= n_pairs
@@ -93,7 +126,7 @@ def _hip_vs_oracle(cfg, seed, compact, min_rows, with_trainer):
         kth = -np.sort(-sc, axis=1)[:, k - 1:k + 1].mean(1)
         gap = np.abs(sc - kth[:, None])[mism]
         assert gap.max() <= 1e-6, f"{int(mism.sum())} keep decisions differ with a score gap of {gap.max():.2e}"
-        ora = _oracle_full(wl, keep_override=torch.from_numpy(keep_hip[:n_pairs].copy()))
+        ora = _oracle_full(wl, keep_override=torch.from_numpy(keep_hip[:n_pairs].copy()), drop_keep=drop_keep)
     print(f"full-size parity: {n_pairs} graphs, {int(mism.sum())} tie-equivalent keep flips, rows {rows:.0f}")
 
     assert float((phi.detach().cpu() - ora["phi"]).abs().max()) <= 1e-4
@@ -143,6 +176,15 @@ def test_config1_headline_batch_gradients_vs_oracle(compact):
     """BASELINE configs[1] at FULL size, the batch bench.py times (seed 20240229): 960 pairs, h = 300."""
     from get_amd.synth import SynthConfig
     _hip_vs_oracle(SynthConfig(batch=32, n_evd=30), 20240229, compact, 8192, with_trainer=True)
+
+
+@pytest.mark.parametrize("compact", [True, False])
+def test_config1_headline_batch_TRAINING_MODE_gradients_vs_oracle(compact):
+    """The same batch in the mode the bench line is measured in: train(True), the four cells' input dropout on.  The oracle replays
+    the product's stateless masks (O.model_forward drop_keep): the 64 x 320 / 64 x 160 loaders' mask, the dX epilogue's, the
+    scorer's and the masked weight-gradient operand are checked at full size."""
+    from get_amd.synth import SynthConfig
+    _hip_vs_oracle(SynthConfig(batch=32, n_evd=30), 20240229, compact, 8192, with_trainer=False, train=True)
 
 
 @pytest.mark.parametrize("compact", [True, False])

@@ -1206,3 +1206,80 @@ def test_fp32x3p_follows_a_plain_torch_optimizer():
     assert abs(out["fp32"][0] - out["fp32"][2]) > 1e-4 * abs(out["fp32"][0]), "the parameters did not move"
     for a, b in zip(out["fp32"], out["fp32x3p"]):
         assert abs(a - b) <= 2e-6 * max(1.0, abs(a)), out
+
+
+@pytest.mark.parametrize("name", ["small", "full"])
+@pytest.mark.parametrize("native", [True, "compact"])
+def test_training_mode_model_vs_oracle_replaying_the_dropout_masks(name, native):
+    """The mode the bench line is measured in: train(True), input dropout of the four GGNN cells on (wrapper.py:189-190, p from the
+    constructor).  The composite path draws four seeds from torch's CPU generator (fused.py) and applies stateless hash masks inside
+    its kernels (projection loader, scorer, dX epilogue, the weight-gradient operand); the oracle replays exactly those masks
+    (O.model_forward drop_keep) -- indexed by padded row for the padded layout, by node-compact row for the compact one.  Logits,
+    attention weights, scorer scores, keep-sets and every live gradient at the eval-mode tolerances."""
+    from get_amd import ops
+    cfg, seed = MODEL_CASES[name]
+    model = build_model(cfg, seed).train(True)
+    raw = make_raw_batch(cfg, seed)
+    inp = assemble_inputs(raw, cfg, O.convert_text)
+    kargs = to_dev(reference_kargs(inp, torch, output_ranking=True))
+    query = torch.from_numpy(inp["query"]).to(DEV)
+    document = torch.from_numpy(inp["document"]).to(DEV)
+    qa, q_ids, q_n = ops.graph_build(torch.from_numpy(raw["claim_tokens"]).to(DEV), torch.from_numpy(raw["claim_len"]).to(DEV), cfg.window)
+    da, d_ids, d_n = ops.graph_build(torch.from_numpy(raw["evd_tokens"]).to(DEV), torch.from_numpy(raw["evd_len"]).to(DEV), cfg.window)
+    plan = None
+    if native == "compact":
+        plan = ops.RaggedPlan(d_n, d_ids, int(d_n.sum().item()))
+        da = da.with_plan(plan)
+    kargs["query_adj"], kargs["docs_adj"] = qa, da
+    torch.manual_seed(20240917)
+    seeds = torch.randint(0, 2 ** 31 - 1, (4,)).tolist()          # what fused.prepare will draw: claim, cell1, scorer, cell2
+    torch.manual_seed(20240917)
+    phi, (ww, ew) = model(query, document, **kargs)
+    assert getattr(model, "_gh_binding", None) is not None, "the composite path did not run"
+    labels = torch.from_numpy(inp["labels"]).to(DEV)
+    torch.nn.functional.cross_entropy(phi, labels).backward()
+    torch.cuda.synchronize()
+    # --- the same masks on the host
+    p_claim = float(model.ggnn4claim_1.dropout.p)
+    p_gnn = float(model.ggnn_with_gsl.feat_prop1.dropout.p)
+    assert p_claim > 0 and p_gnn > 0
+    B, L = inp["query"].shape
+    B1, R = inp["doc_ids"].shape
+    D, H = cfg.emb_dim, cfg.hidden
+    def rows_mask(sd, width, p):          # (B1, R, width) in padded order
+        kc = ops.dropout_mask_reference(sd, B1 * R, width, p)
+        if plan is None:
+            return torch.from_numpy(kc.reshape(B1, R, width))
+        k = np.zeros_like(kc)
+        k[plan.src.cpu().numpy()] = kc     # compact row -> padded row
+        return torch.from_numpy(k.reshape(B1, R, width))
+    drop_keep = {"claim": (torch.from_numpy(ops.dropout_mask_reference(seeds[0], B * L, D, p_claim).reshape(B, L, D)), p_claim),
+                 "cell1": (rows_mask(seeds[1], D, p_gnn), p_gnn),
+                 "scorer": (rows_mask(seeds[2], H, p_gnn), p_gnn),
+                 "cell2": (rows_mask(seeds[3], H, p_gnn), p_gnn)}
+    T = torch.from_numpy
+    po = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and k != "embedding.weight") for k, v in model.state_dict().items()}
+    ocfg = dict(cfg.__dict__)
+    phi_o, ww_o, ew_o, aux = O.model_forward(po, ocfg, T(inp["query"]), T(inp["document"]), T(inp["query_adj"]), T(inp["doc_ids"]),
+                                             T(inp["doc_adj"]), T(inp["query_lens"]), inp["evd_counts"], T(inp["doc_sources"]),
+                                             T(inp["query_sources"]), return_aux=True, drop_keep=drop_keep)
+    O.cross_entropy(phi_o, T(inp["labels"])).backward()
+    real = inp["doc_ids"] >= 1
+    assert float((phi.detach().cpu() - phi_o.detach()).abs().max()) <= 1e-4
+    ww_h = ww.detach().cpu().numpy()
+    if plan is not None and ww_h.shape[0] != B1:
+        ww_h = plan.to_padded(ww.detach()).cpu().numpy()
+    ww_h = ww_h.reshape(B1, R, -1)
+    assert np.abs(ww_h - ww_o.detach().numpy())[real].max() <= 1e-5
+    assert float((ew.detach().cpu() - ew_o.detach()).abs().max()) <= 1e-5
+    sc_h = model.ggnn_with_gsl.last_score.cpu().numpy().reshape(B1, R)
+    assert np.abs(sc_h - aux["score"].detach().numpy())[real].max() <= 1e-5
+    n_live = 0
+    for k, prm in model.named_parameters():
+        go = po[k].grad if k in po else None
+        if prm.grad is None or go is None:
+            continue
+        scale = max(float(go.abs().max()), 1e-8)
+        assert float((prm.grad.cpu() - go).abs().max()) <= 1e-3 * scale + 1e-7, k
+        n_live += 1
+    assert n_live >= 40

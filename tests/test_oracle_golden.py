@@ -63,6 +63,28 @@ def test_g2_ggnn_cell(ci):
         check_grad(z, f"c{ci}_g::{k}", v.grad.numpy())
 
 
+def test_g2_training_mode_dropout_replay_matches_the_reference():
+    """Training mode of the cell (wrapper.py:189-190): the reference's own run with nn.Dropout on the cell input, its drawn keep
+    mask captured from the dropout module (oracle/make_golden.py).  The oracle's mask-replay form -- ggnn_cell(keep=(mask, p)), the
+    form every training-mode parity test of the HIP path goes through -- must reproduce that output and its gradients."""
+    z, meta = load("g2_ggnn.npz")
+    ci = 0
+    c = cases.g2_inputs(ci, O.convert_text)
+    n, r, din = c["x"].shape
+    keep = np.unpackbits(z[f"c{ci}_train_keep"])[:n * r * din].reshape(n, r, din).astype(bool)
+    p_drop = meta[ci]["drop_p"]
+    assert abs(keep.mean() - (1 - p_drop)) < 0.03
+    p = {k: T(v, grad=True) for k, v in c["p"].items()}
+    x = T(c["x"], grad=True)
+    out = O.ggnn_cell(T(c["adj"]).float(), x, p, keep=(torch.from_numpy(keep), p_drop))
+    assert np.abs(out.detach().numpy() - z[f"c{ci}_train_out"]).max() <= 2e-5
+    (out * T(c["gw"])).sum().backward()
+    assert np.abs(x.grad.numpy() - z[f"c{ci}_train_dx"]).max() <= 1e-4 * max(1.0, np.abs(z[f"c{ci}_train_dx"]).max())
+    gw = z[f"c{ci}_train_g::proj.linear.weight"]
+    assert np.abs(p["proj.linear.weight"].grad.numpy() - gw).max() <= 1e-3 * np.abs(gw).max()
+    assert np.abs(x.grad.numpy()[~keep]).max() == 0.0          # dropped inputs receive no gradient
+
+
 # ---------------------------------------------------------------- G3 ----------
 def test_g3_gsl_keep_sets():
     z, meta = load("g3_gsl.npz")
