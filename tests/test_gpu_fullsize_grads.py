@@ -204,6 +204,25 @@ def test_headline_batch_snopes_counts_gradients_vs_oracle():
     _hip_vs_oracle(cfg, 20240229, True, 8192, with_trainer=False)
 
 
+def test_snopes_counts_TRAINING_MODE_gradients_vs_oracle():
+    """Ragged Snopes-histogram counts (B = 139) in training mode: the realistic-series leg's mode and shape."""
+    from get_amd.synth import SynthConfig, snopes_evidence_counts
+    counts = snopes_evidence_counts(np.random.default_rng(20240229 + 17), 139)
+    cfg = SynthConfig(batch=139, n_evd=30, evd_counts=[int(c) for c in counts])
+    _hip_vs_oracle(cfg, 20240229, True, 8192, with_trainer=False, train=True)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_config4_shaped_h768_batch_gradients_vs_oracle(train):
+    """BASELINE configs[4]'s model (h = 768, 8 word heads, window 5, gsl_rate 0.8) in exact fp32 at a batch whose ~15 K node rows take
+    the big-tile path -- three 320-wide / five 160-wide column blocks per row, head scores and scorer projection reduced per block,
+    bias gradients from several column-block problems -- against the oracle, evaluation and training mode (8 claims x 30 evidences:
+    the oracle's autograd pass at h = 768 stays within seconds)."""
+    from get_amd.synth import SynthConfig
+    cfg = SynthConfig(batch=8, n_evd=30, hidden=768, emb_dim=768, word_heads=8, window=5, gsl_rate=0.8)
+    _hip_vs_oracle(cfg, 20240305, True, 8192, with_trainer=False, train=train)
+
+
 @pytest.mark.parametrize("m,k,n", [(62128, 300, 300), (96000, 600, 300), (9000, 300, 300), (62128, 768, 768)])
 def test_linear_fwd_bwd_big_tile_fp32_vs_fp64(m, k, n):
     """gh_linear_fwd/bwd at >= 8192 rows (64-row NT tiles, the K-chunked weight-gradient GEMM + reduce_partials, bias
