@@ -401,8 +401,12 @@ def test_h768_bf16_gemm_mode_tracks_the_fp32_oracle():
         assert err <= 6e-2 * float(g32.abs().max()) + 1e-7, (k, err, float(g32.abs().max()))
 
 
-def test_h768_bf16_storage_vs_the_cpu_oracle():
-    """BASELINE configs[4], DIRECT oracle comparison: the bf16 storage pipeline at h = 768, 8 word heads,
+@pytest.mark.parametrize("train", [False, True])
+def test_h768_bf16_storage_vs_the_cpu_oracle(train):
+    """(train = True: the mode its bench line is measured in -- the four cells' input dropout on, the oracle replaying the product's
+    stateless masks, test_training_mode_model_vs_oracle_replaying_the_dropout_masks; in bf16 storage the first cell's masked operand is
+    materialised once by gather_rows and re-used by its weight gradient.)
+    BASELINE configs[4], DIRECT oracle comparison: the bf16 storage pipeline at h = 768, 8 word heads,
     window 5, rate 0.8, at a batch that takes the big-tile path, against O.model_forward (wrapper.py:188-206 arithmetic in
     fp32 on the CPU) on the SAME batch -- not against the HIP fp32 path.  Stated bf16 bounds per quantity: logits 2e-3,
     word / evidence attention weights 5e-3, scorer scores 1e-2, every live gradient 6e-2 of its largest entry; GSL keep
@@ -413,19 +417,39 @@ def test_h768_bf16_storage_vs_the_cpu_oracle():
     cfg = SynthConfig(batch=6, n_evd=30, emb_dim=768, hidden=768, word_heads=8, evd_heads=2, window=5, gsl_rate=0.8, vocab=900,
                       n_article_src=40, n_claim_src=10)
     seed = 769
-    model = build_model(cfg, seed)
+    model = build_model(cfg, seed).train(train)
     raw = make_raw_batch(cfg, seed)
     inp = assemble_inputs(raw, cfg, O.convert_text)
     kargs = to_dev(reference_kargs(inp, torch, output_ranking=True))
     da, d_ids, d_n = ops.graph_build(torch.from_numpy(raw["evd_tokens"]).to(DEV), torch.from_numpy(raw["evd_len"]).to(DEV), cfg.window)
-    kargs["docs_adj"] = da.with_plan(ops.RaggedPlan(d_n, d_ids, int(d_n.sum().item())))
+    plan = ops.RaggedPlan(d_n, d_ids, int(d_n.sum().item()))
+    kargs["docs_adj"] = da.with_plan(plan)
     assert int(d_n.sum().item()) >= 8192
+    drop_keep = None
+    if train:
+        torch.manual_seed(seed)
+        seeds = torch.randint(0, 2 ** 31 - 1, (4,)).tolist()
+        torch.manual_seed(seed)
+        p_c, p_g = float(model.ggnn4claim_1.dropout.p), float(model.ggnn_with_gsl.feat_prop1.dropout.p)
+        B_, L_ = inp["query"].shape
+        B1_, R_ = inp["doc_ids"].shape
+        src = plan.src.cpu().numpy()
+
+        def rows_mask(sd, width):
+            kc = ops.dropout_mask_reference(sd, B1_ * R_, width, p_g)
+            k = np.zeros_like(kc)
+            k[src] = kc
+            return torch.from_numpy(k.reshape(B1_, R_, width))
+        drop_keep = {"claim": (torch.from_numpy(ops.dropout_mask_reference(seeds[0], B_ * L_, cfg.emb_dim, p_c).reshape(B_, L_, cfg.emb_dim)), p_c),
+                     "cell1": (rows_mask(seeds[1], cfg.emb_dim), p_g), "scorer": (rows_mask(seeds[2], cfg.hidden), p_g),
+                     "cell2": (rows_mask(seeds[3], cfg.hidden), p_g)}
     q, d = torch.from_numpy(inp["query"]).to(DEV), torch.from_numpy(inp["document"]).to(DEV)
     labels = torch.from_numpy(inp["labels"]).to(DEV)
     _lib.set_gemm_mode("bf16")
     try:
         _lib.gemm_path_counters(reset=True)
         phi, (ww, ew) = model(q, d, **kargs)
+        assert not train or getattr(model, "_gh_binding", None) is not None, "the masks are replayed for the composite path's seeds"
         score = model.ggnn_with_gsl.last_score.detach().cpu()
         keep = model.ggnn_with_gsl.last_keep.cpu().numpy().astype(np.uint64)
         torch.nn.functional.cross_entropy(phi, labels).backward()
@@ -440,7 +464,7 @@ def test_h768_bf16_storage_vs_the_cpu_oracle():
     p["article_source_embs.weight"] = T(art).requires_grad_(True)
     phi_o, ww_o, ew_o, aux = O.model_forward(p, cfg.__dict__, T(inp["query"]), T(inp["document"]), T(inp["query_adj"]),
                                              T(inp["doc_ids"]), T(inp["doc_adj"]), T(inp["query_lens"]), inp["evd_counts"],
-                                             T(inp["doc_sources"]), T(inp["query_sources"]), return_aux=True)
+                                             T(inp["doc_sources"]), T(inp["query_sources"]), return_aux=True, drop_keep=drop_keep)
     O.cross_entropy(phi_o, T(inp["labels"])).backward()
     d_phi = float((phi.detach().cpu() - phi_o.detach()).abs().max())
     d_ww = float((ww.detach().cpu() - ww_o.detach()).abs().max())
