@@ -368,7 +368,10 @@ def make_step(args, wl, trainer, source="resident"):
         query, document, kargs = b.inputs()
         phi = model(query, document, **kargs)
         loss = ops.cross_entropy(phi, b.labels)        # losses.py:29-32, loss + gradient in one launch
-        loss.backward()
+        if source in ("reference", "reference_sync"):
+            loss.backward()                            # what the unchanged fitter calls
+        else:
+            ops.backward(loss)                         # = loss.backward() without autograd's root fill + scale launches
         trainer.step()
         if streamed is not None:
             streamed.prefetch()
@@ -472,7 +475,7 @@ def phase_split(wl, trainer, steps=5):
         e[1].record()
         loss = ops.cross_entropy(model(query, document, **kargs), b.labels)
         e[2].record()
-        loss.backward()
+        ops.backward(loss)
         e[3].record()
         trainer.allreduce()
         e[4].record()

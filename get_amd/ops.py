@@ -947,6 +947,12 @@ def cross_entropy(phi, labels):
     return _ce(phi, labels)
 
 
+def backward(loss):
+    """loss.backward() without autograd's root fill + scale launches (get_amd.fused.backward)."""
+    from .fused import backward as _bw
+    _bw(loss)
+
+
 # --------------------------------------------------------------------------- optimiser
 def adam_step_flat(p, g, m, v, step, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3, grad_scale=1.0):
     """One Adam step on flat fp32 buffers (declare_fitter.py:58-61 semantics)."""

@@ -1307,3 +1307,36 @@ def test_training_mode_model_vs_oracle_replaying_the_dropout_masks(name, native)
         assert float((prm.grad.cpu() - go).abs().max()) <= 1e-3 * scale + 1e-7, k
         n_live += 1
     assert n_live >= 40
+
+
+def test_unit_seed_backward_equals_loss_backward():
+    """ops.backward(loss) hands autograd a cached constant 1 as the root gradient, which the fused cross-entropy recognises by
+    address and skips its scale launch: gradients bit-identical to loss.backward(); a scaled loss, or another device scalar as the
+    root gradient, still takes the multiply."""
+    from get_amd import ops
+    g = torch.Generator().manual_seed(11)
+    phi0 = (torch.randn(32, 2, generator=g) * 2).to(DEV)
+    y = torch.randint(0, 2, (32,), generator=g).to(DEV)
+    grads = []
+    for mode in ("plain", "unit", "scaled", "other_one"):
+        phi = phi0.clone().requires_grad_(True)
+        loss = ops.cross_entropy(phi, y)
+        if mode == "plain":
+            loss.backward()
+        elif mode == "unit":
+            ops.backward(loss)
+        elif mode == "scaled":
+            (loss * 3.0).backward()
+        else:
+            torch.autograd.backward(loss, grad_tensors=[torch.full((), 3.0, device=DEV)])
+        grads.append(phi.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert float((grads[2] - 3.0 * grads[0]).abs().max()) <= 1e-7 and torch.equal(grads[2], grads[3])
+    # through the whole model: the composite path's gradients are the same either way
+    res = []
+    for unit in (False, True):
+        cfg, model, inp, phi, ww, ew, _ = run_case("small", native_graphs="compact")
+        loss = ops.cross_entropy(phi, torch.from_numpy(inp["labels"]).to(DEV))
+        ops.backward(loss) if unit else loss.backward()
+        res.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert set(res[0]) == set(res[1]) and all(torch.equal(res[0][k], res[1][k]) for k in res[0])

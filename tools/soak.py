@@ -31,7 +31,7 @@ def main():
         tr.zero_grad()
         q, d, k = b.inputs()
         loss = ops.cross_entropy(model(q, d, **k), b.labels)
-        loss.backward()
+        ops.backward(loss)
         tr.step()
         if i % 500 == 0 or i == steps - 1:
             losses.append((i, float(loss.item())))
