@@ -870,7 +870,10 @@ def main():
                                    f"(B1={wl['b1']:.0f} pairs), L_left={cfg.len_left}, L_right={cfg.len_right}, D=H={cfg.hidden}, "
                                    f"{cfg.word_heads} word heads / {cfg.evd_heads} evidence heads, gnn_window={cfg.window}, "
                                    f"gsl_rate={cfg.gsl_rate}",
-                       "step": "device graph build + forward + CE loss + backward + flat grad all-reduce + fused Adam",
+                       "step": "device graph build + forward + CE loss + backward + flat grad all-reduce + fused Adam "
+                               "(backward = get_amd.ops.backward(loss): loss.backward() with a cached constant 1 as the root gradient, so "
+                               "autograd's ones_like fill and the multiply by it -- two scalar launches -- do not run; gradients bit-identical; "
+                               "the reference_api legs call loss.backward() like the unchanged fitter)",
                        "batches": f"{len(wl['batches'])} distinct resident batches, rotated every step",
                        "mode": "eval (dropout off)" if args.eval_mode else "train (dropout on)",
                        "layout": (f"node-compact: {wl['m_real']:.0f} real-node rows of {wl['b1'] * cfg.len_right:.0f} padded rows "
