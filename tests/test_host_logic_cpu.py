@@ -117,3 +117,21 @@ def test_bench_block_statistics_tolerate_one_hiccup_block():
     assert many["timed"]["unstable"] and many["timed"]["outlier_blocks"] == 3
     calm = bench.summarize_blocks({"blocks_s": [0.063, 0.0632, 0.0629, 0.0631, 0.063], "settle_s": []}, 10, [9600] * 5)
     assert "unstable" not in calm["timed"] and calm["timed"]["outlier_blocks"] == 0 and "spread_rel_without_outliers" not in calm["timed"]
+
+
+def test_unit_seed_backward_is_plain_backward_for_any_loss():
+    """get_amd.fused.backward(loss) = torch.autograd.backward with a cached constant 1 as the root gradient: for a loss that does not
+    know the trick (plain torch cross-entropy, here on the CPU) the gradients are those of loss.backward()."""
+    from get_amd import fused
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(16, 3, generator=g)
+    y = torch.randint(0, 3, (16,), generator=g)
+    grads = []
+    for unit in (False, True):
+        x = x0.clone().requires_grad_(True)
+        loss = torch.nn.functional.cross_entropy(x, y)
+        fused.backward(loss) if unit else loss.backward()
+        grads.append(x.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    one = fused.unit_seed(torch.device("cpu"))
+    assert one.shape == () and float(one) == 1.0 and fused.unit_seed(torch.device("cpu")) is one
