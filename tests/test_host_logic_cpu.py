@@ -122,6 +122,7 @@ def test_bench_block_statistics_tolerate_one_hiccup_block():
 def test_unit_seed_backward_is_plain_backward_for_any_loss():
     """get_amd.fused.backward(loss) = torch.autograd.backward with a cached constant 1 as the root gradient: for a loss that does not
     know the trick (plain torch cross-entropy, here on the CPU) the gradients are those of loss.backward()."""
+    import torch
     from get_amd import fused
     g = torch.Generator().manual_seed(5)
     x0 = torch.randn(16, 3, generator=g)
