@@ -62,7 +62,7 @@ __device__ __forceinline__ unsigned nt_pack_bf16(float a, float b) {
 template <int WM, int WN, int NI, int MI = 2, int MODE = 0>
 // (second argument = waves per SIMD the register budget must allow: 256-thread workgroups put one wave on every SIMD, so it is also
 //  the workgroups per CU; the 512-thread 128 x 256 tile puts two, and wants two workgroups = four waves per SIMD)
-__global__ void __launch_bounds__(WM * WN * 64, (MI == 4 && NI == 4 && WN == 4) ? 4 : (MI == 4 && NI == 4) ? 3 : (MI == 4 || MODE == 3 || MODE == 4) ? 2 : (WM == 2 && WN == 2 && NI == 5 && MODE == 0) ? 4 : 3)
+__global__ void __launch_bounds__(WM * WN * 64, (MI == 8) ? 2 : (MI == 4 && NI == 4 && WN == 4) ? 4 : (MI == 4 && NI == 4) ? 3 : (MI == 4 || MODE == 3 || MODE == 4) ? 2 : (WM == 2 && WN == 2 && NI == 5 && MODE == 0) ? 4 : 3)
 gemm_nt_kernel(const Launch L_byval) {
   (void)L_byval;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -71,7 +71,11 @@ gemm_nt_kernel(const Launch L_byval) {
   constexpr int NW = WM * WN, NTHR = NW * 64;
   constexpr bool BF = MODE == 1;
   constexpr int ESZ = MODE == 2 ? 2 : 4, KQ = 16 / ESZ;          // element size, elements per 16-byte chunk
-  constexpr int BM = 16 * MI * WM, BN = 16 * NI * WN, BK = 4 * KQ;
+  // MI = 8 (bf16 storage only: <2, 4, 4, 8, 2> = a 256 x 256 x 64 tile on 8 waves, one workgroup per CU): the "ping-pong" K loop
+  // below (PP) -- the two wave rows run staggered by one barrier interval, so that each SIMD always has one wave in its
+  // MFMA section and one reading fragments / issuing LDS-DMA.
+  constexpr bool PP = MI == 8;
+  constexpr int BM = 16 * MI * WM, BN = 16 * NI * WN, BK = PP ? 64 : 4 * KQ;
   // MODE 4 ("fp32x3" with PRE-SPLIT weights): B points at the weight's split image (split3_kernel: per row and group
   // of four k the three bf16 pieces hi[4] | mid[4] | lo[4], 24 bytes; row pitch a multiple of 16 bytes, passed as ldb in
   // 4-byte units).  A K tile of B is 96 bytes per row; its LDS image has a pitch of 7 chunks = 112 bytes (the seventh chunk
@@ -91,11 +95,12 @@ gemm_nt_kernel(const Launch L_byval) {
   // (fp32x3, MODE 3, measured with three stages as well: slower -- 122 vs 132 TF at K = 1200 -- its K loop is bound by the
   // VALU work of the in-register splits, not by DMA latency)
   constexpr int NST = (MI == 4 && WM == 4) ? 4 : (MI == 4) ? 3 : 2;      // (256 x 256 / 8 waves: one workgroup per CU, four stages)
-  constexpr bool DYN_LDS = NST != 2 || X3P;                              // more than 64 KB: dynamic allocation
-  constexpr int SMEM = NST * STAGE > EP_BYTES ? NST * STAGE : EP_BYTES;
+  constexpr bool DYN_LDS = NST != 2 || X3P || PP;                        // more than 64 KB: dynamic allocation
+  constexpr int SMEM = PP ? 131072 : (NST * STAGE > EP_BYTES ? NST * STAGE : EP_BYTES);
+  static_assert(!PP || (MODE == 2 && WM == 2 && WN == 4 && NI == 4 && EP_BYTES <= 131072), "ping-pong loop: 256 x 256 bf16 tile on 2 x 4 waves");
   constexpr unsigned OOB = 0x80000000u;
   constexpr int NH = NI / 2;                                       // B fragment batches: X = tiles [0,NH), Y = [NH,NI)
-  static_assert(MI == 2 || (MI == 4 && MODE == 2), "two 16-row tiles per wave (four in the 128 x 256 bf16 configuration)");
+  static_assert(MI == 2 || ((MI == 4 || MI == 8) && MODE == 2), "two 16-row tiles per wave (four / eight in the 128 x 256 / 256 x 256 bf16 configurations)");
   extern __shared__ __attribute__((aligned(16))) unsigned char nt_dyn_smem[];
   __shared__ __attribute__((aligned(16))) unsigned char nt_static_smem[DYN_LDS ? 16 : SMEM];
   unsigned char* const smem = DYN_LDS ? nt_dyn_smem : nt_static_smem;
@@ -541,8 +546,12 @@ gemm_nt_kernel(const Launch L_byval) {
     mma(aP, bY, NH, CY);
   };
   // (any other count -- narrow problems, odd column blocks -- computes every tile: the B rows beyond N are zeros in LDS)
-  if (nvX == NH && nvY == NI - NH - 1) run(std::integral_constant<int, NH>{}, std::integral_constant<int, NI - NH - 1>{});
-  else run(std::integral_constant<int, NH>{}, std::integral_constant<int, NI - NH>{});
+  if constexpr (PP) {
+#include "gemm_nt_pp.hip.h"
+  } else {
+    if (nvX == NH && nvY == NI - NH - 1) run(std::integral_constant<int, NH>{}, std::integral_constant<int, NI - NH - 1>{});
+    else run(std::integral_constant<int, NH>{}, std::integral_constant<int, NI - NH>{});
+  }
 
   // -------------------------------------------------------------------- epilogue on whole rows
   // Two passes (mi = 0, 1), each: accumulators (+bias) -> LDS, then a LINEAR pass over the 16*WM staged rows: item i
@@ -927,9 +936,15 @@ gemm_nt_kernel(const Launch L_byval) {
   };
   epilogue_pass(std::integral_constant<int, 0>{});
   epilogue_pass(std::integral_constant<int, 1>{});
-  if constexpr (MI == 4) {
+  if constexpr (MI >= 4) {
     epilogue_pass(std::integral_constant<int, 2>{});
     epilogue_pass(std::integral_constant<int, 3>{});
+  }
+  if constexpr (MI == 8) {
+    epilogue_pass(std::integral_constant<int, 4>{});
+    epilogue_pass(std::integral_constant<int, 5>{});
+    epilogue_pass(std::integral_constant<int, 6>{});
+    epilogue_pass(std::integral_constant<int, 7>{});
   }
 #endif
 }

@@ -143,15 +143,15 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
       if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 2, 4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); attr = true; }
       hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 4, 4, 2>), dim3(grid), dim3(256), kLds, s, L);
       launched = true;
-    } else if constexpr (WM == 4 && WN == 2 && NI == 8 && MI == 4) {      // 256 x 256 tile, 8 waves (NT only)
+    } else if constexpr (WM == 2 && WN == 4 && NI == 4 && MI == 8) {      // 256 x 256 x 64 tile, 8 waves, ping-pong K loop (NT only; gemm_nt_pp.hip.h)
       if (tn) return hipErrorInvalidValue;
-      constexpr int kLds = 4 * (256 + 256) * 64;          // four K-loop stages
+      constexpr int kLds = 131072;                        // two K tiles of 64 KB (the epilogue staging fits inside)
       static bool attr = false;
-      if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<4, 2, 8, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); attr = true; }
-      hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 8, 4, 2>), dim3(grid), dim3(512), kLds, s, L);
+      if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, 4, 4, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); attr = true; }
+      hipLaunchKernelGGL((gemm_nt_kernel<2, 4, 4, 8, 2>), dim3(grid), dim3(512), kLds, s, L);
       launched = true;
     } else return hipErrorInvalidValue;
-  } else if (MI == 4) {
+  } else if (MI >= 4) {
     return hipErrorInvalidValue;          // the 128 x 256 tile exists for the bf16 storage pipeline only
   } else if (fast && !tn) {
     // gh_set_gemm_mode(1): bf16 operand rounding in the activation-sized (64x320 tile) launches only
@@ -527,7 +527,7 @@ struct Batch {
   // att_softmax_fwd, adds the partials in block order -- deterministic).  0 = whole rows only.
   long long e_block_stride = 0;
   bool wide = false;      // 128 x 256 bf16 tile (launch_cfg<2, 2, 8, 4>)
-  bool wide256 = false;   // 256 x 256 bf16 tile, 8 waves (launch_cfg<4, 2, 8, 4>)
+  bool wide256 = false;   // 256 x 256 x 64 bf16 tile, 8 waves, ping-pong K loop (launch_cfg<2, 4, 4, 8>)
   bool wide128 = false;   // 128 x 128 bf16 tile, three workgroups per CU (launch_cfg<2, 2, 4, 4>; tool build: GH_BF16_TILE=128)
   // (round 5: the same 128 x 256 tile on EIGHT waves -- 64 x 64 per wave, two workgroups = four waves per SIMD -- needs 146 VGPRs
   //  for its 128-register budget: 82 spills, 16 instead of 12 ds_read_b128 per 32 MFMAs; configs[4] bf16 115.3 -> 99.6 K pairs/s. Removed.)
@@ -553,7 +553,9 @@ struct Batch {
     if (tile256 < 0) tile256 = measure_env("GH_BF16_TILE", 0) == 256 ? 1 : 0;
     static int tile256_sites = -1;
     if (tile256_sites < 0) tile256_sites = measure_env("GH_BF16_TILE256_SITES", 0);      // (per call site, tool build)
-    if (wide && rows_hint >= 32768 && (tile256 || (site > 0 && ((tile256_sites >> (site - 1)) & 1)))) { wide256 = true; bm = 256; }
+    static int tile256_rows = -1;
+    if (tile256_rows < 0) tile256_rows = measure_env("GH_BF16_TILE256_ROWS", 32768);
+    if (wide && rows_hint >= tile256_rows && (tile256 || (site > 0 && ((tile256_sites >> (site - 1)) & 1)))) { wide256 = true; bm = 256; }
     static int tile128 = -1;
     if (tile128 < 0) tile128 = measure_env("GH_BF16_TILE", 0) == 128 ? 1 : 0;
     if (wide && tile128) { wide128 = true; bn = 128; }
@@ -736,7 +738,19 @@ struct Batch {
         return launch_cfg<1, 4, 5>(L, tn, s);
       }
     }
-    if (wide256) return launch_cfg<4, 2, 8, 4>(L, tn, s);
+    if (wide256) {
+      // the ping-pong loop's preconditions (gemm_nt_pp.hip.h): whole 64-deep K tiles, no K split, no dropout inside the K loop
+      bool ok = L.ksplit == 1;
+      for (int i = 0; i < L.nprob; ++i) {
+        if (L.p[i].drop_mode == 1) ok = false;
+        for (int j = 0; j < L.p[i].nseg; ++j) if (L.p[i].seg[j].K % 64) ok = false;
+      }
+      if (ok) return launch_cfg<2, 4, 4, 8>(L, tn, s);
+      int mt = 0;
+      for (int i = 0; i < L.nprob; ++i) { const int t = (L.p[i].M + 127) / 128; if (t > mt) mt = t; }
+      L.m_tiles = mt;
+      return launch_cfg<2, 2, 8, 4>(L, tn, s);
+    }
     if (wide128) return launch_cfg<2, 2, 4, 4>(L, tn, s);
     if (wide) return launch_cfg<2, 2, 8, 4>(L, tn, s);
     return big ? launch_cfg<2, 2, 10>(L, tn, s) : launch_cfg<1, 4, 5>(L, tn, s);
