@@ -558,8 +558,13 @@ gemm_nt_kernel(const Launch L_byval) {
   // is float4 (row i / C4, column chunk i % C4) with C4 = EP_PITCH/4 a compile-time divisor, so a wave instruction
   // touches one contiguous run of a row in every epilogue stream.  Row reductions (attention head scores, the GSL
   // scorer's projection) read the finished rows back from LDS, one wave per row, in a fixed order (deterministic).
-  if (dbg_bits & 1) {
-    if (acc[0][0][0] == 12345.678f && acc[MI - 1][NI - 1][3] == 1.f) P.C[0] = 0.f;
+  if (dbg_bits & 1) {      // (tool build: K loop only.  Every accumulator stays live -- a test of two of them lets the compiler drop the other MFMAs)
+    float sum = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) sum += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
+    if (sum == 12345.678f) P.C[0] = 0.f;
     return;
   }
   const int epi = P.epi;
@@ -576,7 +581,7 @@ gemm_nt_kernel(const Launch L_byval) {
   const bool out_dead = scorer && P.ldu == 1;                            // EPI_TANH_H: padding rows' outputs feed the scorer only
   const bool rowred = (epi == EPI_ATT) || scorer;
   float* ep = reinterpret_cast<float*>(smem);
-  float* const ep_bias_ptr = ep + 16 * WM * EP_PITCH + NW * 64 * 4;
+  float* const ep_bias_ptr = ep + (PP ? 64 : 16 * WM) * EP_PITCH + NW * 64 * 4;      // (PP: behind the 64 staged rows of gemm_nt_pp_epi.hip.h)
   const int N4 = N >> 2;
   constexpr int C4 = EP_PITCH / 4;
   constexpr int ITEMS = 16 * WM * C4;
@@ -614,6 +619,46 @@ gemm_nt_kernel(const Launch L_byval) {
     // of the epilogue inputs: no change)
     if (!(dbg_bits & 16)) { __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p + o)); return; }
     *reinterpret_cast<float4*>(p + o) = v;
+  };
+  auto row_reduce = [&](auto MIT) __attribute__((always_inline)) {
+    constexpr int mi = decltype(MIT)::value;
+    if (rowred) {
+      // e[row][c] = sum_k y[row][k] w2[c][k] for the 16*WM finished rows in LDS: a [16 x N] x [N x <=8] product per row
+      // tile, on MFMA.  Wave (b, kp) takes row tile b and every KSPL-th K tile; partials meet in LDS (fixed order).
+      __syncthreads();
+      constexpr int KSPL = NW / WM;
+      const int nred = scorer ? 1 : heads;
+      const int b = wave % WM, kp = wave / WM;
+      const float* arow = ep + (b * 16 + l15) * EP_PITCH + 4 * q;
+      // (EPI_ATT on a column block of a wider row -- Batch::add, att_blocks: w2 is [heads][ldu], this block starts at its column)
+      const float* wrow = P.w2 + (size_t)min(l15, nred - 1) * (epi == EPI_ATT ? P.ldu : N) + 4 * q;
+      f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int k0 = kp * 16; k0 < N; k0 += 16 * KSPL) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + k0);          // columns >= N of the staged tile are exact zeros
+        f32x4 w4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (l15 < nred && k0 + 4 * q < N) w4 = *reinterpret_cast<const f32x4*>(wrow + k0);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) d = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s2], a4[s2], d, 0, 0, 0);
+      }
+      // d[r] = partial e[row l15][c = 4q + r]
+      float* red = ep + 16 * WM * EP_PITCH;                                   // [KSPL][WM][64] float4, behind the staged rows
+      *reinterpret_cast<f32x4*>(red + ((kp * WM + b) * 64 + lane) * 4) = d;
+      __syncthreads();
+      if (kp == 0) {
+        f32x4 sum = d;
+#pragma unroll
+        for (int k2 = 1; k2 < KSPL; ++k2) sum += *reinterpret_cast<const f32x4*>(red + ((k2 * WM + b) * 64 + lane) * 4);
+        const int row = m0 + b * 16 * MI + mi * 16 + l15;
+        if (row < M) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * q + r < nred) {
+              if (P.e_atomic == 1) atomicAdd(&P.e[(size_t)row * nred + 4 * q + r], sum[r]);
+              else P.e[(size_t)row * nred + 4 * q + r] = sum[r];
+            }
+        }
+      }
+    }
   };
   auto epilogue_pass = [&](auto MIT) __attribute__((always_inline)) {
     constexpr int mi = decltype(MIT)::value;
@@ -896,44 +941,14 @@ gemm_nt_kernel(const Launch L_byval) {
     else if (epi == EPI_BWD_DRX) pass(std::integral_constant<int, EPI_BWD_DRX>{});
     else if (epi == EPI_GATE_PRE) pass(std::integral_constant<int, EPI_GATE_PRE>{});
     else if (epi == EPI_ATT) pass(std::integral_constant<int, EPI_ATT>{});
-    if (rowred) {
-      // e[row][c] = sum_k y[row][k] w2[c][k] for the 16*WM finished rows in LDS: a [16 x N] x [N x <=8] product per row
-      // tile, on MFMA.  Wave (b, kp) takes row tile b and every KSPL-th K tile; partials meet in LDS (fixed order).
-      __syncthreads();
-      constexpr int KSPL = NW / WM;
-      const int nred = scorer ? 1 : heads;
-      const int b = wave % WM, kp = wave / WM;
-      const float* arow = ep + (b * 16 + l15) * EP_PITCH + 4 * q;
-      // (EPI_ATT on a column block of a wider row -- Batch::add, att_blocks: w2 is [heads][ldu], this block starts at its column)
-      const float* wrow = P.w2 + (size_t)min(l15, nred - 1) * (epi == EPI_ATT ? P.ldu : N) + 4 * q;
-      f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int k0 = kp * 16; k0 < N; k0 += 16 * KSPL) {
-        const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + k0);          // columns >= N of the staged tile are exact zeros
-        f32x4 w4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (l15 < nred && k0 + 4 * q < N) w4 = *reinterpret_cast<const f32x4*>(wrow + k0);
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) d = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s2], a4[s2], d, 0, 0, 0);
-      }
-      // d[r] = partial e[row l15][c = 4q + r]
-      float* red = ep + 16 * WM * EP_PITCH;                                   // [KSPL][WM][64] float4, behind the staged rows
-      *reinterpret_cast<f32x4*>(red + ((kp * WM + b) * 64 + lane) * 4) = d;
-      __syncthreads();
-      if (kp == 0) {
-        f32x4 sum = d;
-#pragma unroll
-        for (int k2 = 1; k2 < KSPL; ++k2) sum += *reinterpret_cast<const f32x4*>(red + ((k2 * WM + b) * 64 + lane) * 4);
-        const int row = m0 + b * 16 * MI + mi * 16 + l15;
-        if (row < M) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (4 * q + r < nred) {
-              if (P.e_atomic == 1) atomicAdd(&P.e[(size_t)row * nred + 4 * q + r], sum[r]);
-              else P.e[(size_t)row * nred + 4 * q + r] = sum[r];
-            }
-        }
-      }
-    }
+    row_reduce(MIT);
   };
+  if constexpr (PP) {
+    if (epi != EPI_ATT) {
+#include "gemm_nt_pp_epi.hip.h"
+      return;
+    }
+  }
   epilogue_pass(std::integral_constant<int, 0>{});
   epilogue_pass(std::integral_constant<int, 1>{});
   if constexpr (MI >= 4) {
