@@ -516,6 +516,11 @@ def parity_check(wl, k=4):
 
 
 DOMINANT = "gemm_big"
+SEED = 20240229                   # data / model seed of every workload (rank r adds r to the data seed)
+# Largest |logit - CPU oracle| the bf16 storage pipeline may show on the configs[4] bench batch (asserted at full size, evaluation and
+# training mode, by tests/test_gpu_fullsize_grads.py::test_config4_bf16_storage_at_the_bench_batch_vs_oracle; measured 1.6e-3 - 1.8e-3).
+# The configs[4] bf16 leg reports itself as FAILED when its own oracle slice exceeds it.
+BF16_BENCH_LOGIT_BOUND = 5e-3
 STRONG_GLOBAL_BATCH = 256         # BASELINE configs[3]
 
 # The BASELINE configs the headline invocation does not run as its main workload, printed beside it (`other_configs`) so that
@@ -528,6 +533,11 @@ OTHER_CONFIGS = [
     ("configs[4] h=768, 8 word heads, gnn_window=5, gsl_rate=0.8, B=32 x 30, bf16 storage in the cells",
      dict(batch=32, n_evd=30, hidden=768, emb_dim=768, word_heads=8, window=5, gsl_rate=0.8), "bf16", 10),
 ]
+
+
+def other_config_seed(i: int) -> int:
+    """Seed of OTHER_CONFIGS[i]'s workload (tests/test_gpu_fullsize_grads.py rebuilds the configs[4] bf16 batch from it)."""
+    return SEED + 7 * (i + 1)
 
 
 def other_config_leg(args, name, overrides, mode, steps, device, dist, seed):
@@ -558,10 +568,15 @@ def other_config_leg(args, name, overrides, mode, steps, device, dist, seed):
                                "measured": f"HIP events around every {DOMINANT} launch of the first {pd['steps']} timed steps"}
         leg["parity"] = parity_check(wl, k=2)
         if mode == "bf16":
-            leg["parity"]["note"] = ("bf16 storage inside the cells is NOT the 1e-4 fp32 contract: against the fp32 oracle the logits of this batch "
-                                     "sit at the 1e-3 .. 1e-2 level, GSL keep decisions of nodes whose scores tie within bf16 noise may flip "
-                                     "(counted above); the asserted bf16 bounds (logits 2e-3, weights 5e-3, gradients 6e-2 on its batch) are "
-                                     "tests/test_gpu_model.py::test_h768_bf16_storage_vs_the_cpu_oracle")
+            # bf16 storage inside the cells is not the 1e-4 fp32 contract: its asserted bound at THIS batch is BF16_BENCH_LOGIT_BOUND
+            # (tests/test_gpu_fullsize_grads.py checks logits, weights, scores, keep-sets and every gradient of the full batch)
+            d = leg["parity"]["max_abs_logit_diff_vs_cpu_oracle"]
+            leg["parity"]["bound"] = BF16_BENCH_LOGIT_BOUND
+            leg["parity"]["within_bound"] = bool(d <= BF16_BENCH_LOGIT_BOUND)
+            leg["parity"]["bound_asserted_by"] = "tests/test_gpu_fullsize_grads.py::test_config4_bf16_storage_at_the_bench_batch_vs_oracle"
+            if not leg["parity"]["within_bound"]:
+                leg["failed"] = f"logits differ from the CPU oracle by {d:.2e} > {BF16_BENCH_LOGIT_BOUND:.0e}: the timing of this leg is not a valid number"
+                leg["value"] = None
         fl = flops_per_pair(cfg, wl["nnz_per_graph"], wl["m_real"] / max(wl["b1"], 1) if wl["compact"] else None)
         fl_run = fl.get("executed", fl["fwd_bwd"])
         leg["path_tflops"] = fl_run * s["value"] / 1e12
@@ -746,7 +761,6 @@ def main():
     _lib.load()
     _lib.set_gemm_mode(args.gemm_mode)
 
-    SEED = 20240229
     per_rank = args.batch
     shard = None
     if args.global_batch > 0:
@@ -1025,7 +1039,7 @@ def main():
                                        "rows": series}
         if world == 1 and headline and default_side and not args.no_other_configs:
             # the other BASELINE configs as legs of the same run (two of five configs had no driver-observed timing)
-            out["other_configs"] = [other_config_leg(args, nm, ov, md, st, device, dist, SEED + 7 * (i + 1))
+            out["other_configs"] = [other_config_leg(args, nm, ov, md, st, device, dist, other_config_seed(i))
                                     for i, (nm, ov, md, st) in enumerate(OTHER_CONFIGS)]
         if world == 1 and not args.no_cpu_baseline and not args.forward_only:
             out["parity"] = parity_check(wl)

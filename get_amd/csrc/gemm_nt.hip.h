@@ -944,10 +944,9 @@ gemm_nt_kernel(const Launch L_byval) {
     row_reduce(MIT);
   };
   if constexpr (PP) {
-    if (epi != EPI_ATT) {
+    bool pp_done = true;
 #include "gemm_nt_pp_epi.hip.h"
-      return;
-    }
+    if (pp_done) return;
   }
   epilogue_pass(std::integral_constant<int, 0>{});
   epilogue_pass(std::integral_constant<int, 1>{});

@@ -1,4 +1,5 @@
-// Epilogue of gemm_nt_kernel<2, 4, 4, 8, 2> (256 x 256 bf16 tile, 512 threads, ONE workgroup per CU), every kind except EPI_ATT.
+// Epilogue of gemm_nt_kernel<2, 4, 4, 8, 2> (256 x 256 bf16 tile, 512 threads, ONE workgroup per CU).  (EPI_ATT with other than fp32
+// streams leaves `pp_done` false and takes the kernel's plain passes.)
 // Included INSIDE the kernel body (gemm_nt.hip.h).  Same whole-row scheme as `pass8` -- eight passes of 32 staged rows, items of
 // eight columns, one 16-byte access per bf16 stream and item -- but SOFTWARE-PIPELINED across the passes: with one workgroup per
 // CU nothing else runs underneath an epilogue, and a pass that requests its input streams only after its rows are staged waits a
@@ -67,7 +68,8 @@
   auto pp_fast = [&](auto EPI, auto ACCF, auto GINF) __attribute__((always_inline)) {
     constexpr int E = decltype(EPI)::value;
     constexpr bool ACC = decltype(ACCF)::value, GIN = decltype(GINF)::value;
-    constexpr int NIN = E == EPI_STORE ? (ACC ? 1 : 0) : E == EPI_SIGMOID_Z ? 0 : E == EPI_SIGMOID_R ? 1 : E == EPI_TANH_H ? 2 : 3;
+    constexpr int NIN = E == EPI_STORE ? (ACC ? 1 : 0) : (E == EPI_SIGMOID_Z || E == EPI_ATT) ? 0 : E == EPI_SIGMOID_R ? 1 : E == EPI_TANH_H ? 2 : 3;
+    constexpr bool ATT = E == EPI_ATT;      // fp32 streams: u[pair of the row][col] in (two 16-byte halves per item), t out
     constexpr int NOUT = (E == EPI_STORE || E == EPI_SIGMOID_Z) ? 1 : E == EPI_GATE_PRE ? 3 : 2;
     // input streams: STORE+accumulate reads C; BWD_DRX's third input is out1 (dxp += .); GATE_PRE's is in2
     const void* i0 = E == EPI_STORE ? (const void*)C : (const void*)in0;
@@ -76,7 +78,7 @@
     const rsrc_t rs_i0 = __builtin_amdgcn_make_buffer_rsrc((void*)(NIN >= 1 ? i0 : (const void*)C), 0, 0x7fffffff, 0x00020000);
     const rsrc_t rs_i1 = __builtin_amdgcn_make_buffer_rsrc((void*)(NIN >= 2 ? i1 : (const void*)C), 0, 0x7fffffff, 0x00020000);
     const rsrc_t rs_i2 = __builtin_amdgcn_make_buffer_rsrc((void*)(NIN >= 3 ? i2 : (const void*)C), 0, 0x7fffffff, 0x00020000);
-    const rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(GIN ? (const void*)P.gin : (const void*)C), 0, 0x7fffffff, 0x00020000);
+    const rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(GIN ? (const void*)P.gin : ATT ? (const void*)P.u : (const void*)C), 0, 0x7fffffff, 0x00020000);
     const rsrc_t rs_o0 = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, 0x7fffffff, 0x00020000);
     const rsrc_t rs_o1 = __builtin_amdgcn_make_buffer_rsrc((void*)(NOUT >= 2 ? (void*)out1 : (void*)C), 0, 0x7fffffff, 0x00020000);
     const rsrc_t rs_o2 = __builtin_amdgcn_make_buffer_rsrc((void*)(NOUT >= 3 ? (void*)P.out2 : (void*)C), 0, 0x7fffffff, 0x00020000);
@@ -86,6 +88,20 @@
       const bool ok = pp_item(p_, j, row, col, rr);
       return ok ? (unsigned)(row * ldc + col) * (unsigned)esz : OOB;
     };
+    // EPI_ATT: byte offset of the item's u row (the row's pair / claim through rowg, else row / R), all passes up front
+    unsigned uoff[MI][2];
+    if constexpr (ATT) {
+#pragma unroll
+      for (int p_ = 0; p_ < MI; ++p_)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          int row, col, rr;
+          const bool ok = pp_item(p_, j, row, col, rr);
+          const int rc_ = min(row, M - 1);
+          const int ur = P.rowg ? P.rowg[rc_] : rc_ / P.R;
+          uoff[p_][j] = ok ? (unsigned)(ur * P.ldu + col) * 4u : OOB;
+        }
+    }
     auto issue = [&](auto PT, auto SET) __attribute__((always_inline)) {
       constexpr int p_ = decltype(PT)::value, set = decltype(SET)::value;
 #pragma unroll
@@ -94,8 +110,9 @@
         if constexpr (NIN >= 1) ra[set][j] = __builtin_bit_cast(pp_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_i0, vo, 0, 0));
         if constexpr (NIN >= 2) rb[set][j] = __builtin_bit_cast(pp_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_i1, vo, 0, 0));
         if constexpr (NIN >= 3) rc[set][j] = __builtin_bit_cast(pp_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_i2, vo, 0, 0));
-        if constexpr (GIN) {
-          const unsigned vg = voff(p_, j, 4);
+        if constexpr (GIN || ATT) {
+          unsigned vg;
+          if constexpr (ATT) vg = uoff[p_][j]; else vg = voff(p_, j, 4);
           rg[set][j][0] = __builtin_bit_cast(pp_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, vg, 0, 0));
           rg[set][j][1] = __builtin_bit_cast(pp_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, vg, 16, 0));
         }
@@ -114,7 +131,18 @@
         float* sp = ep + rr * EP_PITCH + col;
         float4 wa = add4(*reinterpret_cast<const float4*>(sp), *reinterpret_cast<const float4*>(bsum + col));
         float4 wb = add4(*reinterpret_cast<const float4*>(sp + 4), *reinterpret_cast<const float4*>(bsum + col + 4));
-        if (E == EPI_STORE) {
+        if (E == EPI_ATT) {      // t = tanh(v + u[pair]) -> C (fp32) and back into the staged row for the head-score reduction
+          const f32x4 g0 = __builtin_bit_cast(f32x4, rg[set][j][0]), g1 = __builtin_bit_cast(f32x4, rg[set][j][1]);
+          const float4 ta = tanh4(add4(wa, make_float4(g0[0], g0[1], g0[2], g0[3])));
+          const float4 tb = tanh4(add4(wb, make_float4(g1[0], g1[1], g1[2], g1[3])));
+          const unsigned vo4 = voff(p_, j, 4);
+          __builtin_amdgcn_raw_buffer_store_b128(pp_u32x4{__builtin_bit_cast(unsigned, ta.x), __builtin_bit_cast(unsigned, ta.y), __builtin_bit_cast(unsigned, ta.z), __builtin_bit_cast(unsigned, ta.w)}, rs_o0, vo4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(pp_u32x4{__builtin_bit_cast(unsigned, tb.x), __builtin_bit_cast(unsigned, tb.y), __builtin_bit_cast(unsigned, tb.z), __builtin_bit_cast(unsigned, tb.w)}, rs_o0, vo4, 16, 0);
+          if (vo != OOB) {
+            *reinterpret_cast<float4*>(sp) = ta;
+            *reinterpret_cast<float4*>(sp + 4) = tb;
+          }
+        } else if (E == EPI_STORE) {
           if (drop_mode == 3) {
             const unsigned idx = (unsigned)row * (unsigned)drop_ld + (unsigned)(P.drop_col0 + col);
             wa = drop4(wa, drop_seed, idx, drop_thresh, drop_scale);
@@ -176,6 +204,7 @@
       if constexpr (p_ + 1 < MI) issue(std::integral_constant<int, p_ + 1>{}, std::integral_constant<int, (p_ + 1) & 1>{});
       compute(PT);
       if constexpr (E == EPI_TANH_H) { if (rowred) row_reduce(PT); }
+      if constexpr (ATT) row_reduce(PT);
     };
     issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     pass(std::integral_constant<int, 0>{}); pass(std::integral_constant<int, 1>{}); pass(std::integral_constant<int, 2>{});
@@ -187,6 +216,7 @@
     constexpr std::integral_constant<bool, true> YES{};
     const bool no_c32 = c32 == nullptr;
     if (!(dbg_bits & 128) && no_c32) {
+      if (epi == EPI_ATT && pp_io == 0) { pp_fast(std::integral_constant<int, EPI_ATT>{}, NO, NO); return; }
       if (epi == EPI_STORE && (pp_io & 1)) {
         if (accumulate) pp_fast(std::integral_constant<int, EPI_STORE>{}, YES, NO); else pp_fast(std::integral_constant<int, EPI_STORE>{}, NO, NO);
         return;
@@ -203,6 +233,8 @@
   }
 
   // ------------------------------------------------------------------ generic form: run-time stream formats
+  if (epi == EPI_ATT) pp_done = false;
+  else {
   const float* s0p = (epi == EPI_SIGMOID_R || epi == EPI_TANH_H || epi == EPI_BWD_DRX || epi == EPI_GATE_PRE) ? in0 : nullptr;
   const float* s1p = (epi == EPI_TANH_H || epi == EPI_BWD_DRX || epi == EPI_GATE_PRE) ? in1 : nullptr;
   const float* s2p = epi == EPI_BWD_DRX ? (const float*)out1 : epi == EPI_GATE_PRE ? P.in2 : (epi == EPI_STORE && accumulate) ? (const float*)C : nullptr;
@@ -322,4 +354,5 @@
   else if (epi == EPI_SIGMOID_R) pp_all(std::integral_constant<int, EPI_SIGMOID_R>{});
   else if (epi == EPI_TANH_H) pp_all(std::integral_constant<int, EPI_TANH_H>{});
   else if (epi == EPI_BWD_DRX) pp_all(std::integral_constant<int, EPI_BWD_DRX>{});
+  }
 }

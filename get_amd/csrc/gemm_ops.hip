@@ -546,16 +546,17 @@ struct Batch {
     static int no_wide = -1;
     if (no_wide < 0) no_wide = measure_env("GH_BF16_TILE", 0) == 320 ? 1 : 0;
     if (wide_bf16 && big && !tn_ && !no_wide) { wide = true; bm = 128; bn = 256; }
-    // 256 x 256 / 8 waves (one workgroup per CU, four LDS stages) halves the L2 -> LDS bytes per FLOP of the 128 x 256 tile.
-    // Measured on configs[4] (B = 32): 0.200 (three stages) / 0.198 (four) of the bf16 peak against 0.207 -- with one workgroup
-    // per CU nothing runs underneath its epilogue.  Kept for the tool build only (GH_BF16_TILE=256).
-    static int tile256 = -1;
-    if (tile256 < 0) tile256 = measure_env("GH_BF16_TILE", 0) == 256 ? 1 : 0;
-    static int tile256_sites = -1;
-    if (tile256_sites < 0) tile256_sites = measure_env("GH_BF16_TILE256_SITES", 0);      // (per call site, tool build)
+    // 256 x 256 x 64 / 8 waves, one workgroup per CU, ping-pong K loop + software-pipelined epilogue (gemm_nt_pp.hip.h, round 6):
+    // the default for activation-sized launches of the bf16 storage pipeline -- configs[4], B = 32: gemm_big 4.25 -> 3.09 ms per
+    // step, 128.1 -> 148.6 K pairs/s.  (Round 3's 256 x 256 tile -- the 128 x 256 tile's K loop on 8 waves, 32-deep stages --
+    // measured 0.200 against 0.207: not the tile size but the loop structure is the lever.)  Launches below 32 768 rows (fewer
+    // than 1.5 workgroups per CU) keep the 128 x 256 tile.  Tool build: GH_BF16_TILE=1 restores 128 x 256 everywhere,
+    // GH_BF16_TILE256_ROWS moves the row threshold.
+    static int tile_env = -1;
+    if (tile_env < 0) tile_env = measure_env("GH_BF16_TILE", 0);
     static int tile256_rows = -1;
     if (tile256_rows < 0) tile256_rows = measure_env("GH_BF16_TILE256_ROWS", 32768);
-    if (wide && rows_hint >= tile256_rows && (tile256 || (site > 0 && ((tile256_sites >> (site - 1)) & 1)))) { wide256 = true; bm = 256; }
+    if (wide && rows_hint >= tile256_rows && tile_env != 1 && tile_env != 128) { wide256 = true; bm = 256; }
     static int tile128 = -1;
     if (tile128 < 0) tile128 = measure_env("GH_BF16_TILE", 0) == 128 ? 1 : 0;
     if (wide && tile128) { wide128 = true; bn = 128; }
@@ -873,6 +874,10 @@ int gh::cell_fwd_impl(int bf, float* out32, const uint64_t* bits, const float* d
   const int M = m_rows;
   if (M == 0) return 0;
   GH_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ggnn_cell_fwd: dropout p=%f not in [0,1)", drop_p);
+  // the stateless dropout mask hashes a 32-BIT element index row * width + column (gemm.hip.h drop_hash): beyond 2^32 elements
+  // two rows would share their mask
+  GH_REQUIRE((drop_p <= 0.f && score_drop_p <= 0.f) || (long long)M * (long long)(din > h ? din : h) < (1LL << 32),
+             "ggnn_cell_fwd: %d rows x %d columns exceed the dropout mask's 32-bit element index", M, din > h ? din : h);
   GH_REQUIRE((score_w == nullptr) == (score_x == nullptr), "ggnn_cell_fwd: score_w and score_x come together");
   GH_REQUIRE(score_drop_p >= 0.f && score_drop_p < 1.f, "ggnn_cell_fwd: scorer dropout p=%f not in [0,1)", score_drop_p);
   const bool wide = bf && h % 256 == 0;      // 128 x 256 bf16 tiles cover the width exactly (h = 768)
@@ -1037,6 +1042,8 @@ int gh::cell_bwd_impl(int bf, const uint64_t* bits, const float* dinv, const flo
   GH_REQUIRE(!bf || (din % 8 == 0 && h % 8 == 0 && din <= h), "ggnn_cell_bwd_bf16: needs din %% 8 == 0, h %% 8 == 0, din <= h (din=%d h=%d)", din, h);
   if (!goff) m_real = n * r;
   GH_REQUIRE(m_real >= 0 && m_real <= n * r, "ggnn_cell_bwd: node-compact rows %d do not fit n*r=%d", m_real, n * r);
+  GH_REQUIRE(drop_p <= 0.f || (long long)n * r * (long long)din < (1LL << 32),
+             "ggnn_cell_bwd: %d rows x %d columns exceed the dropout mask's 32-bit element index", n * r, din);
   const int M = m_real;      // padding rows receive no gradient and contribute none
   if (M == 0) return 0;
   // out = h z + xp (1-z):  dhp = g z (1-h^2), dzp = g (h-xp) z (1-z), dxp = g (1-z)

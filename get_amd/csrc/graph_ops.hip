@@ -1220,6 +1220,7 @@ int gh::scorer_gsl_impl(const uint64_t* bits, const float* dinv, const float* va
   prof_begin((hipStream_t)stream, PROF_SCORER_GSL);
   GH_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "scorer_gsl: dropout p=%f not in [0,1)", drop_p);
   GH_REQUIRE(!(pads_collapsed && drop_p > 0.f), "scorer_gsl: collapsed padding rows are an evaluation-mode layout (no dropout)");
+  GH_REQUIRE(drop_p <= 0.f || (long long)n * r * (long long)h < (1LL << 32), "scorer_gsl: %d rows x %d columns exceed the dropout mask's 32-bit element index", n * r, h);
   const double th = (double)drop_p * 4294967296.0;
   const unsigned thresh = drop_p > 0.f ? (th >= 4294967295.0 ? 4294967295u : (unsigned)th) : 0u;
   GH_REQUIRE((feat != nullptr) != (score_x != nullptr), "scorer_gsl: exactly one of feat / score_x");

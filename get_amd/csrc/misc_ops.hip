@@ -437,6 +437,7 @@ gather_rows_bf16_kernel(const unsigned short* __restrict__ table, const int32_t*
 int launch_gather_rows(const float* table, const int32_t* ids, float* dst, int m, int d, hipStream_t s, float drop_p,
                        unsigned drop_seed, int bf16) {
   if (m <= 0) return 0;
+  GH_REQUIRE(drop_p <= 0.f || (long long)m * (long long)d < (1LL << 32), "gather_rows: %d rows x %d columns exceed the dropout mask's 32-bit element index", m, d);
   if (bf16) {
     GH_REQUIRE(d % 4 == 0, "gather_rows: the bf16 variant needs d %% 4 == 0");
     const size_t n = (size_t)m * (d / 4);

@@ -298,3 +298,77 @@ def test_single_rank_group_reduces_only_when_asked():
             assert tr.comm_bytes == (tr.numel * 4 if flag else 0)
     finally:
         dist.destroy_process_group()
+
+
+def _worker_world8_real_model(rank, world, port, out):
+    """One rank of the world-8 rehearsal: the REAL model's parameter set (small case, CPU tensors -- its forward is GPU-only, so a
+    backward pass is emulated by writing rank-dependent gradients into the bucket's views in the order the real backward
+    produces them: early range, milestone hook, late range)."""
+    from get_amd import modules
+    from get_amd.dist import LATE_PREFIXES
+    from get_amd.synth import make_embeddings
+    from oracle.cases_model import MODEL_CASES
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, seed = MODEL_CASES["small"]
+    emb, art, clm = make_embeddings(cfg, seed)
+    torch.manual_seed(1000 + rank)                         # replicas start DIFFERENT: the broadcast must make them equal
+    model = modules.Graph_basedSemantiStructure(cfg.model_params(emb, art, clm))
+    tr = FlatTrainer(model)
+    assert tr.world == world and 0 < tr.n_early < tr.numel
+    tr.broadcast_parameters(src=0)
+    tr.attach_overlap()                                     # model.ggnn_with_gsl.grad_milestone_hook = allreduce_early_async
+    hook = model.ggnn_with_gsl.grad_milestone_hook
+    assert hook is not None
+    names = tr.live_names
+    early = [n for n in names if not n.startswith(LATE_PREFIXES)]
+    late = [n for n in names if n.startswith(LATE_PREFIXES)]
+    assert names == early + late and early and late
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for step in range(3):
+        tr.zero_grad()
+        fill = lambda i: float((rank + 1) * (i % 7 + 1) + step)      # gradient of parameter i on this rank
+        for i, n in enumerate(names):
+            if n in late:
+                continue
+            params[n].grad.fill_(fill(i))
+        assert tr._early_work is None
+        hook()                                              # what GGNN_with_GSL's backward hook does at the milestone
+        assert tr._early_work is not None, "the early range must go out asynchronously at world 8"
+        for i, n in enumerate(names):
+            if n in late:
+                params[n].grad.fill_(fill(i))
+        tr.allreduce()                                      # waits for the early range, reduces the late one
+        assert tr._early_work is None
+        for i, n in enumerate(names):
+            exp = sum((r + 1) * (i % 7 + 1) + step for r in range(world))
+            worst = max(worst, float((params[n].grad - exp).abs().max()))
+    # parameters identical on every rank after the broadcast (dead and frozen tensors included)
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        out.put((worst, all(torch.equal(g, gathered[0]) for g in gathered), tr.comm_calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world8_overlapped_allreduce_on_the_real_models_bucket():
+    """the first RCCL run at 8 ranks must not also be the first world-8 run of the overlap logic.  Eight gloo
+    ranks, FlatTrainer on the real model's parameters with attach_overlap(): broadcast from rank 0, then three emulated steps --
+    early gradients, milestone hook (asynchronous early all-reduce), late gradients, allreduce() -- and every gradient equals
+    the sum over the eight ranks' contributions."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_world8_real_model, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    worst, same, calls = q.get(timeout=5)
+    assert worst == 0.0 and same
+    assert calls == 3 * 2                                   # per step: the early range (asynchronous) + the late range (comm_calls counts all-reduces)

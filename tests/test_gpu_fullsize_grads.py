@@ -244,3 +244,81 @@ def test_linear_fwd_bwd_big_tile_fp32_vs_fp64(m, k, n):
     assert float((y.detach().cpu() - yo.detach()).abs().max()) <= 2e-5 * max(1.0, float(yo.abs().max()))
     for got, exp in ((xt.grad, xo.grad), (wt.grad, wo.grad), (bt.grad, bo.grad)):
         assert float((got.cpu() - exp).abs().max()) <= 1e-4 * float(exp.abs().max()) + 1e-6
+
+
+# bf16 storage bounds AT THE BENCH BATCH (configs[4], B = 32 x 30, h = 768).  The 6-claim test
+# (test_gpu_model.py::test_h768_bf16_storage_vs_the_cpu_oracle) asserts logits 2e-3 on ITS batch; the bounds below are the ones that
+# hold on the 960-pair batch the bench line is quoted on, ~2.5 x the values measured there in round 6 (evaluation / training mode:
+# logits 1.6e-3 / 1.8e-3, word weights 0.9e-3 / 1.2e-3, evidence weights 1.1e-4, scorer scores 6.7e-3 / 1.0e-2, worst gradient
+# 2.0e-2 / 1.7e-2 of its tensor's largest entry over 29.6 M values, GSL keep decisions flipped for 88 / 106 of 61 856 real nodes in
+# 44 / 54 of 960 graphs -- nodes whose score ties with the k-th within bf16 noise).  The logit bound is bench.BF16_BENCH_LOGIT_BOUND:
+# bench.py's configs[4] bf16 leg checks its own oracle slice against it and reports the leg as failed beyond it.
+def _bf16_bounds():
+    from bench import BF16_BENCH_LOGIT_BOUND
+    return dict(logits=BF16_BENCH_LOGIT_BOUND, word_weights=3e-3, evd_weights=5e-4, scores=2.5e-2, grads=5e-2, keep_nodes=0.005, keep_graphs=0.12)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_config4_bf16_storage_at_the_bench_batch_vs_oracle(train):
+    """BASELINE configs[4] bf16 storage pipeline on EXACTLY the batch `bench.py`'s other_configs leg times (other_config_leg:
+    build_workload(seed=other_config_seed(2), cfg=SynthConfig(**OTHER_CONFIGS[2][1])),
+    960 pairs, ~62 K real node rows -> the 256 x 256 ping-pong NT tile, the 128 x 320 bf16 weight-gradient tile): logits, both
+    attention-weight tensors, scorer scores and every live gradient against O.model_forward + CE + autograd
+    (graph_based_semantic_structure.py:76-125, wrapper.py:188-206 in fp32 on the CPU), evaluation mode and training mode (the
+    oracle replays the product's dropout masks).  Bounds: _bf16_bounds() above."""
+    from bench import OTHER_CONFIGS, build_workload, other_config_seed
+    from get_amd import _lib, ops
+    from get_amd.synth import SynthConfig
+    (name, overrides, mode, _), = [c for c in OTHER_CONFIGS if c[2] == "bf16"]
+    SEED = other_config_seed([c[0] for c in OTHER_CONFIGS].index(name))
+    cfg = SynthConfig(**overrides)
+    assert cfg.hidden == 768 and cfg.batch == 32 and mode == "bf16"
+    _lib.set_gemm_mode("bf16")
+    ops.bump_weight_epoch()
+    try:
+        wl = build_workload(seed=SEED, device=DEV, cfg=cfg, n_batches=2)
+        assert wl["compact"] and wl["m_real"] >= 32768, "the bench batch must take the 256 x 256 tile"
+        model = wl["model"].train(train)
+        seeds = None
+        if train:
+            torch.manual_seed(SEED + 99)
+            seeds = torch.randint(0, 2 ** 31 - 1, (4,)).tolist()
+            torch.manual_seed(SEED + 99)
+        _lib.gemm_path_counters(reset=True)
+        phi, (ww, ew) = model(wl["query"], wl["document"], **dict(wl["kargs"], output_ranking=True))
+        assert not train or getattr(model, "_gh_binding", None) is not None
+        torch.nn.functional.cross_entropy(phi, wl["labels"]).backward()
+        torch.cuda.synchronize()
+        assert _lib.gemm_path_counters()["generic_large"] == 0
+        keep_hip = _unpack_keep(model.ggnn_with_gsl.last_keep, cfg.len_right)
+        score_hip = model.ggnn_with_gsl.last_score.cpu()
+    finally:
+        _lib.set_gemm_mode("fp32")
+        ops.bump_weight_epoch()
+    drop_keep = _dropout_keeps(wl, model, seeds, cfg, True) if train else None
+    ora = _oracle_full(wl, drop_keep=drop_keep)
+    real = ora["inp"]["doc_ids"] > 0
+    n_pairs = real.shape[0]
+    mism = (keep_hip[:n_pairs] != ora["keep"].numpy()) & real
+    d_phi = float((phi.detach().cpu() - ora["phi"]).abs().max())
+    d_ww = float((ww.detach().cpu() - ora["ww"]).abs().max())
+    d_ew = float((ew.detach().cpu() - ora["ew"]).abs().max())
+    d_sc = float((score_hip[:n_pairs] - ora["score"])[torch.from_numpy(real)].abs().max())
+    worst, n_checked = (0.0, None), 0
+    for k, prm in model.named_parameters():
+        go = ora["grads"].get(k)
+        if go is None or prm.grad is None:
+            continue
+        rel = float((prm.grad.cpu() - go).abs().max()) / (float(go.abs().max()) + 1e-12)
+        if rel > worst[0]:
+            worst = (rel, k)
+        n_checked += prm.numel()
+    print(f"configs[4] bf16 at the bench batch (train={train}): logits {d_phi:.2e}, word weights {d_ww:.2e}, evidence weights {d_ew:.2e}, "
+          f"scores {d_sc:.2e}, worst gradient {worst[0]:.2e} ({worst[1]}) over {n_checked} values, keep decisions differ in "
+          f"{int(mism.any(1).sum())} of {n_pairs} graphs ({int(mism.sum())} of {int(real.sum())} real nodes)")
+    B = _bf16_bounds()
+    assert 1e-6 < d_phi <= B["logits"], d_phi
+    assert d_ww <= B["word_weights"] and d_ew <= B["evd_weights"], (d_ww, d_ew)
+    assert d_sc <= B["scores"], d_sc
+    assert mism.sum() <= B["keep_nodes"] * real.sum() and mism.any(1).sum() <= B["keep_graphs"] * n_pairs
+    assert n_checked >= 20_000_000 and worst[0] <= B["grads"], worst

@@ -1340,3 +1340,75 @@ def test_unit_seed_backward_equals_loss_backward():
         ops.backward(loss) if unit else loss.backward()
         res.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
     assert set(res[0]) == set(res[1]) and all(torch.equal(res[0][k], res[1][k]) for k in res[0])
+
+
+def _g9_kargs():
+    """The **kargs the reference fitter handed to net(...) (G9, captured by oracle/make_golden.py from
+    char_man_fitter_query_repr1.py:164-258), rebuilt VERBATIM: every key incl. the five forward() ignores, int64 / float64
+    dtypes, the two 3-tuples of sort indices, the scalar fixed_num_evidences."""
+    z, meta = load("g9_fitter_kargs_small.npz")
+
+    def get(name, d):
+        if d["kind"] == "scalar":
+            return d["value"]
+        if d["kind"] == "tuple":
+            return tuple(get(f"{name}::{i}", di) for i, di in enumerate(d["items"]))
+        t = torch.from_numpy(np.ascontiguousarray(z[name]))
+        assert str(z[name].dtype) == d["dtype"] and list(z[name].shape) == d["shape"]
+        return t
+    kargs = {k: get(f"k::{k}", meta["desc"][k]) for k in meta["keys"]}
+    return z, meta, kargs
+
+
+def test_g9_captured_fitter_kargs_verbatim_on_the_hip_model():
+    """the captured hand-over itself -- not oracle.assemble.reference_kargs' restatement of it -- goes into
+    the HIP model: `net(query, document, **kargs)` exactly as char_man_fitter_query_repr1.py:234-253 calls it (dense float64
+    adjacencies, int64 ids, 3-tuples, the ignored keys), and must reproduce the reference's own outputs on that batch (G7
+    `small`: logits 1e-4, both attention-weight tensors and the scorer scores 1e-5)."""
+    z9, meta, kargs = _g9_kargs()
+    g7, _ = load("g7_model_small.npz")
+    cfg, seed = MODEL_CASES[meta["case"]]
+    model = build_model(cfg, seed)
+    assert {"query_content_without_padding_evidences", "query_char_source", "doc_char_source", "docs_lens", "fc_labels"} <= set(kargs)
+    assert kargs["docs_adj"].dtype == torch.float64 and isinstance(kargs["doc_lens_indices"], tuple) and len(kargs["doc_lens_indices"]) == 3
+    q, d = torch.from_numpy(z9["query"]).to(DEV), torch.from_numpy(z9["document"]).to(DEV)
+    with torch.no_grad():
+        phi = model(q, d, **to_dev(kargs))                                   # the training loop's call: logits only
+        assert torch.is_tensor(phi) and phi.shape == (cfg.batch, cfg.num_classes)
+        phi2, (ww, ew) = model(q, d, **to_dev(dict(kargs, output_ranking=True)))   # the evaluation loop adds output_ranking (:318)
+    assert np.abs(phi.cpu().numpy() - g7["phi"]).max() <= 1e-4
+    assert torch.equal(phi, phi2)
+    assert np.abs(ww.cpu().numpy() - g7["word_w"]).max() <= 1e-5
+    assert np.abs(ew.cpu().numpy() - g7["evd_w"]).max() <= 1e-5
+    assert np.abs(model.ggnn_with_gsl.last_score.cpu().numpy() - g7["score"]).max() <= 1e-5
+
+
+def test_g9_padded_fitter_tensors_through_the_depadding_shim():
+    """The same captured batch in the form the fitter holds BEFORE its de-padding loop (char_man_fitter_query_repr1.py:196-223:
+    (B, n, R) ids and a (B, n, R, R) float64 adjacency, rebuilt here by scattering G9's de-padded rows back by the evidence
+    counts) through get_amd.batch.kargs_from_reference_tensors (gh_ref_depad): same reference outputs (G7)."""
+    from get_amd.batch import kargs_from_reference_tensors
+    z9, meta, kargs = _g9_kargs()
+    g7, _ = load("g7_model_small.npz")
+    cfg, seed = MODEL_CASES[meta["case"]]
+    model = build_model(cfg, seed)
+    counts = kargs["evd_cnt_each_query"].numpy()
+    B, n, R = cfg.batch, int(kargs["fixed_num_evidences"]), cfg.len_right
+    ids = np.zeros((B, n, R), np.int64)
+    adj = np.zeros((B, n, R, R), np.float64)
+    last = 0
+    for b in range(B):
+        c = int(counts[b])
+        ids[b, :c] = kargs["doc_content_without_padding_evidences"].numpy()[last:last + c]
+        adj[b, :c] = kargs["docs_adj"].numpy()[last:last + c]
+        last += c
+    assert np.array_equal(ids, z9["document"])             # what the fitter passes as `document` IS the padded id tensor
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    k2 = kargs_from_reference_tensors(kargs["query_lens"].to(DEV), T(ids), T(adj), kargs["query_adj"].to(DEV), kargs["evd_cnt_each_query"].to(DEV),
+                                      kargs["doc_sources"].to(DEV), kargs["query_sources"].to(DEV), n_max=n)
+    k2["output_ranking"] = True
+    with torch.no_grad():
+        phi, (ww, ew) = model(torch.from_numpy(z9["query"]).to(DEV), T(ids), **k2)
+    assert np.abs(phi.cpu().numpy() - g7["phi"]).max() <= 1e-4
+    assert np.abs(ww.cpu().numpy() - g7["word_w"]).max() <= 1e-5
+    assert np.abs(ew.cpu().numpy() - g7["evd_w"]).max() <= 1e-5

@@ -136,3 +136,29 @@ def test_unit_seed_backward_is_plain_backward_for_any_loss():
     assert torch.equal(grads[0], grads[1])
     one = fused.unit_seed(torch.device("cpu"))
     assert one.shape == () and float(one) == 1.0 and fused.unit_seed(torch.device("cpu")) is one
+
+
+def test_stateless_dropout_mask_is_unbiased_and_uncorrelated():
+    """Mask hygiene of the kernels' stateless dropout (gemm.hip.h drop_hash: murmur3-finalised idx * golden-ratio + seed;
+    ops.dropout_mask_reference is its host replica, wrapper.py:185-190 is the op it implements): over 1.2e7 elements the keep
+    rate, the per-column and per-row keep rates, the lag-1 correlations along rows and along columns, and the correlation of
+    two seeds' masks all sit within 4 sigma of an i.i.d. Bernoulli(1 - p) field."""
+    import numpy as np
+    from get_amd.ops import dropout_mask_reference
+    rows, cols = 40000, 300
+    n = rows * cols
+    for p, seed in ((0.2, 12345), (0.5, 7)):
+        k = dropout_mask_reference(seed, rows, cols, p).astype(np.float64)
+        q = 1.0 - p
+        sd = np.sqrt(p * q)
+        assert abs(k.mean() - q) <= 4 * sd / np.sqrt(n)
+        assert np.abs(k.mean(0) - q).max() <= 4.9 * sd / np.sqrt(rows)          # 300 columns: 4.9 sigma ~ 1e-4 two-sided family-wise
+        assert np.abs(k.mean(1) - q).max() <= 5.5 * sd / np.sqrt(cols)          # 40 000 rows
+        c = k - q
+        for a, b in ((c[:, 1:], c[:, :-1]), (c[1:], c[:-1]), (c[2:], c[:-2]), (c[:, 4:], c[:, :-4])):
+            r = float((a * b).mean()) / (p * q)
+            assert abs(r) <= 4.0 / np.sqrt(a.size), r
+        k2 = dropout_mask_reference(seed + 1, rows, cols, p).astype(np.float64) - q
+        assert abs(float((c * k2).mean()) / (p * q)) <= 4.0 / np.sqrt(n)
+        k3 = dropout_mask_reference(seed ^ 0x5bd1e995, rows, cols, p).astype(np.float64) - q
+        assert abs(float((c * k3).mean()) / (p * q)) <= 4.0 / np.sqrt(n)
