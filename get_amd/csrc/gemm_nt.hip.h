@@ -943,6 +943,11 @@ gemm_nt_kernel(const Launch L_byval) {
     else if (epi == EPI_ATT) pass(std::integral_constant<int, EPI_ATT>{});
     row_reduce(MIT);
   };
+  if constexpr ((MODE == 0 || MODE == 1) && MI == 2) {      // (the experimental fp32x3 modes keep the plain passes: build time)
+    bool f32_done = false;
+#include "gemm_nt_epi32.hip.h"
+    if (f32_done) return;
+  }
   if constexpr (PP) {
     bool pp_done = true;
 #include "gemm_nt_pp_epi.hip.h"
