@@ -175,6 +175,10 @@ class ReferenceDepad:
         dev = evd_docs_adj.device
         self._meta = (query_lens, query_adj, evd_counts, doc_sources, query_sources, int(n_max), r)
         self._stream = stream if stream is not None else torch.cuda.current_stream(dev)
+        if stream is not None:
+            # the construction stream must see the tensors the caller produced on ITS stream (prefetch_reference did this itself;
+            # a direct ReferenceDepad(stream=side) user had no such ordering)
+            self._stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self._stream):
             ids = evd_doc_contents.contiguous()
             counts = evd_counts.to(device=dev, dtype=torch.int64).contiguous()
@@ -202,12 +206,14 @@ class ReferenceDepad:
         cur = torch.cuda.current_stream(self.d_ids.device)
         if cur != self._stream:
             cur.wait_event(self._event)
-            for t in (self.d_ids, self.bits, self.vals, self.dinv, self.n_nodes):
+            # everything allocated on the construction stream and touched from `cur` (the weighted fallback below relaunches on cur
+            # with counts / stats / ids as well)
+            for t in (self.d_ids, self.bits, self.vals, self.dinv, self.n_nodes) + tuple(x for x in self._keep if torch.is_tensor(x) and x.is_cuda):
                 t.record_stream(cur)
         e_conts = self.d_ids[:b1]
         if weighted:
             # some graph is not D^-1/2 A D^-1/2 of its own pattern (never from convert_text, but legal input): the whole batch
-            # takes the weighted mode, whose dense values the first launch wrote for the offending graphs only
+            # takes the weighted mode; the second launch rewrites every graph's dense values
             from ._lib import call
             call("gh_ref_depad", *self._args, 1, cur.cuda_stream)
             adj = ops.PackedAdj(self.bits[:b1], None, self.vals[:b1], None, int(b1), r)

@@ -81,7 +81,11 @@ static int make_dims(const gh_get_model* Mo, const gh_get_batch* Ba, Dims& d) {
   }
   static int att16_on = -1;
   if (att16_on < 0) att16_on = measure_env("GH_ATT16", 1);
-  d.att16 = d.bf && gemm_mode() == 1 && Mo->att_word_w1_16 && Mo->att_word_w1t_16 && att16_on;
+  // att16 = "no fp32 copy of the second cell's output exists": it must imply every condition of att_fwd_impl's / att_bwd_impl's own
+  // use16 predicate (gemm_ops.hip: bf16 gemm mode, >= 8192 rows, right / left / hidden widths multiples of 8) -- restated here in
+  // full rather than relied upon by construction (d.bf already holds Mr >= 8192 and H % 8 == 0; the word attention's right and
+  // left widths and its hidden width are all H)
+  d.att16 = d.bf && gemm_mode() == 1 && Mo->att_word_w1_16 && Mo->att_word_w1t_16 && att16_on && d.Mr >= 8192 && d.H % 8 == 0;
   return 0;
 }
 
@@ -466,6 +470,7 @@ extern "C" int gh_get_forward(const gh_get_model* Mo, const gh_get_batch* Ba, fl
     GH_TRY(gh_scorer_gsl(Ba->d_bits, Ba->d_dinv, Ba->d_vals, goff, (d.compact && Ba->collapsed) ? 1 : 0, nullptr, A + f.score_x, Mo->scorer_w,
                          Mo->scorer_gate, d.B1, d.R, H, Ba->k_keep, O + f.score, keep, 0.f, 0, (void*)s));
   } else if (d.bf) {        // wide hidden layer, bf16 storage: every column block of the last epilogue reduces its share of the projection
+    GH_REQUIRE((H + 127) / 128 <= 8, "get_forward: hidden width %d needs more than the 8 scorer-partial slots", H);      // (before anything is written)
     int parts = 1;          // into a partial of its own; the scorer kernel adds them in block order (no fp32 copy of the cell output at all)
     GH_TRY(cell_fwd(Mo->cell1, c16_1, f.c1, A, Ba->d_bits, Ba->d_dinv, Ba->d_vals, nullptr, goff, d.Mr, d.M1, table1, ids1, d.B1, d.R, d.D, H,
                     Ba->drop_gnn, Ba->seed_cell1, Mo->scorer_w, A + f.score_x, Ba->drop_gnn, Ba->seed_scorer, s, 0, &parts));

@@ -361,6 +361,19 @@ class _ArenaPool:
 
     def __init__(self):
         self.free = {}          # device index -> list of tensors
+        self.side = {}          # device index -> the side stream that may still read / write a pooled buffer
+
+    def note_side(self, dev, side):
+        if side is not None:
+            dev = torch.device(dev)
+            self.side[(dev.type, dev.index if dev.index is not None else torch.cuda.current_device())] = side
+
+    def _release(self, t: torch.Tensor):
+        """A buffer leaves the pool for good (superseded, evicted, cleared): it goes back to the caching allocator, which may hand it
+        to another stream -- tell the allocator about the side stream's use first (pooled buffers skip record_stream while pooled)."""
+        s_ = self.side.get((t.device.type, t.device.index))
+        if s_ is not None:
+            t.record_stream(s_)
 
     def _list(self, dev):
         dev = torch.device(dev)
@@ -376,6 +389,9 @@ class _ArenaPool:
         if best is not None:
             return lst.pop(best)
         size = _arena_floats(n)
+        for t in lst:
+            if size / self.SLACK <= t.numel() < size:
+                self._release(t)
         lst[:] = [t for t in lst if not (size / self.SLACK <= t.numel() < size)]
         return torch.empty(size, device=dev, dtype=torch.float32)
 
@@ -383,9 +399,14 @@ class _ArenaPool:
         lst = self._list(t.device)
         lst.append(t)
         while len(lst) > self.MAX_FREE:
-            lst.pop(min(range(len(lst)), key=lambda i: lst[i].numel()))
+            self._release(lst.pop(min(range(len(lst)), key=lambda i: lst[i].numel())))
 
     def clear(self):
+        """Hand every pooled buffer back to torch's caching allocator (callers that need the memory: `model_pool(model).clear()`,
+        then torch.cuda.empty_cache())."""
+        for lst in self.free.values():
+            for t in lst:
+                self._release(t)
         self.free.clear()
 
 
@@ -418,6 +439,8 @@ class _GetFused(torch.autograd.Function):
         if side is not None:
             if pool is None:
                 arena.record_stream(side)      # (pooled arenas never go back to the allocator while work is in flight)
+            else:
+                pool.note_side(dev, side)      # (... and tell the allocator about the side stream when they finally do: _ArenaPool._release)
             obs.record_stream(side)
         _lib.call("gh_get_forward", ctypes.addressof(M), ctypes.addressof(prep.struct), arena.data_ptr(), obs.data_ptr(), main, side_raw)
         B, b1, R = prep.b, prep.b1, prep.r
@@ -473,7 +496,17 @@ class _GetFused(torch.autograd.Function):
             _lib.call("gh_get_backward", *args, 1, main, side_raw)
             if side is not None:
                 ops._side_pending.add(dev.index if dev.index is not None else torch.cuda.current_device())
-            hook()
+            try:
+                hook()
+            except BaseException:
+                # phase 1 returned with the side stream NOT joined: before the arena / scratch can go anywhere, order the caller's
+                # stream behind it (the graph is about to be dropped with work still in flight on both streams)
+                if side is not None:
+                    torch.cuda.current_stream(dev).wait_stream(side)
+                    for t in (arena, work):
+                        t.record_stream(side)
+                ctx.arena = None
+                raise
             _lib.call("gh_get_backward", *args, 2, main, side_raw)
         ctx.arena = None                  # (a second backward on this graph raises above)
         if pool is not None:              # both streams are joined at the end of gh_get_backward: later launches are ordered behind it
@@ -482,6 +515,12 @@ class _GetFused(torch.autograd.Function):
         if direct:
             return (None, None, None) + (None,) * len(ctx.anchor_ids)
         return (None, None, None) + tuple(views.get(i) for i in ctx.anchor_ids)
+
+
+def model_pool(model) -> _ArenaPool:
+    """The persistent arena pool of `model` (public: `get_amd.fused.model_pool(model).clear()` returns its multi-GB buffers to torch's
+    caching allocator -- they are invisible to torch.cuda.empty_cache() while pooled; a no-grad forward clears them as well)."""
+    return _binding(model).pool
 
 
 def eligible(model, query, kargs) -> bool:
@@ -561,7 +600,9 @@ class _CrossEntropy(torch.autograd.Function):
     def backward(ctx, g):
         (out,) = ctx.saved_tensors
         if g.data_ptr() == unit_seed(g.device).data_ptr():      # backward(loss) below: the upstream gradient IS the constant 1
-            return out[1:].view(ctx.shape), None
+            # (a fresh tensor, not a view of the saved one: autograd may accumulate into a gradient it solely owns -- phi feeding a
+            #  second loss term -- and retain_graph / a second backward must find `out` unchanged; the copy is 4 bytes x B x C)
+            return out[1:].view(ctx.shape).clone(), None
         return out[1:].view(ctx.shape) * g, None          # (one scale launch; g is the scalar upstream gradient)
 
 
@@ -580,7 +621,11 @@ def unit_seed(device) -> torch.Tensor:
 def backward(loss: torch.Tensor) -> None:
     """`loss.backward()` for a loss made by `cross_entropy`, without the two scalar launches autograd adds at the root (a fill for
     ones_like(loss), a multiply of the saved logit gradient by it -- 11 us + a dispatch gap per step on MI355X): the root gradient
-    is a cached constant 1, which the loss's backward recognises by its address.  Any other loss takes the plain path."""
+    is a cached constant 1, which the loss's backward recognises by its address.  Any other loss (not a 0-d fp32 tensor: a
+    grad_tensors mismatch otherwise) takes the plain path."""
+    if loss.dim() != 0 or loss.dtype != torch.float32 or not loss.is_cuda:
+        loss.backward()
+        return
     torch.autograd.backward(loss, grad_tensors=[unit_seed(loss.device)])
 
 

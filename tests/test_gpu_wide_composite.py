@@ -219,3 +219,28 @@ def test_grad_mode_observables_release_the_arena_when_detached():
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() - base <= pooled + (8 << 20), "the second step allocated new arenas instead of reusing the pool"
     assert len(kept) == 3
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_h1024_widest_eligible_hidden_size_composite_vs_per_module(mode, monkeypatch):
+    """The composite path's eligibility reaches h <= 1024 (ABI 9); the suite otherwise covers h = 300 and h = 768 only.
+    h = 1024 (four 256-wide column blocks: four scorer / head-score partials per row), a batch of >= 8192 real node rows: composite
+    against the per-module path, same bounds as at h = 768."""
+    from bench import build_workload
+    from get_amd.synth import SynthConfig
+    cfg = SynthConfig(batch=6, n_evd=30, emb_dim=1024, hidden=1024, word_heads=8, evd_heads=2, window=5, gsl_rate=0.8,
+                      vocab=900, n_article_src=40, n_claim_src=10)
+    wl = build_workload(seed=20240306, device=DEV, cfg=cfg, compact=True)
+    assert wl["m_real"] >= 8192
+    a = _run(wl, False, mode, monkeypatch)
+    b = _run(wl, True, mode, monkeypatch)
+    if mode == "fp32":
+        assert torch.equal(a["keep"], b["keep"])
+        tol_v, tol_g = 2e-6, 2e-5
+    else:
+        assert int((a["keep"] != b["keep"]).any(1).sum()) <= 0.05 * a["keep"].shape[0]
+        tol_v, tol_g = 2e-3, 2e-2
+    for k in ("phi", "ww", "ew", "score"):
+        assert float((a[k] - b[k]).abs().max()) <= tol_v * max(1.0, float(a[k].abs().max())), k
+    for k, g in a["grads"].items():
+        assert float((g - b["grads"][k]).abs().max()) <= tol_g * max(float(g.abs().max()), 1e-8), k
