@@ -858,6 +858,25 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
       lslab = (((hv + ns - 1) / ns) + 1) & ~1;
       lgrid = dim3(n, (hv + lslab - 1) / lslab);
     }
+    // Rows that are whole 128-byte lines (h = 768: 1536 B in bf16, 3072 B in fp32): slabs of whole lines.  The even split above
+    // gives 40 bf16 columns = 320 B per row and slab -- 2.5 lines, every slab boundary inside a line that two workgroups fetch
+    // (configs[4] bf16, A/B on one box: five slabs of 40 columns 0.675 ms of aggregation per step, four slabs of 48 columns =
+    // 3 lines 0.607 ms; 64 columns = 51 KB of LDS per workgroup 0.91 ms).  Up to 40 KB of slab image per workgroup.
+    {
+      const int col_b = bf16 ? 8 : 16, per_line = 128 / col_b;            // float4 columns per 128-byte line
+      static int aligned = -1;
+      if (aligned < 0) aligned = measure_env("GH_SPMM_LINE_SLABS", 1);
+      if (aligned && cap_env <= 0 && ((size_t)h * (bf16 ? 2 : 4)) % 128 == 0 && hv % per_line == 0) {
+        int best = 0;
+        for (int c = per_line; c <= hv && (size_t)r * c * col_b <= 40 * 1024; c += per_line) best = c;
+        if (best >= 2 * per_line) {
+          const int ns = (hv + best - 1) / best;
+          int even = (((hv + ns - 1) / ns) + per_line - 1) / per_line * per_line;      // as even as whole lines allow
+          lslab = even;
+          lgrid = dim3(n, (hv + lslab - 1) / lslab);
+        }
+      }
+    }
     const size_t llds = (size_t)r * lslab * (bf16 ? 8 : 16) + (size_t)cap * 8 + (size_t)(r + 1) * 4 + (size_t)r * 4 + 4 + (size_t)r * 8;   // + item table
     const void* fn;
     const int lv = variant > 5 ? 5 : variant;
