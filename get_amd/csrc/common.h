@@ -99,7 +99,7 @@ int launch_tiny_linear_fwd(const float* x, const float* w, const float* bias, fl
 // head backward in one launch (misc_ops.hip head_bwd_kernel): d_y0 = g_phi w1; [dx0 | dx1] = d_y0 w0 (w0 as stored, [H][E]); dw1 / db1 +=
 int launch_head_bwd(const float* g_phi, const float* y0, const float* w1, const float* w0, int B, int H, int C, int Xl, int E,
                     float* d_y0, float* dw1, float* db1, float* dx0, int dx0_accumulate, float* dx1, hipStream_t s);
-size_t head_bwd_lds(int B, int H, int C, int E);      // 0: the sizes do not fit its LDS staging
+size_t head_bwd_lds(int B, int H, int C, int E, const float* w0);      // 0: the sizes do not fit its LDS staging
 int launch_tiny_linear_bwd(const float* x, const float* w, const float* g, float* dx, float* dw, float* db, int m, int k, int n,
                            hipStream_t s);
 int launch_att_softmax_fwd(float* e, const float* mask, const float* right, const int32_t* goff, int m_real,

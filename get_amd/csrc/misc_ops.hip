@@ -1411,6 +1411,11 @@ tiny_linear_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
 // 33 us of launch latency for 0.07 GFLOP.  One workgroup per 64 columns j: wave kg takes the k range [kg H/4, (kg+1) H/4), a lane one
 // column, 32 claims at a time in registers; w0 is read once (coalesced along j), d_y0 comes from LDS as wave-uniform 16-byte reads.
 // The weight gradients of out0 (d_y0^T [left | att]) stay with the side stream's TN launch, which reads the d_y0 this kernel writes.
+// CPT = 4 (round 6): a lane owns FOUR consecutive columns (16-byte loads of w0: 256 contiguous bytes per k row and workgroup instead of
+// 64).  At h = 768 the head's input is 13 K wide: 832 workgroups of 16 columns each fetched w0 (41 MB) in 64-byte pieces with two
+// dependent round trips per thread -- 135 us on the critical path of the configs[4] step; 208 workgroups of 64 columns stream it.
+// Used when the width gives >= 192 such workgroups; narrower heads (h = 300: 3556 columns) keep one column per lane.
+template <int CPT>
 __global__ void __launch_bounds__(256)
 head_bwd_kernel(const float* __restrict__ g_phi, const float* __restrict__ y0, const float* __restrict__ w1, const float* __restrict__ w0,
                 int B, int H, int C, int Xl, int E, float* __restrict__ d_y0, float* __restrict__ dw1, float* __restrict__ db1,
@@ -1420,9 +1425,9 @@ head_bwd_kernel(const float* __restrict__ g_phi, const float* __restrict__ y0, c
   float* w1s = dy + dy_floats;                               // [C][H]
   float* gs = w1s + (size_t)C * H;                           // [B][C]
   float* ys = gs + (size_t)B * C;                            // [nk][B]: y0 columns of this workgroup's share of dw1
-  const int tid = threadIdx.x, col = tid & 15, kg = tid >> 4;       // 16 columns x 16 k ranges per workgroup
-  const int j = blockIdx.x * 16 + col;
-  const int jc = min(j, E - 1);
+  const int tid = threadIdx.x, col = tid & 15, kg = tid >> 4;       // 16 column groups x 16 k ranges per workgroup
+  const int j = (blockIdx.x * 16 + col) * CPT;
+  const int jc = min(j, E - CPT);
   const int H4 = H / 4;
   const int kq0 = (kg * H4) / 16, kq1 = ((kg + 1) * H4) / 16;     // this thread's range of float4 k-groups
   // everything small is staged once with independent loads (a per-element walk over g_phi / w1 / y0 in global memory put one
@@ -1456,52 +1461,71 @@ head_bwd_kernel(const float* __restrict__ g_phi, const float* __restrict__ y0, c
       if (blockIdx.x == 0 && b < nb) d_y0[(size_t)(b0 + b) * H + k] = v;
     }
     __syncthreads();
-    float acc[32];
+    float acc[32][CPT];
 #pragma unroll
-    for (int b = 0; b < 32; ++b) acc[b] = 0.f;
-    // eight k-groups (32 rows of w0) requested before any of them is used: one memory round trip per thread for H <= 512
-    for (int kq = kq0; kq < kq1; kq += 8) {
-      float wv[8][4];
+    for (int b = 0; b < 32; ++b)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int c = 0; c < CPT; ++c) acc[b][c] = 0.f;
+    // several k-groups (4 rows of w0 each) requested before any of them is used: one memory round trip per thread for H <= 512
+    constexpr int U = CPT == 1 ? 8 : 4;
+    for (int kq = kq0; kq < kq1; kq += U) {
+      float wv[U][4][CPT];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
         const int k = 4 * min(kq + u, kq1 - 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wv[u][i] = w0[(size_t)(k + i) * E + jc];
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (CPT == 4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(w0 + (size_t)(k + i) * E + jc);
+            wv[u][i][0] = t4.x; wv[u][i][1] = t4.y; wv[u][i][2] = t4.z; wv[u][i][3] = t4.w;
+          } else {
+            wv[u][i][0] = w0[(size_t)(k + i) * E + jc];
+          }
+        }
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < U; ++u) {
         if (kq + u >= kq1) break;
         const int k = 4 * (kq + u);
 #pragma unroll
         for (int b = 0; b < 32; ++b) {
           const float4 d4 = *reinterpret_cast<const float4*>(dy + b * H + k);
-          acc[b] += d4.x * wv[u][0] + d4.y * wv[u][1] + d4.z * wv[u][2] + d4.w * wv[u][3];
+#pragma unroll
+          for (int c = 0; c < CPT; ++c)
+            acc[b][c] += d4.x * wv[u][0][c] + d4.y * wv[u][1][c] + d4.z * wv[u][2][c] + d4.w * wv[u][3][c];
         }
       }
     }
     __syncthreads();                                         // every wave is done with dy: it becomes the partial buffer
-    float* red = dy;                                         // [16 k ranges][32][16 columns + 1]
+    float* red = dy;                                         // [16 k ranges][32][16 column groups + 1], one of a lane's CPT columns at a time
 #pragma unroll
-    for (int b = 0; b < 32; ++b) red[(kg * 32 + b) * 17 + col] = acc[b];
-    __syncthreads();
-    for (int i = tid; i < 32 * 16; i += 256) {
-      const int b = i >> 4, l = i & 15, jj = blockIdx.x * 16 + l;
-      if (b >= nb || jj >= E) continue;
-      float v = 0.f;
+    for (int c = 0; c < CPT; ++c) {
+      if (c > 0) __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v += red[(r * 32 + b) * 17 + l];
-      if (jj < Xl) {
-        if (dx0) { float* o = dx0 + (size_t)(b0 + b) * Xl + jj; *o = dx0_accumulate ? *o + v : v; }
-      } else if (dx1) {
-        dx1[(size_t)(b0 + b) * (E - Xl) + (jj - Xl)] = v;
+      for (int b = 0; b < 32; ++b) red[(kg * 32 + b) * 17 + col] = acc[b][c];
+      __syncthreads();
+      for (int i = tid; i < 32 * 16; i += 256) {
+        const int b = i >> 4, l = i & 15, jj = (blockIdx.x * 16 + l) * CPT + c;
+        if (b >= nb || jj >= E) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v += red[(r * 32 + b) * 17 + l];
+        if (jj < Xl) {
+          if (dx0) { float* o = dx0 + (size_t)(b0 + b) * Xl + jj; *o = dx0_accumulate ? *o + v : v; }
+        } else if (dx1) {
+          dx1[(size_t)(b0 + b) * (E - Xl) + (jj - Xl)] = v;
+        }
       }
     }
   }
 }
 
 // LDS bytes of head_bwd_kernel for these sizes (0: does not fit -- the caller keeps the three-launch path)
-size_t head_bwd_lds(int B, int H, int C, int E) {
-  const int G = (E + 15) / 16;
+static bool head_bwd_wide(int E, const float* w0) {      // four columns per lane: 16-byte rows and enough workgroups to fill the chip
+  return E % 4 == 0 && (E + 63) / 64 >= 192 && (reinterpret_cast<uintptr_t>(w0) & 15) == 0;
+}
+size_t head_bwd_lds(int B, int H, int C, int E, const float* w0) {
+  const int G = head_bwd_wide(E, w0) ? (E + 63) / 64 : (E + 15) / 16;
   const size_t dyf = (size_t)32 * H > (size_t)16 * 32 * 17 ? (size_t)32 * H : (size_t)16 * 32 * 17;
   const size_t fl = dyf + (size_t)C * H + (size_t)B * C + (size_t)((H + G - 1) / G) * B;
   return fl * 4 <= 160 * 1024 ? fl * 4 : 0;
@@ -1511,15 +1535,23 @@ int launch_head_bwd(const float* g_phi, const float* y0, const float* w1, const 
                     float* d_y0, float* dw1, float* db1, float* dx0, int dx0_accumulate, float* dx1, hipStream_t s) {
   GH_REQUIRE(B > 0 && H > 0 && H % 4 == 0, "head_bwd: hidden width %d must be a multiple of 4", H);
   GH_REQUIRE(C >= 1 && C <= 8 && Xl >= 0 && Xl <= E && d_y0, "head_bwd: bad sizes (C=%d Xl=%d E=%d)", C, Xl, E);
-  const size_t lds = head_bwd_lds(B, H, C, E);
+  const size_t lds = head_bwd_lds(B, H, C, E, w0);
   GH_REQUIRE(lds > 0, "head_bwd: B=%d, H=%d do not fit the kernel's LDS staging", B, H);
   if (lds > 64 * 1024) {
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)head_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)head_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
   }
   const int dyf = 32 * H > 16 * 32 * 17 ? 32 * H : 16 * 32 * 17;
-  hipLaunchKernelGGL(head_bwd_kernel, dim3((E + 15) / 16), dim3(256), lds, s, g_phi, y0, w1, w0, B, H, C, Xl, E, d_y0, dw1, db1, dx0,
-                     dx0_accumulate, dx1, dyf);
+  if (head_bwd_wide(E, w0))
+    hipLaunchKernelGGL(head_bwd_kernel<4>, dim3((E + 63) / 64), dim3(256), lds, s, g_phi, y0, w1, w0, B, H, C, Xl, E, d_y0, dw1, db1, dx0,
+                       dx0_accumulate, dx1, dyf);
+  else
+    hipLaunchKernelGGL(head_bwd_kernel<1>, dim3((E + 15) / 16), dim3(256), lds, s, g_phi, y0, w1, w0, B, H, C, Xl, E, d_y0, dw1, db1, dx0,
+                       dx0_accumulate, dx1, dyf);
   GH_LAUNCH_CHECK();
   return 0;
 }

@@ -538,7 +538,7 @@ extern "C" int gh_get_backward(const gh_get_model* Mo, const gh_get_batch* Ba, c
     // ---- head
     static int head_fused = -1;
     if (head_fused < 0) head_fused = measure_env("GH_HEAD_BWD", 1);
-    if (head_fused && d.C <= 8 && H % 4 == 0 && Mo->out0_w && Mo->out1_w && head_bwd_lds(d.B, H, d.C, d.E) > 0) {
+    if (head_fused && d.C <= 8 && H % 4 == 0 && Mo->out0_w && Mo->out1_w && head_bwd_lds(d.B, H, d.C, d.E, Mo->out0_w) > 0) {
       // both layers' input gradients and the second layer's weight gradients in one launch (head_bwd_kernel)
       GH_TRY(launch_head_bwd(g_phi, A + f.y0, Mo->out1_w, Mo->out0_w, d.B, H, d.C, d.Xl, d.E, Wb + w.d_y0, Mo->d_out1_w, Mo->d_out1_b,
                              Wb + w.d_new_left, 0, Wb + w.d_att_e, s));
