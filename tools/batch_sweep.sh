@@ -1,8 +1,8 @@
 #!/bin/bash
-# configs[3]'s global batch on ONE GPU (the N = 1 point of the strong-scaling curve) and a per-GPU batch sweep -> gpurun_out/r05/batch_sweep.txt
+# configs[3]'s global batch on ONE GPU (the N = 1 point of the strong-scaling curve) and a per-GPU batch sweep -> gpurun_out/r06/batch_sweep.txt
 # (12 warm-up steps: at these sizes the first steps of a fresh process include allocator growth)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r05; mkdir -p $O
+O=gpurun_out/r06; mkdir -p $O
 [ -f tools/_commit.txt ] && echo "build $(cat tools/_commit.txt)" > $O/batch_sweep.txt
 for args in "--batch 32" "--batch 32 --evd-dist snopes" "--batch 64" "--batch 128" "--global-batch 256" "--batch 64 --evd-dist snopes" "--batch 256 --evd-dist snopes" "--global-batch 256 --evd-dist snopes"; do
   n=$(echo $args | tr -d ' -' )
