@@ -13,7 +13,7 @@ f=$(find /tmp/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $
 for c in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | tr ' ' '_' | cut -c1-24)
   d=/tmp/pmc_$n; rm -rf $d
-  ( cd /tmp && timeout 600 rocprofv3 --pmc $c --output-format csv -d $d -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-series --no-side-modes --no-other-configs > $GRAFT_REPO_ROOT/$O/pmc_$n.log 2>&1 )
+  ( cd /tmp && timeout 600 rocprofv3 --pmc $c --output-format csv -d $d -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-series --no-side-modes --no-other-configs --no-strong > $GRAFT_REPO_ROOT/$O/pmc_$n.log 2>&1 )
   python tools/pmc_sum.py $d > $O/pmc_$n.txt 2>&1
 done
 python tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "$(cat $O/commit.txt 2>/dev/null)" > $O/pmc_traffic.json 2>> $O/bench_err.log
