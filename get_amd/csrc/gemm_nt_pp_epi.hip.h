@@ -120,7 +120,8 @@
     };
     auto st = [&](const rsrc_t rs, unsigned vo, const float4 a, const float4 b) __attribute__((always_inline)) {
       // nontemporal (aux = nt): an epilogue stream is ~100 MB that the next launch reads from its start; its tail in L2 only evicts
-      // the weight panels the K loops re-read (A/B on configs[4] bf16, one box: 146.5 -> 148.0 K pairs/s, gemm_big 3.12 -> 3.10 ms)
+      // the weight panels the K loops re-read (A/B on configs[4] bf16, one box: 146.5 -> 148.0 K pairs/s, gemm_big 3.12 -> 3.10 ms;
+      // nontemporal only for the backward-only streams r / h~, default policy for z, r xp, out and the gate heads: 3.06 -> 3.11 ms)
       __builtin_amdgcn_raw_buffer_store_b128(pp_pack(a, b), rs, vo, 0, 2);
     };
     auto compute = [&](auto PT) __attribute__((always_inline)) {

@@ -152,7 +152,12 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
       launched = true;
     } else return hipErrorInvalidValue;
   } else if (MI >= 4) {
-    return hipErrorInvalidValue;          // the 128 x 256 tile exists for the bf16 storage pipeline only
+    return hipErrorInvalidValue;          // the 128 x 256 / 256 x 256 tiles exist for the bf16 storage pipeline only
+  }
+  // (the rest of this function only exists for the MI = 2 configurations: as plain run-time branches the fp32 / fp32x3 / generic
+  //  launches below were instantiated for the bf16-only tile shapes as well -- nine never-launched kernels, half of this file's build time)
+  if constexpr (MI == 2) {
+  if (launched) {
   } else if (fast && !tn) {
     // gh_set_gemm_mode(1): bf16 operand rounding in the activation-sized (64x320 tile) launches only
     if (g_gemm_mode == 1 && WM == 2 && WN == 2 && NI == 10) {
@@ -188,6 +193,8 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
     if (tn) hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, true>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
     else hipLaunchKernelGGL((gemm_kernel<WM, WN, NI, false>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
   }
+  }      // MI == 2
+  if (!launched && MI != 2) return hipErrorInvalidValue;
   prof_end(tag, flops, s);
   return hipGetLastError();
 }
