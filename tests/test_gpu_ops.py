@@ -729,6 +729,50 @@ def test_bf16_storage_cell_tracks_fp32(bf16_mode, compact, drop_p):
         assert float((g16[k] - g32[k]).abs().max()) <= 5e-2 * float(g32[k].abs().max()) + 1e-6, k
 
 
+@pytest.mark.parametrize("h,din,rows_kind", [(256, 256, "padded"), (512, 256, "compact"), (256, 128, "compact")])
+def test_bf16_cell_on_the_256_tile_tracks_fp32(bf16_mode, h, din, rows_kind):
+    """The 256 x 256 x 64 ping-pong tile (gemm_nt_pp.hip.h; default for bf16-storage launches of >= 32 768 rows) at widths other than
+    the bench's 768: one and two column blocks, a projection that is (256) and is not (128) tile-eligible, padded and node-compact
+    rows, M not a multiple of 256, dropout on -- gh_ggnn_cell_fwd/bwd_bf16 against the fp32 cell on the same inputs and mask.
+    Same stated tolerance as test_bf16_storage_cell_tracks_fp32: outputs 3e-2 absolute, gradients 5e-2 of their largest entry."""
+    from get_amd import _lib, modules, ops
+    from get_amd.synth import make_tokens
+    rng = np.random.default_rng(1000 + h + din)
+    compact = rows_kind == "compact"
+    n, r = (760 if compact else 333), 100
+    toks, lens = make_tokens(rng, n, r, 5000, r // 2, r)
+    padj, node_ids, nn = ops.graph_build(T(toks), T(lens), 3)
+    plan = ops.RaggedPlan(nn, node_ids, int(nn.sum().item())) if compact else None
+    rows = plan.m_real if compact else n * r
+    assert rows >= 32768 and rows % 256 != 0
+    x = rng.standard_normal((n, r, din)).astype(np.float32) * 0.5
+    gw = rng.standard_normal((n, r, h)).astype(np.float32)
+    prm = cases.cell_params(rng, din, h)
+    mod = modules.GGNN(din, h, dropout=0.0)
+    _load_cell(mod, prm)
+    mod = mod.to(DEV)
+    res = {}
+    for mode in ("fp32", "bf16"):
+        _lib.set_gemm_mode(mode)
+        for p_ in mod.parameters():
+            p_.grad = None
+        if compact:
+            xc = plan.from_padded(T(x))[:plan.m_real].clone().requires_grad_(True)
+            out = ops.ggnn_cell(padj, xc, None, mod._params(), 0.2, 777, plan=plan, rows=plan.m_real)
+            (out * plan.from_padded(T(gw))[:plan.m_real]).sum().backward()
+        else:
+            xc = T(x, grad=True)
+            out = ops.ggnn_cell(padj, xc, None, mod._params(), 0.2, 777)
+            (out * T(gw)).sum().backward()
+        res[mode] = (out.detach().clone(), xc.grad.clone(), {k: q.grad.clone() for k, q in mod.named_parameters()})
+    o32, dx32, g32 = res["fp32"]
+    o16, dx16, g16 = res["bf16"]
+    assert 1e-6 < float((o16 - o32).abs().max()) <= 3e-2
+    assert float((dx16 - dx32).abs().max()) <= 5e-2 * float(dx32.abs().max())
+    for k in g32:
+        assert float((g16[k] - g32[k]).abs().max()) <= 5e-2 * float(g32[k].abs().max()) + 1e-6, k
+
+
 def test_evd_assemble_bwd_writes_every_row_of_d_avg():
     """gh_evd_assemble_bwd needs no cleared d_avg: the rows of real (claim, slot) pairs receive their gradient, the rows of a claim's
     evidences beyond its n_max-th (no slot in the padded tensor) receive zeros -- checked on a NaN-filled buffer with one claim over
