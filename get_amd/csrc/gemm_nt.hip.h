@@ -62,7 +62,7 @@ __device__ __forceinline__ unsigned nt_pack_bf16(float a, float b) {
 template <int WM, int WN, int NI, int MI = 2, int MODE = 0>
 // (second argument = waves per SIMD the register budget must allow: 256-thread workgroups put one wave on every SIMD, so it is also
 //  the workgroups per CU; the 512-thread 128 x 256 tile puts two, and wants two workgroups = four waves per SIMD)
-__global__ void __launch_bounds__(WM * WN * 64, (MI == 8) ? 2 : (MI == 4 && NI == 4 && WN == 4) ? 4 : (MI == 4 && NI == 4) ? 3 : (MI == 4 || MODE == 3 || MODE == 4) ? 2 : (WM == 2 && WN == 2 && NI == 5 && MODE == 0) ? 4 : 3)
+__global__ void __launch_bounds__(WM * WN * 64, (MI == 8) ? 2 : (WM == 4 && WN == 2 && NI == 5 && MI == 2) ? 4 : (MI == 4 && NI == 4 && WN == 4) ? 4 : (MI == 4 && NI == 4) ? 3 : (MI == 4 || MODE == 3 || MODE == 4) ? 2 : (WM == 2 && WN == 2 && NI == 5 && MODE == 0) ? 4 : 3)
 gemm_nt_kernel(const Launch L_byval) {
   (void)L_byval;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -75,6 +75,9 @@ gemm_nt_kernel(const Launch L_byval) {
   // below (PP) -- the two wave rows run staggered by one barrier interval, so that each SIMD always has one wave in its
   // MFMA section and one reading fragments / issuing LDS-DMA.
   constexpr bool PP = MI == 8;
+  constexpr bool PP32_ = MODE == 0 && WM == 4 && WN == 2 && NI == 5 && MI == 2;
+  // <4, 2, 5, 2, 0>: the exact-fp32 128 x 160 x 16 tile on 8 waves, two workgroups per CU, ping-pong K loop (gemm_nt_pp32.hip.h)
+  constexpr bool PP32 = MODE == 0 && WM == 4 && WN == 2 && NI == 5 && MI == 2;
   constexpr int BM = 16 * MI * WM, BN = 16 * NI * WN, BK = PP ? 64 : 4 * KQ;
   // MODE 4 ("fp32x3" with PRE-SPLIT weights): B points at the weight's split image (split3_kernel: per row and group
   // of four k the three bf16 pieces hi[4] | mid[4] | lo[4], 24 bytes; row pitch a multiple of 16 bytes, passed as ldb in
@@ -96,7 +99,7 @@ gemm_nt_kernel(const Launch L_byval) {
   // VALU work of the in-register splits, not by DMA latency)
   constexpr int NST = (MI == 4 && WM == 4) ? 4 : (MI == 4) ? 3 : 2;      // (256 x 256 / 8 waves: one workgroup per CU, four stages)
   constexpr bool DYN_LDS = NST != 2 || X3P || PP;                        // more than 64 KB: dynamic allocation
-  constexpr int SMEM = PP ? 131072 : (NST * STAGE > EP_BYTES ? NST * STAGE : EP_BYTES);
+  constexpr int SMEM = PP ? 131072 : PP32_ ? (3 * STAGE + 1024 > EP_BYTES ? 3 * STAGE + 1024 : EP_BYTES) : (NST * STAGE > EP_BYTES ? NST * STAGE : EP_BYTES);
   static_assert(!PP || (MODE == 2 && WM == 2 && WN == 4 && NI == 4 && EP_BYTES <= 131072), "ping-pong loop: 256 x 256 bf16 tile on 2 x 4 waves");
   constexpr unsigned OOB = 0x80000000u;
   constexpr int NH = NI / 2;                                       // B fragment batches: X = tiles [0,NH), Y = [NH,NI)
@@ -548,6 +551,8 @@ gemm_nt_kernel(const Launch L_byval) {
   // (any other count -- narrow problems, odd column blocks -- computes every tile: the B rows beyond N are zeros in LDS)
   if constexpr (PP) {
 #include "gemm_nt_pp.hip.h"
+  } else if constexpr (PP32) {
+#include "gemm_nt_pp32.hip.h"
   } else {
     if (nvX == NH && nvY == NI - NH - 1) run(std::integral_constant<int, NH>{}, std::integral_constant<int, NI - NH - 1>{});
     else run(std::integral_constant<int, NH>{}, std::integral_constant<int, NI - NH>{});

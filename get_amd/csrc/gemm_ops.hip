@@ -168,6 +168,9 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
       // weights) and the claim cell are 0.5 ms of fp32 MFMA time per step
       if constexpr (WM == 1 && WN == 4 && NI == 5)
         hipLaunchKernelGGL((gemm_nt_kernel<1, 4, 5, 2, true>), dim3(grid), dim3(256), 0, s, L);
+    } else if constexpr (WM == 4) {      // the ping-pong fp32 tile exists in the exact mode only (Batch sets pp32 for g_gemm_mode == 0)
+      if (g_gemm_mode != 0) return hipErrorInvalidValue;
+      hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, NI, 2>), dim3(grid), dim3(WM * WN * 64), 0, s, L);
     } else if (g_gemm_mode == 2 || g_gemm_mode == 3) {      // fp32x3 (experimental): fp32 values and results, products from 3-way bf16 splits on the bf16 MFMA
       Launch L2;
       bool pre = false;
@@ -529,6 +532,11 @@ struct Batch {
   // the K loops: launches with stream-heavy epilogues gain, plain-store launches lose (prototype, tools/glds_proto.hip NHALF:
   // h-gate-like epilogue K = 300: 62.6 -> 68.2 TF, K = 600: 87.7 -> 90.5; plain store: 92.4 -> 88.7).  Chosen per call site.
   bool narrow = false;
+  // 128 x 160 fp32 tile, 8 waves, two workgroups per CU, ping-pong K loop (launch_cfg<4, 2, 5>; gemm_nt_pp32.hip.h).  TOOL BUILD ONLY
+  // (GH_PP32_ROWS): built in round 6 as the fp32 half of VERDICT r5 item 1 and measured SLOWER than the 64 x 320 / 64 x 160 tiles at three
+  // / four workgroups per CU: K loops alone 3.37 against 3.15 ms per step, whole launches 3.98 against 3.72 (two and three LDS buffers
+  // alike; a half-K-loop start stagger of each CU's second workgroup: no effect at any amount).  DESIGN 4.5.
+  bool pp32 = false;
   // EPI_ATT on rows wider than one column block (h = 768): every block applies tanh(. + u) to its columns and reduces ITS share
   // of the head scores W2 . t into a partial buffer of its own, e + block * e_block_stride (plain stores: the consumer,
   // att_softmax_fwd, adds the partials in block order -- deterministic).  0 = whole rows only.
@@ -574,6 +582,13 @@ struct Batch {
     // row tiles) get twice the workgroups on 1024 slots: 99.0 -> 102.0 K pairs/s on the Snopes-histogram step at B = 32
     const bool thin = rows_hint <= 24576;
     if (site > 0 && big && !tn_ && !wide && g_gemm_mode == 0 && narrow_mask != 0 && (((narrow_mask >> (site - 1)) & 1) || less_pad || thin)) { narrow = true; bn = 160; }
+    static int pp32_rows = -1;
+    if (pp32_rows < 0) pp32_rows = measure_env("GH_PP32_ROWS", 1 << 30);      // (tool build: row threshold of the fp32 ping-pong tile)
+    // (`narrow` stays set: the call sites' column-block logic -- two 160-wide blocks per 300-wide problem, the scorer's two partial dot
+    //  products -- is the 64 x 160 tile's; launches without a call-site id, e.g. the attention's t product with its head scores, keep the 64 x 320 tile)
+#ifdef GH_MEASURE
+    if (site > 0 && big && !tn_ && !wide && g_gemm_mode == 0 && rows_hint >= pp32_rows) { pp32 = true; narrow = true; bm = 128; bn = 160; }
+#endif
     // (round 5: thin launches on 32 x 160 tiles -- one 16-row MFMA tile per wave, 80 - 96 VGPRs, five or six workgroups per CU, twice
     //  the waves for grids that fill less than one round -- measured on the Snopes-count step: 109.4 K -> 108.2 - 109.4 K pairs/s
     //  at every site mask.  Removed.)
@@ -730,6 +745,9 @@ struct Batch {
   }
 
   hipError_t launch_any() {
+#ifdef GH_MEASURE      // (the fp32 ping-pong tile is a measured-and-dropped experiment, DESIGN 4.5: instantiated in the tool build only)
+    if (pp32 && !tn && L.ksplit == 1 && !L.p[0].elt) return launch_cfg<4, 2, 5>(L, tn, s);
+#endif
     if (narrow && !tn && L.ksplit == 1 && !L.p[0].elt) return launch_cfg<2, 2, 5>(L, tn, s);
     if (big && !tn && L.ksplit == 1 && !L.p[0].elt) {
       // Occupancy-aware tile choice.  The chip holds 768 workgroups of either configuration (3 per CU); a grid of 64-row
