@@ -111,7 +111,10 @@
   {
     const int units = (dbg_bits >> 8) & 0xff;      // (tool build: GH_DBG = units << 8; 64 cycles per unit and K tile)
     const int stag = units ? units : 10;
-    if ((int)blockIdx.x >= 256 && (int)blockIdx.x < 512 && stag < 200)
+    const int pat = (dbg_bits >> 16) & 3;          // which workgroups are "second on their CU": 0 = blocks [256, 512) (breadth-first dispatch),
+    const int b_ = (int)blockIdx.x;                //   1 = odd XCD-local index (depth-first), 2 = odd XCD-local index among the first 512, 3 = [512, 1024)
+    const bool second = pat == 0 ? (b_ >= 256 && b_ < 512) : pat == 1 ? ((b_ >> 3) & 1) != 0 : pat == 2 ? (b_ < 512 && ((b_ >> 3) & 1) != 0) : (b_ >= 512 && b_ < 1024);
+    if (second && stag < 200)
       for (int i = 0; i < T * stag; ++i) __builtin_amdgcn_s_sleep(1);      // 64 cycles each
   }
   if (upper) {
