@@ -157,7 +157,11 @@ nt256_kernel(const Params P) {
   // ---- prologue: tile 0 entirely, tile 1 except its second A half (phase 1 of tile 0 stages that one)
   stage(0, OPA, H0); stage(0, OPB, H0); stage(0, OPB, H1); stage(0, OPA, H1);
   stage(1, OPA, H0); stage(1, OPB, H0); stage(1, OPB, H1);
+#ifdef TWOPHASE
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#else
   asm volatile("s_waitcnt vmcnt(" VMW ")" ::: "memory");
+#endif
   asm volatile("s_barrier" ::: "memory");
   if (wr == 1) asm volatile("s_barrier" ::: "memory");      // the second wave row runs one barrier interval behind
   __builtin_amdgcn_sched_barrier(0);
@@ -168,6 +172,28 @@ nt256_kernel(const Params P) {
   /* phase 3 */ RD_A(B_, 1) stage(t + 2, OPB, H0); END_L_NOVM(); M_SECTION(1, 1);     \
   /* phase 4 */ stage(t + 2, OPB, H1); END_L_WAIT(); M_SECTION(1, 0);
 
+#ifdef TWOPHASE
+  // two phases per K tile: phase 1 reads A0 + B0 + B1 (16 fragment reads) and computes quadrants (0,0), (0,1); phase 2 reads A1 and
+  // computes (1,1), (1,0).  Slots: A0, B0, B1 are free after phase 1 (both wave rows), A1 after phase 2.  Stages per wave and phase: 4
+  // DMA instructions (two half-tiles): phase 1 of tile t stages A1(t+1) [free since (t-1, P2)] and ... see TILE2 below.
+#define M2_SECTION(RH_, C0_, C1_) do { if (PRIO) __builtin_amdgcn_s_setprio(1); QUAD(RH_, C0_) QUAD(RH_, C1_) if (PRIO) __builtin_amdgcn_s_setprio(0); \
+    __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+  // issue order per wave: (t,P1): A1(t+1); (t,P2): A0(t+2), B0(t+2), B1(t+2).  Needed: A0,B0,B1(t+1) at (t+1,P1): issued at (t-1,P2);
+  // wait at the end of (t,P2): younger = A1(t+1) [t,P1] + A0,B0,B1(t+2) [t,P2] = 8 instructions -> vmcnt(8).
+  // A1(t+1) needed at (t+1,P2): wait at the end of (t+1,P1): younger = A0,B0,B1(t+2), A1(t+2) = 8 -> vmcnt(8).
+#define WAIT8()  do { asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TILE2(B_)                                                                     \
+  /* phase 1 */ RD_B(B_, 0) RD_B(B_, 1) RD_A(B_, 0) stage(t + 1, OPA, H1); WAIT8(); M2_SECTION(0, 0, 1); \
+  /* phase 2 */ RD_A(B_, 1) stage(t + 2, OPA, H0); stage(t + 2, OPB, H0); stage(t + 2, OPB, H1); WAIT8(); M2_SECTION(1, 1, 0);
+  int t = 0;
+  for (; t + 1 < T; t += 2) {
+    TILE2(0)
+    ++t;
+    TILE2(1)
+    --t;
+  }
+  if (t < T) { TILE2(0) }
+#else
   int t = 0;
   for (; t + 1 < T; t += 2) {
     TILE(0)
@@ -176,6 +202,7 @@ nt256_kernel(const Params P) {
     --t;
   }
   if (t < T) { TILE(0) }
+#endif
   if (wr == 0) asm volatile("s_barrier" ::: "memory");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
