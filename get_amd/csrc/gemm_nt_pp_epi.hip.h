@@ -65,9 +65,15 @@
   };
 
   // ------------------------------------------------------------------ straight-line form: every stream bf16
-  auto pp_fast = [&](auto EPI, auto ACCF, auto GINF) __attribute__((always_inline)) {
+  auto pp_fast = [&](auto EPI, auto ACCF, auto GINF, auto SCF) __attribute__((always_inline)) {
     constexpr int E = decltype(EPI)::value;
     constexpr bool ACC = decltype(ACCF)::value, GIN = decltype(GINF)::value;
+    // SC (EPI_TANH_H with the GSL scorer's projection, one partial per column block): the block's share of the dot product
+    // out[row] . w2 is reduced IN REGISTERS -- a thread's eight columns against its eight scorer weights (the same eight for both of
+    // its items and every pass: col = 8 (tid & 31)), then a butterfly over the 32 lanes that hold the row -- instead of writing the
+    // finished rows back to LDS and reducing them on the MFMA between two more barriers per pass (row_reduce); the store of the
+    // partial is one more out-of-range-predicated buffer store, so the passes stay straight-line.
+    constexpr bool SC = decltype(SCF)::value;
     constexpr int NIN = E == EPI_STORE ? (ACC ? 1 : 0) : (E == EPI_SIGMOID_Z || E == EPI_ATT) ? 0 : E == EPI_SIGMOID_R ? 1 : E == EPI_TANH_H ? 2 : 3;
     constexpr bool ATT = E == EPI_ATT;      // fp32 streams: u[pair of the row][col] in (two 16-byte halves per item), t out
     constexpr int NOUT = (E == EPI_STORE || E == EPI_SIGMOID_Z) ? 1 : E == EPI_GATE_PRE ? 3 : 2;
@@ -83,6 +89,12 @@
     const rsrc_t rs_o1 = __builtin_amdgcn_make_buffer_rsrc((void*)(NOUT >= 2 ? (void*)out1 : (void*)C), 0, 0x7fffffff, 0x00020000);
     const rsrc_t rs_o2 = __builtin_amdgcn_make_buffer_rsrc((void*)(NOUT >= 3 ? (void*)P.out2 : (void*)C), 0, 0x7fffffff, 0x00020000);
     pp_u32x4 ra[2][2], rb[2][2], rc[2][2], rg[2][2][2];      // [register set][item]; gin: two 16-byte halves of eight fp32
+    float4 sw0 = make_float4(0.f, 0.f, 0.f, 0.f), sw1 = sw0;
+    const rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc((void*)(SC ? (void*)P.e : (void*)C), 0, 0x7fffffff, 0x00020000);
+    if constexpr (SC) {
+      const int c0 = 8 * (tid & 31);
+      if (c0 < N) { sw0 = *reinterpret_cast<const float4*>(P.w2 + c0); sw1 = *reinterpret_cast<const float4*>(P.w2 + c0 + 4); }
+    }
     auto voff = [&](int p_, int j, int esz) __attribute__((always_inline)) {
       int row, col, rr;
       const bool ok = pp_item(p_, j, row, col, rr);
@@ -166,7 +178,17 @@
           const float4 ya = mix4(ha, z.a, x.a), yb = mix4(hb, z.b, x.b);
           st(rs_o0, vo, ha, hb);
           st(rs_o1, vo, ya, yb);
-          if (scorer) {      // the word scorer sees dropout(out) in fp32 (wrapper.py:189-190): staged for the row reduction
+          if constexpr (SC) {      // the word scorer sees dropout(out) in fp32 (wrapper.py:189-190)
+            float4 sa = ya, sb = yb;
+            if (drop_mode == 2) {
+              const unsigned idx = (unsigned)row * (unsigned)drop_ld + (unsigned)(P.drop_col0 + col);
+              sa = drop4(sa, drop_seed, idx, drop_thresh, drop_scale);
+              sb = drop4(sb, drop_seed, idx + 4u, drop_thresh, drop_scale);
+            }
+            float v = vo != OOB ? sa.x * sw0.x + sa.y * sw0.y + sa.z * sw0.z + sa.w * sw0.w + sb.x * sw1.x + sb.y * sw1.y + sb.z * sw1.z + sb.w * sw1.w : 0.f;
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_e, ((lane & 31) == 0 && row < M) ? (unsigned)row * 4u : OOB, 0, 0);
+          } else if (scorer) {      // (partials added atomically / whole rows: the staged form, reduced by row_reduce below)
             float4 sa = ya, sb = yb;
             if (drop_mode == 2) {
               const unsigned idx = (unsigned)row * (unsigned)drop_ld + (unsigned)(P.drop_col0 + col);
@@ -206,7 +228,7 @@
       pp_stage(PT);
       if constexpr (p_ + 1 < MI) issue(std::integral_constant<int, p_ + 1>{}, std::integral_constant<int, (p_ + 1) & 1>{});
       compute(PT);
-      if constexpr (E == EPI_TANH_H) { if (rowred) row_reduce(PT); }
+      if constexpr (E == EPI_TANH_H && !SC) { if (rowred) row_reduce(PT); }
       if constexpr (ATT) row_reduce(PT);
     };
     issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -219,17 +241,21 @@
     constexpr std::integral_constant<bool, true> YES{};
     const bool no_c32 = c32 == nullptr;
     if (!(dbg_bits & 128) && no_c32) {
-      if (epi == EPI_ATT && pp_io == 0) { pp_fast(std::integral_constant<int, EPI_ATT>{}, NO, NO); return; }
+      if (epi == EPI_ATT && pp_io == 0) { pp_fast(std::integral_constant<int, EPI_ATT>{}, NO, NO, NO); return; }
       if (epi == EPI_STORE && (pp_io & 1)) {
-        if (accumulate) pp_fast(std::integral_constant<int, EPI_STORE>{}, YES, NO); else pp_fast(std::integral_constant<int, EPI_STORE>{}, NO, NO);
+        if (accumulate) pp_fast(std::integral_constant<int, EPI_STORE>{}, YES, NO, NO); else pp_fast(std::integral_constant<int, EPI_STORE>{}, NO, NO, NO);
         return;
       }
-      if (epi == EPI_SIGMOID_Z && (pp_io & 1)) { pp_fast(std::integral_constant<int, EPI_SIGMOID_Z>{}, NO, NO); return; }
-      if (epi == EPI_SIGMOID_R && (pp_io & 7) == 7) { pp_fast(std::integral_constant<int, EPI_SIGMOID_R>{}, NO, NO); return; }
-      if (epi == EPI_TANH_H && (pp_io & 15) == 15) { pp_fast(std::integral_constant<int, EPI_TANH_H>{}, NO, NO); return; }
-      if (epi == EPI_BWD_DRX && (pp_io & 15) == 15) { pp_fast(std::integral_constant<int, EPI_BWD_DRX>{}, NO, NO); return; }
+      if (epi == EPI_SIGMOID_Z && (pp_io & 1)) { pp_fast(std::integral_constant<int, EPI_SIGMOID_Z>{}, NO, NO, NO); return; }
+      if (epi == EPI_SIGMOID_R && (pp_io & 7) == 7) { pp_fast(std::integral_constant<int, EPI_SIGMOID_R>{}, NO, NO, NO); return; }
+      if (epi == EPI_TANH_H && (pp_io & 15) == 15) {
+        if (scorer && P.e_atomic != 1 && !(dbg_bits & 512)) pp_fast(std::integral_constant<int, EPI_TANH_H>{}, NO, NO, YES);
+        else pp_fast(std::integral_constant<int, EPI_TANH_H>{}, NO, NO, NO);
+        return;
+      }
+      if (epi == EPI_BWD_DRX && (pp_io & 15) == 15) { pp_fast(std::integral_constant<int, EPI_BWD_DRX>{}, NO, NO, NO); return; }
       if (epi == EPI_GATE_PRE && (pp_io & 63) == 63) {
-        if (P.gin) pp_fast(std::integral_constant<int, EPI_GATE_PRE>{}, NO, YES); else pp_fast(std::integral_constant<int, EPI_GATE_PRE>{}, NO, NO);
+        if (P.gin) pp_fast(std::integral_constant<int, EPI_GATE_PRE>{}, NO, YES, NO); else pp_fast(std::integral_constant<int, EPI_GATE_PRE>{}, NO, NO, NO);
         return;
       }
     }
