@@ -19,7 +19,7 @@ _I = ctypes.c_int
 _F = ctypes.c_float
 _L = ctypes.c_int64
 _U = ctypes.c_uint32
-ABI_VERSION = 9          # GH_ABI_VERSION of include/get_hip.h
+ABI_VERSION = 10         # GH_ABI_VERSION of include/get_hip.h
 
 # name -> argtypes (mirrors include/get_hip.h; tests/test_abi.py checks the two agree)
 SIGNATURES = {
@@ -42,6 +42,7 @@ SIGNATURES = {
     "gh_concat_att_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "gh_linear_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "gh_linear_bwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "gh_linear_wgrad_bf16": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _P],
     "gh_evd_assemble_fwd": [_P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "gh_evd_assemble_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "gh_clamp_events": [_P, _I],

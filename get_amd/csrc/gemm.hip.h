@@ -79,7 +79,7 @@ struct Problem {
   const float* gin; const float* in2; float* out2;
 };
 
-#define GH_MAX_PROBLEMS 12     // (sizeof(Launch) = 12 x 336 + 24 = 4056 of the 4096 kernarg bytes: the head's 3556-wide products are 12 column blocks)
+#define GH_MAX_PROBLEMS 12     // (sizeof(Launch) = 12 x 336 + 32 = 4064 of the 4096 kernarg bytes: the head's 3556-wide products are 12 column blocks)
 struct Launch {
   Problem p[GH_MAX_PROBLEMS];
   int nprob;
@@ -87,6 +87,8 @@ struct Launch {
   int ksplit;    // TN: number of K chunks (1 otherwise)
   int kchunk;    // TN: rows per chunk, multiple of 16
   int dbg;       // measurement only (GH_DBG): bit 0 = skip the epilogue, bit 1 = skip the K loop
+  int n_tiles;   // gemm_tn_pp_kernel: max over problems of ceil(N / 256) (its problems are whole outputs, not column blocks)
+  int per;       // gemm_tn_pp_kernel: work items per XCD (XCD x runs items [x per, (x + 1) per) of the chunk-major list)
 };
 static_assert(sizeof(Launch) <= 4096, "Launch travels by value in the kernarg segment (4 KB)");
 

@@ -5,6 +5,7 @@
 #include "gemm.hip.h"
 #include "gemm_nt.hip.h"
 #include "gemm_tn.hip.h"
+#include "gemm_tn_pp.hip.h"
 #include <stdlib.h>
 
 namespace gh {
@@ -54,6 +55,13 @@ static bool tn16_tall() {
   static int v = -1;
   if (v < 0) v = measure_env("GH_TN16_TALL", 1);
   return v != 0;
+}
+// bf16 weight-gradient GEMM on the 256 x 256 x 64 ping-pong tile (gemm_tn_pp.hip.h): K-chunk rows from which a batch of whole-output
+// problems takes it (tool build: GH_TN_PP_ROWS; a huge value restores the 128 x 320 kernel everywhere)
+static int tn_pp_rows() {
+  static int v = -1;
+  if (v < 0) v = measure_env("GH_TN_PP_ROWS", 16384);
+  return v;
 }
 static bool wants_dropout(const Launch& L) {
   for (int i = 0; i < L.nprob; ++i)
@@ -198,6 +206,25 @@ static hipError_t launch_cfg(const Launch& L, bool tn, hipStream_t s) {
   }
   }      // MI == 2
   if (!launched && MI != 2) return hipErrorInvalidValue;
+  prof_end(tag, flops, s);
+  return hipGetLastError();
+}
+
+// bf16 weight gradients on the 256 x 256 x 64 ping-pong tile: one workgroup per CU, work items dealt to the XCDs in runs (L.per each)
+static hipError_t launch_tn_pp(const Launch& L, hipStream_t s) {
+  const int grid = 8 * L.per;
+  if (grid <= 0) return hipSuccess;
+  g_path_counts[0] += 1;
+  const int tag = PROF_GEMM_BIG + 1;
+  double flops = 0.0;
+  if (prof_enabled()) {
+    for (int i = 0; i < L.nprob; ++i) flops += 2.0 * L.p[i].M * L.p[i].N * (double)L.p[i].seg[0].K;
+    prof_begin(s, tag);
+  }
+  constexpr int kLds = 131072;      // two K tiles of 64 KB
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); attr = true; }
+  hipLaunchKernelGGL(gemm_tn_pp_kernel, dim3(grid), dim3(512), kLds, s, L);
   prof_end(tag, flops, s);
   return hipGetLastError();
 }
@@ -543,6 +570,16 @@ struct Batch {
   long long e_block_stride = 0;
   bool wide = false;      // 128 x 256 bf16 tile (launch_cfg<2, 2, 8, 4>)
   bool wide256 = false;   // 256 x 256 x 64 bf16 tile, 8 waves, ping-pong K loop (launch_cfg<2, 4, 4, 8>)
+  // weight gradients of the bf16 storage pipeline on the 256 x 256 x 64 ping-pong tile (gemm_tn_pp.hip.h): the batch's problems stay
+  // WHOLE outputs (no 320-column blocks), the kernel walks their 256 x 256 tiles.  Decided by the first problem of a launch.
+  bool tn_pp = false;
+  bool tn_pp_ok(const Problem& p) const {
+    if (!tn || !p.elt || p.nseg != 1 || g_ws == nullptr || p.epi != EPI_ATOMIC) return false;
+    const Seg& sg = p.seg[0];
+    if (sg.gatherA || sg.gatherB || !sg.vecA || !sg.vecB || sg.K < tn_pp_rows()) return false;
+    if (p.M % 256 || p.N % 256 || p.ldc % 4 || (reinterpret_cast<uintptr_t>(p.C) & 15)) return false;
+    return (size_t)sg.K * (size_t)sg.lda * 2 < ((size_t)1 << 31) && (size_t)sg.K * (size_t)sg.ldb * 2 < ((size_t)1 << 31);
+  }
   bool wide128 = false;   // 128 x 128 bf16 tile, three workgroups per CU (launch_cfg<2, 2, 4, 4>; tool build: GH_BF16_TILE=128)
   // (round 5: the same 128 x 256 tile on EIGHT waves -- 64 x 64 per wave, two workgroups = four waves per SIMD -- needs 146 VGPRs
   //  for its 128-register budget: 82 spills, 16 instead of 12 ds_read_b128 per 32 MFMAs; configs[4] bf16 115.3 -> 99.6 K pairs/s. Removed.)
@@ -595,7 +632,7 @@ struct Batch {
     reset();
   }
   void reset() {
-    L.nprob = 0; L.m_tiles = 0; L.ksplit = 1; L.kchunk = 0; k_total = 0;
+    L.nprob = 0; L.m_tiles = 0; L.ksplit = 1; L.kchunk = 0; k_total = 0; L.n_tiles = 0; L.per = 0;
     static int dbg = -1;
     if (dbg < 0) dbg = measure_env("GH_DBG", 0);
     L.dbg = dbg;
@@ -609,6 +646,12 @@ struct Batch {
     // ... or, with a partial buffer per block (e_block_stride), any number of them: the scorer kernel adds the partials in block order
     const bool scorer_parts = p.epi == EPI_TANH_H && p.w2 && p.N > bn && !scorer_blocks && e_block_stride > 0;
     if ((p.epi == EPI_ATT || (p.epi == EPI_TANH_H && p.w2)) && p.N > bn && !scorer_blocks && !att_blocks && !scorer_parts) { err = hipErrorInvalidValue; return; }
+    if (tn) {
+      const bool want = tn_pp_ok(p);
+      if (L.nprob > 0 && want != tn_pp) flush();      // (a launch is one kernel: problems of the other kind start the next one)
+      if (L.nprob == 0) tn_pp = want;
+    }
+    const int bn = tn_pp ? (1 << 30) : this->bn;
     for (int n0 = 0; n0 < p.N; n0 += bn) {
       Problem q = p;
       q.N = (p.N - n0 < bn) ? p.N - n0 : bn;
@@ -638,9 +681,10 @@ struct Batch {
       if (att_blocks) { q.w2 += n0; q.u += n0; q.e = p.e + (size_t)(n0 / bn) * (size_t)e_block_stride; q.e_atomic = 2; }      // (2: own partial buffer, plain stores)
       if (L.nprob == GH_MAX_PROBLEMS) flush();
       L.p[L.nprob++] = q;
-      const int bm_eff = (tn && q.elt && tn16_tall()) ? 128 : bm;      // (all problems of a TN launch share the storage mode)
+      const int bm_eff = tn_pp ? 256 : (tn && q.elt && tn16_tall()) ? 128 : bm;      // (all problems of a TN launch share the storage mode)
       const int mt = (q.M + bm_eff - 1) / bm_eff;
       if (mt > L.m_tiles) L.m_tiles = mt;
+      if (tn_pp && (q.N + 255) / 256 > L.n_tiles) L.n_tiles = (q.N + 255) / 256;
       if (q.seg[0].K > k_total) k_total = q.seg[0].K;
     }
   }
@@ -666,20 +710,43 @@ struct Batch {
       // the bench step (A/B, one box): 65 chunks 158.6 K pairs/s, 72 chunks 159.9 K, 85 chunks 156.4 K.
       static int xcd_rule = -1;
       if (xcd_rule < 0) xcd_rule = measure_env("GH_TN_XCD_RULE", 1);
-      const int align = L.p[0].elt ? 32 : 16;      // K tile of the kernel (bf16 storage: 32 rows)
+      const int align = tn_pp ? 64 : L.p[0].elt ? 32 : 16;      // K tile of the kernel (bf16 storage: 32 rows, ping-pong tile: 64)
+      if (tn_pp) {
+        // one workgroup per CU: as many K chunks as fill ONE round of 256 workgroups when that occupies >= 85 % of them (h = 768: a
+        // cell's 7 outputs = 63 tiles x 4 chunks = 252), else two rounds; chunks of at least 1024 rows.  The XCD rule does not apply:
+        // the kernel deals its items to the XCDs in runs.
+        const int tiles = L.nprob * L.m_tiles * L.n_tiles;
+        const int ks1 = 256 / tiles > 0 ? 256 / tiles : 1, ks2 = 512 / tiles > 0 ? 512 / tiles : 1;
+        const double e1 = tiles * ks1 / 256.0, e2 = tiles * ks2 / 512.0;
+        static int force = -1;
+        if (force < 0) force = measure_env("GH_TN_PP_KS", 0);
+        ks = (e1 >= 0.85 || e1 >= e2) ? ks1 : ks2;
+        if (force > 0) ks = force;
+        const int kmax = k_total / 1024 > 1 ? k_total / 1024 : 1;
+        if (ks > kmax) ks = kmax;
+        // (the partial tiles must fit the workspace: fewer chunks otherwise)
+        size_t out_bytes = 0;
+        for (int i = 0; i < L.nprob; ++i) out_bytes += ((size_t)L.p[i].M * L.p[i].N + (cs_out[i] ? (size_t)L.p[i].M : 0)) * sizeof(float);
+        while (ks > 1 && (size_t)ks * out_bytes > g_ws_bytes) --ks;
+      } else
       if (xcd_rule && ks >= 12) ks = ((ks + 4) / 8) * 8;
       int chunk = (k_total + ks - 1) / ks;
       chunk = ((chunk + align - 1) / align) * align;
       L.kchunk = chunk;
       L.ksplit = (k_total + chunk - 1) / chunk;
-      if (xcd_rule && L.ksplit >= 12 && L.ksplit % 8 != 0) {      // rounding the chunk up dropped a chunk or two: stretch the chunks to the multiple of 8 below
+      if (tn_pp) L.per = (L.nprob * L.m_tiles * L.n_tiles * L.ksplit + 7) / 8;
+      if (!tn_pp && xcd_rule && L.ksplit >= 12 && L.ksplit % 8 != 0) {      // rounding the chunk up dropped a chunk or two: stretch the chunks to the multiple of 8 below
         const int k8 = (L.ksplit / 8) * 8;
         chunk = (((k_total + k8 - 1) / k8 + align - 1) / align) * align;
         if ((k_total + chunk - 1) / chunk % 8 == 0) { L.kchunk = chunk; L.ksplit = (k_total + chunk - 1) / chunk; }
       }
       // partial tiles -> workspace when it is big enough and every output is float4-shaped
       size_t need = 0;
-      bool ws_ok = g_ws != nullptr && L.ksplit > 1;
+      bool want_cs0 = false;
+      for (int i = 0; i < L.nprob; ++i) want_cs0 = want_cs0 || cs_out[i] != nullptr;
+      // (a single chunk also goes through the workspace when the ping-pong kernel runs it -- it only writes partial tiles -- or when
+      //  bf16 operands want their bias gradient: that rides in the fused kernels' workspace path only)
+      bool ws_ok = g_ws != nullptr && (L.ksplit > 1 || tn_pp || (want_cs0 && L.p[0].elt));
       bool any_cs = false;
       for (int i = 0; i < L.nprob && ws_ok; ++i) {
         if (L.p[i].N % 4) ws_ok = false;
@@ -738,6 +805,7 @@ struct Batch {
         return;
       }
     }
+    if (tn && tn_pp) { err = hipErrorInvalidValue; reset(); return; }      // (the ping-pong kernel writes partial tiles only: no workspace, no launch)
     if (!tn && nt_split_plan()) return;
     hipError_t e = launch_any();
     if (e != hipSuccess) err = e;
@@ -745,6 +813,7 @@ struct Batch {
   }
 
   hipError_t launch_any() {
+    if (tn && tn_pp) return launch_tn_pp(L, s);
 #ifdef GH_MEASURE      // (the fp32 ping-pong tile is a measured-and-dropped experiment, DESIGN 4.5: instantiated in the tool build only)
     if (pp32 && !tn && L.ksplit == 1 && !L.p[0].elt) return launch_cfg<4, 2, 5>(L, tn, s);
 #endif
@@ -1538,6 +1607,24 @@ extern "C" int gh_linear_fwd(const float* x, const float* w, const float* bias, 
   b.add(p);
   b.flush();
   GH_CHECK_HIP(b.err);
+  return 0;
+}
+
+extern "C" int gh_linear_wgrad_bf16(const void* g16, int ldg, const void* x16, int ldx, int m, int n, int k,
+                                    float* dw, int lddw, float* db, gh_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GH_REQUIRE(m > 0 && k > 0 && n > 0 && g16 && x16 && dw, "linear_wgrad_bf16: bad arguments");
+  GH_REQUIRE(n % 8 == 0 && k % 8 == 0 && ldg % 8 == 0 && ldx % 8 == 0 && ldg >= n && ldx >= k && lddw >= k && lddw % 4 == 0,
+             "linear_wgrad_bf16: widths and leading dimensions must be multiples of 8 (lddw: of 4)");
+  GH_REQUIRE(((reinterpret_cast<uintptr_t>(g16) | reinterpret_cast<uintptr_t>(x16) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0,
+             "linear_wgrad_bf16: operands must be 16-byte aligned");
+  Batch b(true, m, s);
+  GH_REQUIRE(b.g_ws != nullptr, "linear_wgrad_bf16: needs the split-K workspace (gh_set_workspace)");
+  b.add(tn_problem(n, k, dw, lddw, (const float*)g16, ldg, (const float*)x16, ldx, m, nullptr, 1));
+  if (db) b.want_colsum(db, nullptr);
+  b.flush();
+  GH_CHECK_HIP(b.err);
+  GH_REQUIRE(!db || (b.colsum_fused && !b.colsum_missed), "linear_wgrad_bf16: the bias gradient did not fit the split-K workspace");
   return 0;
 }
 

@@ -790,6 +790,21 @@ def linear(x, w, b=None):
     return _Linear.apply(x, w, b)
 
 
+def linear_wgrad_bf16(g16: torch.Tensor, x16: torch.Tensor, dw: torch.Tensor, db: torch.Tensor = None):
+    """dw[n][k] += g16^T x16, db[n] += colsum(g16) for bf16 activations / upstream gradients [m][n], [m][k] (row views with a
+    leading dimension are taken as they are) and fp32 accumulators -- gh_linear_wgrad_bf16, the weight-gradient GEMM of the
+    bf16 storage pipeline (gh_ggnn_cell_bwd_bf16) on its own.  Returns dw."""
+    assert g16.dtype == torch.bfloat16 and x16.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    assert g16.dim() == 2 and x16.dim() == 2 and g16.shape[0] == x16.shape[0] and g16.stride(1) == 1 and x16.stride(1) == 1
+    m, n = g16.shape
+    k = x16.shape[1]
+    assert tuple(dw.shape) == (n, k) and dw.stride(1) == 1 and (db is None or (db.dtype == torch.float32 and db.numel() == n and db.is_contiguous()))
+    _lib.ensure_workspace(g16.device)
+    # (row views with a leading dimension: the raw addresses, `ptr` insists on contiguous tensors)
+    call("gh_linear_wgrad_bf16", g16.data_ptr(), g16.stride(0), x16.data_ptr(), x16.stride(0), m, n, k, dw.data_ptr(), dw.stride(0), ptr(db), stream())
+    return dw
+
+
 # --------------------------------------------------------------------------- ragged helpers
 class Segments:
     """Claim -> evidence-pair segmentation of one batch (prefix sums live on the device)."""

@@ -56,7 +56,7 @@ extern "C" {
 
 typedef void* gh_stream_t;
 
-#define GH_ABI_VERSION 9
+#define GH_ABI_VERSION 10
 
 int gh_abi_version(void);
 /* Thread-local message of the last failing call on this thread (never NULL). */
@@ -274,6 +274,15 @@ int gh_linear_fwd(const float* x, const float* w, const float* bias, float* y, i
  * n <= 8 outputs (the 2-class head) then run as one row-per-wave kernel instead of three MFMA launches. */
 int gh_linear_bwd(const float* x, const float* wt, const float* w, const float* g, int m, int k, int n,
                   float* dx, float* dw, float* db, gh_stream_t stream);
+
+/* Weight gradient of a linear layer of the bf16 storage pipeline (gh_ggnn_cell_bwd_bf16's building block, exposed for callers'
+ * own layers and for the exact parity test of the kernel): g16 [m][ldg] and x16 [m][ldx] hold bf16 (n resp. k columns used),
+ *     dw[n][k] (fp32, leading dimension lddw) += g^T x,      db[n] (fp32, NULL ok) += colsum(g),
+ * products exact, fp32 accumulation, a fixed summation order.  Needs the split-K workspace (gh_set_workspace), 16-byte aligned
+ * operands with ldg % 8 == ldx % 8 == 0 and n % 8 == k % 8 == 0.  Outputs whose widths are multiples of 256 over >= 16 384 rows run
+ * on the 256 x 256 x 64 ping-pong tile (gemm_tn_pp.hip.h), the rest on the 128 x 320 tile (gemm_tn.hip.h). */
+int gh_linear_wgrad_bf16(const void* g16, int ldg, const void* x16, int ldx, int m, int n, int k,
+                         float* dw, int lddw, float* db, gh_stream_t stream);
 
 /* ---- a8  ragged helpers: Models/FCWithEvidences/basic_fc_model.py:80-121 ----
  * offsets[b+1] int32 prefix sum of evidence counts (device). */

@@ -45,7 +45,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     for name in _lib.SIGNATURES:
         assert name in decl, f"{name} bound in Python but not declared in get_hip.h"
     lib.gh_abi_version.restype = ctypes.c_int
-    assert lib.gh_abi_version() == 9
+    assert lib.gh_abi_version() == 10
     _lib.load()
 
 

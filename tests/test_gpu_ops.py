@@ -773,6 +773,42 @@ def test_bf16_cell_on_the_256_tile_tracks_fp32(bf16_mode, h, din, rows_kind):
         assert float((g16[k] - g32[k]).abs().max()) <= 5e-2 * float(g32[k].abs().max()) + 1e-6, k
 
 
+@pytest.mark.parametrize("m,n,k,pad", [
+    (62208, 768, 768, 0),        # the configs[4] cell shape: 9 tiles x 28 chunks
+    (20011, 256, 512, 0),        # ragged rows: the last K tile of every chunk is partial, 2 tiles
+    (16384 + 37, 512, 256, 64),  # operand rows with a leading dimension (column views of wider buffers)
+    (40000, 1024, 768, 0),       # 12 tiles: two rounds' worth of chunks
+    (5000, 768, 768, 0),         # below the row threshold: the 128 x 320 kernel (same contract)
+    (33000, 264, 520, 0),        # widths that are not multiples of 256: the 128 x 320 kernel
+])
+def test_bf16_weight_gradient_gemm_exact(m, n, k, pad):
+    """gh_linear_wgrad_bf16 (the weight-gradient GEMM of the bf16 storage pipeline; outputs in multiples of 256 over >= 16 384 rows run
+    on the 256 x 256 x 64 ping-pong tile, gemm_tn_pp.hip.h) against float64 products of the SAME bf16 operand values: the kernel's
+    products are exact and its accumulation is fp32, so the bound is accumulation rounding only -- 2e-5 of the largest entry, which a
+    lost or doubled K tile, a wrong chunk boundary or a swizzle slip would exceed by orders of magnitude.  dw and db ACCUMULATE into
+    the caller's buffers (checked with non-zero initial contents)."""
+    from get_amd import ops
+    gen = torch.Generator(device="cpu").manual_seed(m + n + k)
+    gfull = (torch.randn(m, n + pad, generator=gen) * 0.5).to(torch.bfloat16).to(DEV)
+    xfull = (torch.randn(m, k + pad, generator=gen)).to(torch.bfloat16).to(DEV)
+    g16, x16 = gfull[:, pad // 2: pad // 2 + n], xfull[:, pad // 2: pad // 2 + k]
+    if pad:
+        assert g16.data_ptr() % 16 == 0 and x16.data_ptr() % 16 == 0
+    dw0 = torch.randn(n, k, generator=gen).to(DEV)
+    db0 = torch.randn(n, generator=gen).to(DEV)
+    dw, db = dw0.clone(), db0.clone()
+    ops.linear_wgrad_bf16(g16, x16, dw, db)
+    torch.cuda.synchronize()
+    ref_w = torch.zeros(n, k, dtype=torch.float64, device=DEV)
+    for r0 in range(0, m, 8192):      # (float64 GEMM in row slabs: bounded memory)
+        ref_w += g16[r0:r0 + 8192].double().t() @ x16[r0:r0 + 8192].double()
+    ref_b = g16.double().sum(0)
+    ew = float(((dw - dw0).double() - ref_w).abs().max()) / float(ref_w.abs().max())
+    eb = float(((db - db0).double() - ref_b).abs().max()) / float(ref_b.abs().max())
+    assert ew <= 2e-5, ew
+    assert eb <= 2e-5, eb
+
+
 def test_evd_assemble_bwd_writes_every_row_of_d_avg():
     """gh_evd_assemble_bwd needs no cleared d_avg: the rows of real (claim, slot) pairs receive their gradient, the rows of a claim's
     evidences beyond its n_max-th (no slot in the padded tensor) receive zeros -- checked on a NaN-filled buffer with one claim over
