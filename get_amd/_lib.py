@@ -29,6 +29,7 @@ SIGNATURES = {
     "gh_adj_pack_f32": [_P, _I, _I, _P, _P, _P],
     "gh_ragged_plan": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "gh_spmm": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gh_spmm_bf16": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "gh_transpose": [_P, _P, _I, _I, _P],
     "gh_transpose_batch": [_I, _P, _P, _P, _P, _P],
     "gh_ggnn_cell_fwd": [_P] * 5 + [_I, _I] + [_P] * 2 + [_I] * 4 + [_P] * 13 + [_P] * 7 + [_F, _U, _P, _P, _F, _U, _P],

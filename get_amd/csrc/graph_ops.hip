@@ -868,8 +868,10 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
       if (aligned < 0) aligned = measure_env("GH_SPMM_LINE_SLABS", 1);
       if (aligned && cap_env <= 0 && ((size_t)h * (bf16 ? 2 : 4)) % 128 == 0 && hv % per_line == 0) {
         int best = 0;
-        for (int c = per_line; c <= hv && (size_t)r * c * col_b <= 40 * 1024; c += per_line) best = c;
-        if (best >= 2 * per_line) {
+        static int line_kb = -1;
+        if (line_kb < 0) line_kb = measure_env("GH_SPMM_LINE_KB", 40);
+        for (int c = per_line; c <= hv && (size_t)r * c * col_b <= (size_t)line_kb * 1024; c += per_line) best = c;
+        if (best >= 2 * per_line || (line_kb != 40 && best >= per_line)) {
           const int ns = (hv + best - 1) / best;
           int even = (((hv + ns - 1) / ns) + per_line - 1) / per_line * per_line;      // as even as whole lines allow
           lslab = even;
@@ -1220,6 +1222,14 @@ extern "C" int gh_spmm(const uint64_t* bits, const float* dinv, const float* val
                        int accumulate, gh_stream_t stream) {
   if (n <= 0) return 0;
   return launch_spmm(bits, dinv, vals, keep, goff, m_real, x, y, n, r, h, transpose, accumulate, (hipStream_t)stream, 0);
+}
+
+extern "C" int gh_spmm_bf16(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
+                            const int32_t* goff, int m_real, const void* x16, void* y16, int n, int r, int h, int transpose,
+                            int accumulate, gh_stream_t stream) {
+  if (n <= 0) return 0;
+  GH_REQUIRE(h % 8 == 0, "spmm_bf16: h must be a multiple of 8");
+  return launch_spmm(bits, dinv, vals, keep, goff, m_real, (const float*)x16, (float*)y16, n, r, h, transpose, accumulate, (hipStream_t)stream, 1);
 }
 
 extern "C" int gh_scorer_gsl(const uint64_t* bits, const float* dinv, const float* vals, const int32_t* goff,

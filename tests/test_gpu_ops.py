@@ -523,6 +523,43 @@ def test_compact_spmm_equals_padded(h):
         assert torch.equal(yc, plan.from_padded(yp, plan.m_real))           # same neighbours, same order: bit-exact
 
 
+@pytest.mark.parametrize("h,n_graphs,window", [(768, 300, 5), (256, 40, 3), (520, 9, 5)])
+def test_spmm_bf16_is_the_fp32_aggregation_rounded_once(h, n_graphs, window):
+    """gh_spmm_bf16 (the aggregation of the bf16 storage pipeline: bf16 rows in HBM and in the LDS slab image, whole-line slabs at
+    h = 768) against gh_spmm on the same bf16 values held in fp32: the sums are formed in fp32 in the same order, so the bf16 result
+    must be the fp32 result rounded ONCE (round-to-nearest-even) -- bit for bit, in the padded and the node-compact layout, with a
+    keep set, transposed, and accumulating (y16 read, added in fp32, rounded once).  Hub rows included (split work items)."""
+    from get_amd import _lib, ops
+    rng = np.random.default_rng(4000 + h)
+    n, r = n_graphs, 100
+    toks = rng.integers(100, 5000, size=(n, r)).astype(np.int32)
+    for g in range(n):
+        toks[g, ::3] = 7 + (g % 3)                       # a hub token
+    lens = rng.integers(30, r + 1, size=(n,)).astype(np.int32)
+    padj, node_ids, n_nodes = ops.graph_build(T(toks), T(lens), window)
+    plan = ops.RaggedPlan(n_nodes, node_ids, int(n_nodes.sum().item()))
+    keep = ops.gsl_topk(T(rng.standard_normal((n, r)).astype(np.float32)), 60)
+    x16 = T(rng.standard_normal((n, r, h)).astype(np.float32)).to(torch.bfloat16)
+    y0 = T(rng.standard_normal((n, r, h)).astype(np.float32)).to(torch.bfloat16)
+    for a in (padj, padj.with_keep(keep)):
+        for pl in (None, plan):
+            xin = x16 if pl is None else plan.from_padded(x16.float(), plan.m_real).to(torch.bfloat16).contiguous()
+            yin = y0 if pl is None else plan.from_padded(y0.float(), plan.m_real).to(torch.bfloat16).contiguous()
+            for tr, acc in ((0, 0), (1, 1)):
+                x32 = xin.float().contiguous()
+                y32 = yin.float().contiguous() if acc else torch.empty_like(x32)
+                _lib.call("gh_spmm", *a._args(), *ops._plan_args(pl), _lib.ptr(x32), _lib.ptr(y32), n, r, h, tr, acc, _lib.stream())
+                y16 = yin.clone() if acc else torch.empty_like(xin)
+                _lib.call("gh_spmm_bf16", *a._args(), *ops._plan_args(pl), _lib.ptr(xin), _lib.ptr(y16), n, r, h, tr, acc, _lib.stream())
+                torch.cuda.synchronize()
+                rows = slice(None) if pl is not None else None
+                want = y32.to(torch.bfloat16)
+                if pl is None:      # (padding rows of the padded layout: both kernels write them, compare everything)
+                    assert torch.equal(y16.view(torch.int16), want.view(torch.int16)), (tr, acc)
+                else:
+                    assert torch.equal(y16.view(torch.int16)[rows], want.view(torch.int16)[rows]), (tr, acc)
+
+
 @pytest.mark.parametrize("n_graphs", [9, 300])
 def test_spmm_hub_rows_split_over_work_items_match_dense_fp64(n_graphs):
     """Word graphs with a hub node (a token at every third position: degree ~2/3 of the nodes).  In the node-compact layout

@@ -70,5 +70,33 @@ try:      # tool build: per-phase ticks of the list kernel (thread 0 of every wo
     print(f"phases, thread 0 of each of {a.shape[0]} workgroups, s_memtime ticks (~0.5 ns; with several slabs per workgroup the slab phases hold the LAST slab), mean / p90: " + ", ".join(f"{nm} {a[:, i].mean():.2f}/{np.percentile(a[:, i], 90):.2f}" for i, nm in enumerate(names)) + f"  total {a.sum(1).mean():.2f}")
 except Exception as e:
     print("no phase instrumentation:", e)
+# the bf16 storage pipeline's aggregation at the configs[4] shape (h = 768, window 5, node-compact), with its phase ticks
+try:
+    import ctypes
+    h16 = 768
+    toks16 = make_tokens(rng, n, r, 20000, r, r)[0]
+    adj16, _, nn16 = ops.graph_build(torch.from_numpy(toks16).to(dev), torch.from_numpy(np.full((n,), r, np.int32)).to(dev), 5)
+    goff16 = torch.zeros(n + 1, device=dev, dtype=torch.int32)
+    goff16[1:] = torch.cumsum(nn16, 0).to(torch.int32)
+    m16 = int(goff16[-1])
+    x16 = torch.randn(m16, h16, device=dev).to(torch.bfloat16)
+    y16 = torch.empty_like(x16)
+    nnz16 = float(torch.count_nonzero(adj16.to_dense())) / n
+    for acc in (0, 1):
+        ms16 = timeit(lambda: _lib.call("gh_spmm_bf16", *adj16._args(), goff16.data_ptr(), m16, x16.data_ptr(), y16.data_ptr(), n, r, h16, 0, acc, _lib.stream()))
+        print(f"bf16 h=768 window 5 compact m_real {m16} nnz/graph {nnz16:.1f} accumulate {acc}: {ms16*1e3:7.1f} us  {(2 + acc)*m16*h16*2/ms16/1e6:7.1f} GB/s")
+    L = _lib.load()
+    L.gh_debug_spmm_phases.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    buf = (ctypes.c_uint * (8192 * 8))()
+    L.gh_debug_spmm_phases(None, 1)
+    _lib.call("gh_spmm_bf16", *adj16._args(), goff16.data_ptr(), m16, x16.data_ptr(), y16.data_ptr(), n, r, h16, 0, 0, _lib.stream())
+    torch.cuda.synchronize()
+    L.gh_debug_spmm_phases(buf, 1)
+    a = np.frombuffer(buf, dtype=np.uint32).reshape(8192, 8)[:, :7].astype(np.float64)
+    a = a[a.sum(1) > 0]
+    names = ["issue", "rowwords+scan", "barrier1", "listbuild", "slabwait", "barrier2", "aggregate"]
+    print(f"bf16 phases, thread 0 of each of {a.shape[0]} workgroups (two slabs each: the slab phases hold the LAST slab), mean / p90: " + ", ".join(f"{nm} {a[:, i].mean():.2f}/{np.percentile(a[:, i], 90):.2f}" for i, nm in enumerate(names)) + f"  total {a.sum(1).mean():.2f}")
+except Exception as e:
+    print("bf16 section failed:", e)
 ms = timeit(lambda: y.copy_(x))
 print(f"copy      {ms*1e3:7.1f} us  {2*n*r*h*4/ms/1e6:7.1f} GB/s")
