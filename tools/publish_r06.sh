@@ -24,5 +24,7 @@ cp $O/bench_8rank_gloo_weak.json profiles/r06_bench_8rank_gloo_weak.json
 cp $O/bench_gpus2_on_1gpu_box.out profiles/r06_bench_gpus2_on_a_1gpu_box.txt
 cp $O/batch_sweep.txt profiles/r06_batch_sweep.txt
 [ -f $O/soak.json ] && cp $O/soak.json profiles/r06_soak.json
+[ -s $O/soak_cfg4_bf16.json ] && cp $O/soak_cfg4_bf16.json profiles/r06_soak_cfg4_bf16.json
 [ -f $O/nt256_proto.txt ] && cp $O/nt256_proto.txt profiles/r06_nt256_proto.txt
+[ -f $O/tn256_proto.txt ] && cp $O/tn256_proto.txt profiles/r06_tn256_proto.txt
 echo "published build $(cat $O/commit.txt)"

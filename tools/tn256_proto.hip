@@ -148,11 +148,13 @@ tn256_kernel(const Params P) {
     "+v"(bF[H_][1][0][0]), "+v"(bF[H_][1][0][1]), "+v"(bF[H_][1][1][0]), "+v"(bF[H_][1][1][1]) :: "memory")
 #define BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define M_SECTION(RH_, CH_) do { __builtin_amdgcn_s_setprio(1); QUAD(RH_, CH_) __builtin_amdgcn_s_setprio(0); BAR(); } while (0)
-  // COLSUM: wave (wm, wn) sums tile mi = wn of each row half out of the fragments it holds anyway (16 unpack-adds per half and K tile)
-#define CSUM(RH_) do { if (COLSUM) { _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int rd = 0; rd < 2; ++rd) { \
-    const uint2 v_ = wn == 0 ? aF[0][ks][rd] : wn == 1 ? aF[1][ks][rd] : wn == 2 ? aF[2][ks][rd] : aF[3][ks][rd];                        \
+  // COLSUM: wave (wm, wn) sums tile mi = wn of each row half out of the fragments it holds anyway (32 unpack-adds per half and K tile).
+  // The tile is picked by a wave-uniform BRANCH chain: a run-time index into aF[] put the whole fragment array into scratch (5 x slower).
+#define CS1(RH_, MI_) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int rd = 0; rd < 2; ++rd) {               \
+    const uint2 v_ = aF[MI_][ks][rd];                                                                                                    \
     csum[RH_][0] += __builtin_bit_cast(float, v_.x << 16) + __builtin_bit_cast(float, v_.y << 16);                                       \
-    csum[RH_][1] += __builtin_bit_cast(float, v_.x & 0xffff0000u) + __builtin_bit_cast(float, v_.y & 0xffff0000u); } } } while (0)
+    csum[RH_][1] += __builtin_bit_cast(float, v_.x & 0xffff0000u) + __builtin_bit_cast(float, v_.y & 0xffff0000u); }
+#define CSUM(RH_) do { if (COLSUM) { if (wn == 0) { CS1(RH_, 0) } else if (wn == 1) { CS1(RH_, 1) } else if (wn == 2) { CS1(RH_, 2) } else { CS1(RH_, 3) } } } while (0)
 
   // ---- prologue: tile 0 entirely, tile 1 except its second A half (phase 1 of tile 0 stages that one)
   stage(0, OPA, H0); stage(0, OPB, H0); stage(0, OPB, H1); stage(0, OPA, H1);
