@@ -17,7 +17,7 @@
 // Work items (K chunk, problem, row tile, column tile) are dealt to the XCDs in RUNS -- XCD x takes items [x per, (x + 1) per) of the
 // chunk-major list -- so that the workgroups sharing an L2 stream the same rows of the same operands.
 // The bias gradient (column sums of A over the chunk) comes out of the A fragments the waves hold anyway: wave (wm, wn) sums tile
-// mi = wn of each row half, 32 unpack-adds per half and K tile in the load sections of the two light phases.
+// mi = wn of each row half with one more MFMA per fragment against an all-ones operand (4 per K tile, in the tiles that carry one).
 // Measured (prototype, K = 62 208 rows): 768 x 1536 and 1536 x 1536 outputs 1030 - 1100 TF with their partial-tile stores, against
 // ~840 TF for the 128 x 320 kernel's cell launches inside the step.
 // Host-side preconditions (Batch::flush): bf16 operands, 16-byte aligned rows, I and J multiples of 8, no row gather, partial tiles in
@@ -114,9 +114,15 @@ gemm_tn_pp_kernel(const Launch L_byval) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
   uint2 aF[4][2][2], bF[2][2][2][2];      // A: [mi][k-step][read] of the current row half; B: [column half][ni][k-step][read]
-  float csum[2] = {0.f, 0.f};             // [row half]: this lane's share of the column sum of A's column 64 wm + 16 wn + l15 of the half
+  // [row half]: column sums of A (the bias gradient) for the wave's tile mi = wn, as one more MFMA per fragment against an all-ones B
+  // operand -- every output column of the 16 x 16 result then holds sum_k A[k][i]
+  f32x4 acs[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const bf16x8 ones8 = __builtin_bit_cast(bf16x8, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
   float* const colsum = P.colsum;
-  const bool do_cs = colsum != nullptr && jt == 0;      // (one column tile per row tile carries the bias gradient)
+  // (the two row halves' sums ride in two DIFFERENT column tiles of the row tile when the output has more than one: the tiles that
+  //  carry a bias gradient then run 2 instead of 4 extra MFMAs per K tile, and a launch is as slow as its slowest workgroup)
+  const bool do_cs0 = colsum != nullptr && jt == 0;
+  const bool do_cs1 = colsum != nullptr && jt == (J > 256 ? 1 : 0);
 
 #define GH_TP_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define GH_TP_RD_A(B_, H_)                                                            \
@@ -150,14 +156,15 @@ gemm_tn_pp_kernel(const Launch L_byval) {
 #define GH_TP_VM10() asm volatile("s_waitcnt vmcnt(10)" ::: "memory")
 #define GH_TP_BAR() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define GH_TP_M(RH_, CH_) do { __builtin_amdgcn_s_setprio(1); GH_TP_QUAD(RH_, CH_) __builtin_amdgcn_s_setprio(0); GH_TP_BAR(); } while (0)
-  // column sums: a fragment register pair holds four consecutive k of the lane's column (two bf16 per dword)
-#define GH_TP_CS1(RH_, MI_)                                                                                                        \
-  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int rd = 0; rd < 2; ++rd) {                              \
-    const uint2 v_ = aF[MI_][kk][rd];                                                                                              \
-    csum[RH_] += (__builtin_bit_cast(float, v_.x << 16) + __builtin_bit_cast(float, v_.x & 0xffff0000u)) +                         \
-                 (__builtin_bit_cast(float, v_.y << 16) + __builtin_bit_cast(float, v_.y & 0xffff0000u)); }
-#define GH_TP_CSUM(RH_) do { if (do_cs) { if (wn == 0) { GH_TP_CS1(RH_, 0) } else if (wn == 1) { GH_TP_CS1(RH_, 1) }               \
+  // column sums (waves of the tiles that carry a bias gradient only): two more MFMAs in the first MFMA section that uses the row half.
+  // (Round 6, measured and replaced: 32 unpack-adds per half-tile on the VALU in the load sections of the two light phases -- a dependent
+  //  add chain as long as the other wave row's MFMA section; a single 2304 x 768 output with its bias gradient 198 -> 225 us.  Picking the
+  //  tile by a run-time index into aF[] instead of this wave-uniform branch chain put the fragment array into scratch: 5 x slower.)
+#define GH_TP_CS1(RH_, MI_) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                     \
+    acs[RH_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones8, GH_TP_FRAG(aF[MI_][kk]), acs[RH_], 0, 0, 0);
+#define GH_TP_CSUM(RH_) do { if ((RH_) == 0 ? do_cs0 : do_cs1) { if (wn == 0) { GH_TP_CS1(RH_, 0) } else if (wn == 1) { GH_TP_CS1(RH_, 1) }               \
                                           else if (wn == 2) { GH_TP_CS1(RH_, 2) } else { GH_TP_CS1(RH_, 3) } } } while (0)
+#define GH_TP_MCS(RH_, CH_) do { __builtin_amdgcn_s_setprio(1); GH_TP_QUAD(RH_, CH_) GH_TP_CSUM(RH_); __builtin_amdgcn_s_setprio(0); GH_TP_BAR(); } while (0)
 
   // ---- prologue: tile 0 entirely, tile 1 except its second A half (phase 1 of tile 0 stages that one)
   stage(0, OPA, H0); stage(0, OPB, H0); stage(0, OPB, H1); stage(0, OPA, H1);
@@ -168,10 +175,10 @@ gemm_tn_pp_kernel(const Launch L_byval) {
   __builtin_amdgcn_sched_barrier(0);
 
 #define GH_TP_TILE(B_)                                                                                                             \
-  /* phase 1 */ GH_TP_RD_B(B_, 0) GH_TP_RD_A(B_, 0) stage(t + 1, OPA, H1); GH_TP_VM10(); GH_TP_WAIT_B(0); GH_TP_WAIT_A(); GH_TP_BAR(); GH_TP_M(0, 0); \
-  /* phase 2 */ GH_TP_RD_B(B_, 1) stage(t + 2, OPA, H0); GH_TP_CSUM(0); GH_TP_VM10(); GH_TP_WAIT_B(1); GH_TP_BAR(); GH_TP_M(0, 1);   \
-  /* phase 3 */ GH_TP_RD_A(B_, 1) stage(t + 2, OPB, H0); GH_TP_WAIT_A(); GH_TP_BAR(); GH_TP_M(1, 1);                               \
-  /* phase 4 */ stage(t + 2, OPB, H1); GH_TP_CSUM(1); GH_TP_VM10(); GH_TP_BAR(); GH_TP_M(1, 0);
+  /* phase 1 */ GH_TP_RD_B(B_, 0) GH_TP_RD_A(B_, 0) stage(t + 1, OPA, H1); GH_TP_VM10(); GH_TP_WAIT_B(0); GH_TP_WAIT_A(); GH_TP_BAR(); GH_TP_MCS(0, 0); \
+  /* phase 2 */ GH_TP_RD_B(B_, 1) stage(t + 2, OPA, H0); GH_TP_VM10(); GH_TP_WAIT_B(1); GH_TP_BAR(); GH_TP_M(0, 1);                   \
+  /* phase 3 */ GH_TP_RD_A(B_, 1) stage(t + 2, OPB, H0); GH_TP_WAIT_A(); GH_TP_BAR(); GH_TP_MCS(1, 1);                             \
+  /* phase 4 */ stage(t + 2, OPB, H1); GH_TP_VM10(); GH_TP_BAR(); GH_TP_M(1, 0);
 
   {
     int t = 0;
@@ -197,10 +204,11 @@ gemm_tn_pp_kernel(const Launch L_byval) {
 #undef GH_TP_M
 #undef GH_TP_CS1
 #undef GH_TP_CSUM
+#undef GH_TP_MCS
 #undef GH_TP_TILE
 
   if (GH_DBG_BITS(L) & 1) {      // (tool build: K loop only)
-    float s = csum[0] + csum[1];
+    float s = acs[0][0] + acs[1][0];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
@@ -208,15 +216,11 @@ gemm_tn_pp_kernel(const Launch L_byval) {
     if (s == 12345.678f) P.C[0] = 0.f;
     return;
   }
-  if (do_cs) {
-    // lane (l15, q) holds the sum over its k = 8 q .. 8 q + 7 (mod 32) of column l15 of tile mi = wn
+  // every element of lane (l15, q)'s result is the whole sum of column l15 of tile mi = wn
 #pragma unroll
-    for (int rh = 0; rh < 2; ++rh) {
-      float v = csum[rh];
-      v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-      const int c = i0 + rh * 128 + wm * 64 + wn * 16 + l15;
-      if (q == 0 && c < I) colsum[(size_t)ks * (size_t)P.colsum_stride + c] = v;
-    }
+  for (int rh = 0; rh < 2; ++rh) {
+    const int c = i0 + rh * 128 + wm * 64 + wn * 16 + l15;
+    if ((rh == 0 ? do_cs0 : do_cs1) && q == 0 && c < I) colsum[(size_t)ks * (size_t)P.colsum_stride + c] = acs[rh][0];
   }
   // partial tile: plain 16-byte stores (four consecutive columns per lane), summed by reduce_partials_kernel
   const int ldc = P.ldc;

@@ -39,7 +39,7 @@ python tools/blas_ref.py 2>&1 | grep -v amdgpu.ids > $O/blas_ref.txt
 # the standalone K-loop prototype of the 256 x 256 ping-pong tile at the cell's shapes (tools/nt256_proto.hip, built into tools/_bin)
 [ -x tools/_bin/nt256_base ] && NT256_VARIANTS="base nostore" tools/nt256_run.sh > $O/nt256_proto.txt 2>&1
 # ... and of the weight-gradient kernel on the same loop (tools/tn256_proto.hip)
-[ -x tools/_bin/tn256_base ] && TN256_VARIANTS="base nostore colsum" tools/tn256_run.sh > $O/tn256_proto.txt 2>&1
+[ -x tools/_bin/tn256_base ] && TN256_VARIANTS="base nostore" tools/tn256_run.sh > $O/tn256_proto.txt 2>&1
 # opt-in fp32x3 with pre-split weights, the library-owned communicator, the aggregation micro-benchmark (tool build)
 timeout 600 python bench.py --gemm-mode fp32x3p --no-cpu-baseline --no-series --no-side-modes > $O/bench_fp32x3p.json 2>> $O/bench_err.log
 timeout 600 python bench.py --collective library --no-cpu-baseline --no-series --no-side-modes 2>> $O/bench_err.log | grep '^{' > $O/bench_collective_library.json

@@ -152,8 +152,8 @@ tn256_kernel(const Params P) {
   // The tile is picked by a wave-uniform BRANCH chain: a run-time index into aF[] put the whole fragment array into scratch (5 x slower).
 #define CS1(RH_, MI_) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int rd = 0; rd < 2; ++rd) {               \
     const uint2 v_ = aF[MI_][ks][rd];                                                                                                    \
-    csum[RH_][0] += __builtin_bit_cast(float, v_.x << 16) + __builtin_bit_cast(float, v_.y << 16);                                       \
-    csum[RH_][1] += __builtin_bit_cast(float, v_.x & 0xffff0000u) + __builtin_bit_cast(float, v_.y & 0xffff0000u); }
+    csum[RH_][0] += (__builtin_bit_cast(float, v_.x << 16) + __builtin_bit_cast(float, v_.x & 0xffff0000u)) +                            \
+                    (__builtin_bit_cast(float, v_.y << 16) + __builtin_bit_cast(float, v_.y & 0xffff0000u)); }
 #define CSUM(RH_) do { if (COLSUM) { if (wn == 0) { CS1(RH_, 0) } else if (wn == 1) { CS1(RH_, 1) } else if (wn == 2) { CS1(RH_, 2) } else { CS1(RH_, 3) } } } while (0)
 
   // ---- prologue: tile 0 entirely, tile 1 except its second A half (phase 1 of tile 0 stages that one)
