@@ -843,6 +843,12 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   // ~8K waves in flight their sliding-window working set (~49 MB) thrashes the 32 MB of L2 (hit rate 32 %).
   static int variant = -1;
   if (variant < 0) { variant = measure_env("GH_SPMM_VARIANT", 4); if (variant > 5) variant = 4; }
+  // bf16 rows: columns per thread of the list kernel (tool build: GH_SPMM_BF16_CPT).  A bf16 column is an 8-byte LDS read and four
+  // unpack instructions in front of its FMAs, the per-edge overhead (list entry, address) weighs more than in fp32:
+  // 960 graphs x h = 768, window 5: 148.6 / 126.9 / 120.0 / 122.2 / 126.2 us at 1 / 2 / 3 / 4 / 6 columns per thread (fewer, longer work
+  // items per row beyond three: the last round of items is thinly filled)
+  static int bf_cpt = -1;
+  if (bf_cpt < 0) { bf_cpt = measure_env("GH_SPMM_BF16_CPT", 3); if (bf_cpt < 1 || bf_cpt > 3) bf_cpt = 3; }
   const int ptag = n < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_SPMM;
   prof_begin(s, ptag);
   if (v4 && variant >= 3 && r <= 256 && (!bf16 || hv % 2 == 0)) {
@@ -882,10 +888,13 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
     const size_t llds = (size_t)r * lslab * (bf16 ? 8 : 16) + (size_t)cap * 8 + (size_t)(r + 1) * 4 + (size_t)r * 4 + 4 + (size_t)r * 8;   // + item table
     const void* fn;
     const int lv = variant > 5 ? 5 : variant;
-    if (bf16) fn = lv == 3 ? (const void*)spmm_list_kernel<true, 1> : lv == 5 ? (const void*)spmm_list_kernel<true, 3> : (const void*)spmm_list_kernel<true, 2>;
+    if (bf16) {
+      const int c = lv == 3 ? 1 : lv == 5 ? 3 : bf_cpt;
+      fn = c == 1 ? (const void*)spmm_list_kernel<true, 1> : c == 3 ? (const void*)spmm_list_kernel<true, 3> : (const void*)spmm_list_kernel<true, 2>;
+    }
     else fn = lv == 3 ? (const void*)spmm_list_kernel<false, 1> : lv == 5 ? (const void*)spmm_list_kernel<false, 3> : (const void*)spmm_list_kernel<false, 2>;
     static bool attrl[6] = {false, false, false, false, false, false};
-    const int ai = (bf16 ? 3 : 0) + (lv - 3);
+    const int ai = bf16 ? (3 + (lv == 3 ? 0 : lv == 5 ? 2 : bf_cpt - 1)) : (lv - 3);
     if (!attrl[ai] && llds > 64 * 1024) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrl[ai] = true; }
     // slabs per workgroup, measured inside the bench step (ms of aggregation per step at 1 / 2 / all slabs per workgroup):
     //   960 graphs, R = 100, h = 300 fp32 (4 slabs): 0.302 / 0.282 / 0.262;   640 graphs, R = 200 (8 slabs): 0.536 / 0.467 / 0.426;
