@@ -846,6 +846,34 @@ def test_bf16_weight_gradient_gemm_exact(m, n, k, pad):
     assert eb <= 2e-5, eb
 
 
+@pytest.mark.parametrize("ws_mib", [16, 3])
+def test_bf16_weight_gradient_gemm_with_a_small_workspace(ws_mib):
+    """The ping-pong weight-gradient kernel only writes partial tiles, so its K split is bounded by the split-K workspace: with 16 MiB a
+    768 x 768 output (2.25 MiB of partials per chunk + its bias-gradient partials) gets 6 chunks instead of 28, with 3 MiB a single one
+    (the reduction then only adds that one tile into the caller's buffer).  Same exact bound as above in both cases; the default
+    workspace is restored afterwards."""
+    from get_amd import _lib, ops
+    m, n, k = 20000, 768, 768
+    gen = torch.Generator(device="cpu").manual_seed(ws_mib)
+    g16 = (torch.randn(m, n, generator=gen) * 0.5).to(torch.bfloat16).to(DEV)
+    x16 = torch.randn(m, k, generator=gen).to(torch.bfloat16).to(DEV)
+    dw, db = torch.zeros(n, k, device=DEV), torch.zeros(n, device=DEV)
+    _lib.ensure_workspace(g16.device)
+    small = torch.empty(ws_mib << 18, device=DEV, dtype=torch.float32)
+    st = _lib.stream()
+    try:
+        _lib.call("gh_set_stream_workspace", st, small.data_ptr(), small.numel() * 4)
+        _lib.call("gh_linear_wgrad_bf16", g16.data_ptr(), n, x16.data_ptr(), k, m, n, k, dw.data_ptr(), k, db.data_ptr(), st)
+        torch.cuda.synchronize()
+    finally:
+        _lib._workspaces.clear()              # the next ensure_workspace registers a default-sized buffer again
+        _lib.ensure_workspace(g16.device)
+    ref_w = g16.double().t() @ x16.double()
+    ref_b = g16.double().sum(0)
+    assert float((dw.double() - ref_w).abs().max()) <= 2e-5 * float(ref_w.abs().max())
+    assert float((db.double() - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max())
+
+
 def test_evd_assemble_bwd_writes_every_row_of_d_avg():
     """gh_evd_assemble_bwd needs no cleared d_avg: the rows of real (claim, slot) pairs receive their gradient, the rows of a claim's
     evidences beyond its n_max-th (no slot in the padded tensor) receive zeros -- checked on a NaN-filled buffer with one claim over
