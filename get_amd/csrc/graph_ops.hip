@@ -577,6 +577,11 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
       }
     }
   };
+#ifdef GH_MEASURE
+  const bool dbg_noagg = (split & 256) != 0, dbg_nodma = (split & 512) != 0;      // tool build: one half of the kernel at a time
+  split &= 255;
+  if (!dbg_nodma)
+#endif
   dma_slab();
   __builtin_amdgcn_sched_barrier(0);
   SPMM_T(0);        // loads issued
@@ -671,12 +676,18 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
     __syncthreads();
     c0 = s_ * slab;
     ncol = min(slab, H4 - c0);
+#ifdef GH_MEASURE
+    if (!dbg_nodma)
+#endif
     dma_slab();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the slab has landed (LDS-DMA is tracked by vmcnt)
   SPMM_T(4);          // slab wait
   __syncthreads();
   SPMM_T(5);          // barrier 2 (the slowest list builder / DMA)
+#ifdef GH_MEASURE
+  if (dbg_noagg) continue;
+#endif
   // ---- aggregate: thread = (item, column group q); columns q, q + TPR, ...
   const int TPR = (ncol + CPT - 1) / CPT;
   const unsigned mg_tpr = magic_of(TPR);
@@ -799,6 +810,211 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
   SPMM_T(6);          // aggregate + stores issued (thread 0)
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Aggregation of the bf16 storage pipeline ON THE MATRIX PIPE (round 6).  The edge-list kernel above is VALU-issue-bound on bf16 rows
+// (PMC on configs[4]: 44 M wave VALU instructions per launch = 72 us of a 122 us launch; every (edge, four columns) item costs a list
+// read, an address, four unpack instructions and two packed FMAs), while the same sum as a DENSE product  y_g = A_g x_g  per graph
+// (A_g: <= 128 x 128 normalised adjacency, 7 % dense; x_g: the graph's rows) is 2 R^2 h flops = 15 MFLOP per graph at h = 768 -- a
+// few microseconds of v_mfma_f32_16x16x32_bf16 even though 93 % of the products are with zeros.
+//   * A never exists in memory: lane (l15, q) BUILDS its MFMA operand -- row i = 16 mi + l15, columns 32 ks + 8 q .. + 7 -- from the
+//     row's refined bit words and the graph's d^-1/2 values (or the dense values), once per workgroup, in registers.  The fp32
+//     weights are split THREE ways into bf16 (hi + mid + lo: w - hi and r1 - mid are exact in fp32, the remainder after lo is below
+//     2^-24 |w|), so the products with the bf16 activations are exact to fp32 precision and the accumulation is fp32: the result is
+//     the edge-list kernel's up to fp32 summation order, then rounded ONCE to bf16.
+//   * x_g is the B operand, k-major as it sits in memory: slabs of 128 columns (256 B per row) by LDS-DMA, fragments by two
+//     ds_read_b64_tr_b16 each, 32-byte units XOR-swizzled on the source side exactly as in gemm_tn_pp.hip.h (256-byte pitch).  Rows
+//     between NR and the next multiple of 32 are DMA'd with the out-of-range offset (zeros: 0 x stale LDS could be NaN).
+//   * Wave w owns the row tiles mi = w and w + 4 (R <= 128) and walks the slab's column tiles; only ceil(NR / 32) k-steps and
+//     ceil(NR / 16) row tiles are computed, so the work follows NR^2 in the node-compact layout.
+// Preconditions (launch_spmm): bf16 rows, R <= 128, h % 8 == 0, 16-byte aligned rows.
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2)
+spmm_mfma_bf16_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
+                      const uint64_t* __restrict__ keep, const int32_t* __restrict__ goff, const unsigned short* __restrict__ x,
+                      unsigned short* __restrict__ y, int R, int H, int transpose, int accumulate, int n, int nslab, int seq) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  constexpr int NT = 8 / WAVES, NTHR = WAVES * 64;      // row tiles per wave: wave w owns mi = w + WAVES t
+  __shared__ __attribute__((aligned(16))) unsigned char xs[128 * 256];      // [row][256 B], rows 0 .. KR - 1 of the current slab
+  __shared__ float dv[128];
+  constexpr unsigned OOB = 0x80000000u;
+  int g, sl;
+  {
+    const int nchunk = (nslab + seq - 1) / seq;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    sl = (j % nchunk) * seq;
+    g = (j / nchunk) * 8 + xcd;
+    if (g >= n) return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  const int W = (R + 63) / 64;                 // 1 or 2 words per bit row
+  const int row0 = goff ? goff[g] : g * R;
+  const int NR = goff ? goff[g + 1] - row0 : R;
+  if (NR <= 0) return;
+  const int nks = (NR + 31) >> 5;              // k-steps of 32 graph rows
+  const int KR = nks * 32;
+
+  // ---- the slab DMA (issued first: the operand build below runs under its flight)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)row0 * H), 0, 0x7fffffff, 0x00020000);
+  auto dma_slab = [&](int c0) __attribute__((always_inline)) {
+    const int chunks = KR * 16;
+    for (int base = 0; base < chunks; base += NTHR) {
+      const int it = base + tid;                       // (chunks is a multiple of 512: no partial iteration)
+      const int i = it >> 4, sl16 = it & 15;
+      const int c = sl16 ^ (((i & 3) << 1) | (((i >> 3) & 1) << 3));
+      const int col = c0 + 8 * c;
+      const unsigned off = (i < NR && col < H) ? (unsigned)(i * H + col) * 2u : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + (base + wave * 64) * 16), 16, off, 0, 0, 0);
+    }
+  };
+  // Issue order = completion order on the vector-memory counter: the few small loads (bit rows, keep words, d^-1/2) go FIRST, the slab's
+  // DMA after them, so that the operand build below waits for the former with a counted vmcnt while the latter is still in flight.
+  const float dvv = (tid < 128 && !vals && tid < NR) ? dinv[(size_t)g * R + tid] : 0.f;
+  unsigned long long mw0[NT], mw1[NT], kw0 = ~0ull, kw1 = ~0ull;
+  if (keep) { kw0 = keep[(size_t)g * W]; if (W > 1) kw1 = keep[(size_t)g * W + 1]; }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int i = 16 * (wave + WAVES * t) + l15;
+    mw0[t] = 0ull; mw1[t] = 0ull;
+    if (i < NR) {
+      mw0[t] = bits[((size_t)g * R + i) * W];
+      if (W > 1) mw1[t] = bits[((size_t)g * R + i) * W + 1];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  dma_slab(sl * 128);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- d^-1/2 of the graph's nodes (pattern mode) for everybody
+  if (tid < 128) dv[tid] = dvv;
+  // (a bare barrier: __syncthreads() would also drain vmcnt, i.e. wait for the slab)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // ---- A operands of this wave's row tiles, three bf16 pieces each: aF[t][ks][piece]
+  uint4 aF[NT][4][3];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int mi = wave + WAVES * t;
+    const int i = 16 * mi + l15;
+    const bool live = i < NR;
+    unsigned long long m0 = mw0[t], m1 = mw1[t];
+    if (live && keep) {
+      const bool ki = (((i < 64 ? kw0 : kw1) >> (i & 63)) & 1ull) != 0;
+      if (!ki) { m0 &= kw0; m1 &= kw1; }                // edge survives iff keep(i) || keep(j)
+    }
+    const float di = live && !vals ? dv[i] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int j0 = 32 * ks + 8 * q;
+      const unsigned byte = (unsigned)(((ks < 2 ? m0 : m1) >> ((32 * (ks & 1)) + 8 * q)) & 0xffull);
+      float w[8];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const bool on = (byte >> b) & 1u;
+        float v = 0.f;
+        if (vals) { if (on) v = transpose ? vals[((size_t)g * R + (j0 + b)) * R + i] : vals[((size_t)g * R + i) * R + (j0 + b)]; }
+        else v = on ? di * dv[j0 + b] : 0.f;
+        w[b] = v;
+      }
+      unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float a0 = w[2 * b], a1 = w[2 * b + 1];
+        const unsigned h2 = pack_bf2(a0, a1);
+        const float r0 = a0 - __builtin_bit_cast(float, h2 << 16), r1 = a1 - __builtin_bit_cast(float, h2 & 0xffff0000u);
+        const unsigned m2 = pack_bf2(r0, r1);
+        const float s0 = r0 - __builtin_bit_cast(float, m2 << 16), s1 = r1 - __builtin_bit_cast(float, m2 & 0xffff0000u);
+        hi[b] = h2; mid[b] = m2; lo[b] = pack_bf2(s0, s1);
+      }
+      aF[t][ks][0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      aF[t][ks][1] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+      aF[t][ks][2] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+  }
+  const bool t0_live = 16 * wave < NR, t1_live = NT > 1 && 16 * (wave + WAVES) < NR;      // wave-uniform
+
+  // ---- transpose-read base: lane (p = l15, g = q) points at row 8 q + (p >> 2) (+4: second read, +32 ks), four columns 4 (p & 3)
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)xs;
+  const int f5 = (l15 >> 2) | ((q & 1) << 2);
+  const unsigned rbase = lds0 + (unsigned)((8 * q + (l15 >> 2)) * 256 + 8 * (l15 & 3));
+  auto tr_read = [&](unsigned addr) __attribute__((always_inline)) {
+    uint2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+  };
+
+  const int sl_end = min(nslab, sl + seq);
+  for (int s_ = sl; s_ < sl_end; ++s_) {
+    const int c0 = s_ * 128;
+    if (s_ > sl) {
+      __syncthreads();                    // every wave is done with the previous slab's image
+      dma_slab(c0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int ntile = (min(128, H - c0) + 15) >> 4;
+    // column tiles in pairs over two fragment sets: the next tile's transpose reads (and, accumulating, its y values) are in flight
+    // while the current tile's MFMAs run
+    auto load_b = [&](int ni, uint2* b0, uint2* b1) __attribute__((always_inline)) {
+      const unsigned ad = rbase + (unsigned)(((ni ^ f5) & 7) << 5);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        if (ks < nks) { b0[ks] = tr_read(ad + ks * 8192); b1[ks] = tr_read(ad + ks * 8192 + 1024); }
+        else { b0[ks] = make_uint2(0u, 0u); b1[ks] = make_uint2(0u, 0u); }
+    };
+    auto tile = [&](int ni, uint2* b0, uint2* b1, uint2* nb0, uint2* nb1) __attribute__((always_inline)) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(b1[0]), "+v"(b1[1]), "+v"(b1[2]), "+v"(b1[3]) :: "memory");
+      if (ni + 1 < ntile) load_b(ni + 1, nb0, nb1);
+      // acc[r] = y[row 16 mi + l15][column c0 + 16 ni + 4 q + r]: four consecutive bf16 = one 8-byte access
+      const int col = c0 + 16 * ni + 4 * q;
+      const int i0r = 16 * wave + l15, i1r = i0r + 16 * WAVES;
+      const bool ok0 = i0r < NR && col < H, ok1 = NT > 1 && i1r < NR && col < H;
+      uint2* o0 = reinterpret_cast<uint2*>(y + ((size_t)row0 + i0r) * H + col);
+      uint2* o1 = reinterpret_cast<uint2*>(y + ((size_t)row0 + i1r) * H + col);
+      uint2 p0 = make_uint2(0u, 0u), p1 = make_uint2(0u, 0u);
+      if (accumulate) { if (ok0) p0 = *o0; if (ok1) p1 = *o1; }
+      f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < nks) {
+          const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, make_uint4(b0[ks].x, b0[ks].y, b1[ks].x, b1[ks].y));
+          // (smallest pieces first: the fp32 accumulator sees lo + mid before hi)
+          if (t0_live) {
+#pragma unroll
+            for (int pc = 2; pc >= 0; --pc) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, __builtin_bit_cast(bf16x8_t, aF[0][ks][pc]), acc0, 0, 0, 0);
+          }
+          if constexpr (NT > 1) {
+            if (t1_live) {
+#pragma unroll
+              for (int pc = 2; pc >= 0; --pc) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, __builtin_bit_cast(bf16x8_t, aF[NT - 1][ks][pc]), acc1, 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (ok0) {
+        float4 v = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+        if (accumulate) { const float4 pv = bf4_to_f4(p0); v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w; }
+        *o0 = f4_to_bf4(v);
+      }
+      if (ok1) {
+        float4 v = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+        if (accumulate) { const float4 pv = bf4_to_f4(p1); v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w; }
+        *o1 = f4_to_bf4(v);
+      }
+    };
+    uint2 bA0[4], bA1[4], bB0[4], bB1[4];
+    load_b(0, bA0, bA1);
+    for (int ni = 0; ni < ntile; ni += 2) {
+      tile(ni, bA0, bA1, bB0, bB1);
+      if (ni + 1 < ntile) tile(ni + 1, bB0, bB1, bA0, bA1);
+    }
+  }
+#endif
+}
+
 #ifdef GH_MEASURE
 extern "C" int gh_debug_spmm_phases(unsigned* out, int reset) {     // out: [8192][8]
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spmm_phase), 8192 * 8 * sizeof(unsigned)) != hipSuccess) return 1;
@@ -851,6 +1067,26 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   if (bf_cpt < 0) { bf_cpt = measure_env("GH_SPMM_BF16_CPT", 3); if (bf_cpt < 1 || bf_cpt > 3) bf_cpt = 3; }
   const int ptag = n < PROF_FEW_GROUPS ? PROF_FEW_ROWS : PROF_SPMM;
   prof_begin(s, ptag);
+  static int mfma_agg = -1;
+  if (mfma_agg < 0) mfma_agg = measure_env("GH_SPMM_MFMA", 1);
+  if (bf16 && mfma_agg && r <= 128 && h % 8 == 0 && variant >= 3) {
+    // bf16 rows: the aggregation as a dense product per graph on the matrix pipe (spmm_mfma_bf16_kernel)
+    const int ns = (h + 127) / 128;
+    static int mseq = -1;
+    if (mseq < 0) mseq = measure_env("GH_SPMM_MFMA_SEQ", 3);
+    int seq = n < 256 ? 1 : mseq;
+    if (seq > ns) seq = ns;
+    if (seq < 1) seq = 1;
+    const int nchunk = (ns + seq - 1) / seq;
+    const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x);
+    unsigned short* y16 = reinterpret_cast<unsigned short*>(y);
+    static int mw = -1;
+    if (mw < 0) mw = measure_env("GH_SPMM_MFMA_WAVES", 4);
+    if (mw == 8) hipLaunchKernelGGL(spmm_mfma_bf16_kernel<8>, dim3(((n + 7) / 8) * 8 * nchunk), dim3(512), 0, s, bits, dinv, vals, keep, goff, x16, y16, r, h,
+                                    transpose, accumulate, n, ns, seq);
+    else hipLaunchKernelGGL(spmm_mfma_bf16_kernel<4>, dim3(((n + 7) / 8) * 8 * nchunk), dim3(256), 0, s, bits, dinv, vals, keep, goff, x16, y16, r, h,
+                            transpose, accumulate, n, ns, seq);
+  } else
   if (v4 && variant >= 3 && r <= 256 && (!bf16 || hv % 2 == 0)) {
     // edge-list kernel; variant 3: one column per thread, 4 (default): two, 5: three.  LDS pitch = slab columns.
     const int cap = 10 * r;                        // edges per graph the list holds (a window-5 word graph has <= 9 R)
@@ -901,7 +1137,7 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
     //   960 graphs, h = 768 bf16 image, window 5 (5 slabs): 0.634 / 0.620 / 0.698 -- long per-slab work: the whole graph in one
     //   workgroup leaves one thinly balanced round.  Few-graph launches (claim side) keep one slab per workgroup: latency.
     static int split = -1, spw_env = -1;
-    if (split < 0) split = measure_env("GH_SPMM_SPLIT", 1);
+    if (split < 0) split = measure_env("GH_SPMM_SPLIT", 1) | (measure_env("GH_SPMM_DBG", 0) << 8);
     if (spw_env < 0) spw_env = measure_env("GH_SPMM_SPW", 0);
     int ns_arg = (int)lgrid.y;
     int seq = spw_env > 0 ? spw_env : (n < 256 ? 1 : (bf16 ? 2 : ns_arg));

@@ -108,8 +108,10 @@ int gh_spmm(const uint64_t* bits, const float* dinv, const float* vals, const ui
             int accumulate, gh_stream_t stream);
 
 /* The same aggregation on the bf16 storage pipeline's activations (what gh_ggnn_cell_fwd_bf16 / _bwd_bf16 run internally, exposed for
- * the exact parity test and the micro-benchmark): x16, y16 hold bf16, 16-byte aligned rows, h % 8 == 0; sums in fp32 in the fp32
- * kernel's order, one rounding to bf16 at the store (accumulate: y16 is read, added in fp32, rounded once). */
+ * the parity test and the micro-benchmark): x16, y16 hold bf16, 16-byte aligned rows, h % 8 == 0.  Graphs of r <= 128 nodes run as a
+ * dense product per graph on the matrix pipe (the fp32 edge weights split three ways into bf16: products exact to fp32 precision,
+ * fp32 accumulation), larger ones on the edge-list kernel (fp32 sums in the fp32 kernel's order); either way ONE rounding to bf16
+ * at the store (accumulate: y16 is read, added in fp32, rounded once). */
 int gh_spmm_bf16(const uint64_t* bits, const float* dinv, const float* vals, const uint64_t* keep,
                  const int32_t* goff, int m_real, const void* x16, void* y16, int n, int r, int h, int transpose,
                  int accumulate, gh_stream_t stream);

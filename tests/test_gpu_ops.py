@@ -525,10 +525,11 @@ def test_compact_spmm_equals_padded(h):
 
 @pytest.mark.parametrize("h,n_graphs,window", [(768, 300, 5), (256, 40, 3), (520, 9, 5)])
 def test_spmm_bf16_is_the_fp32_aggregation_rounded_once(h, n_graphs, window):
-    """gh_spmm_bf16 (the aggregation of the bf16 storage pipeline: bf16 rows in HBM and in the LDS slab image, whole-line slabs at
-    h = 768) against gh_spmm on the same bf16 values held in fp32: the sums are formed in fp32 in the same order, so the bf16 result
-    must be the fp32 result rounded ONCE (round-to-nearest-even) -- bit for bit, in the padded and the node-compact layout, with a
-    keep set, transposed, and accumulating (y16 read, added in fp32, rounded once).  Hub rows included (split work items)."""
+    """gh_spmm_bf16 (the aggregation of the bf16 storage pipeline; R <= 128: a dense product per graph on the matrix pipe with the
+    fp32 edge weights split three ways into bf16, csrc/graph_ops.hip spmm_mfma_bf16_kernel) against gh_spmm on the same bf16 values held
+    in fp32: products exact to fp32 precision, fp32 accumulation, ONE rounding to bf16 -- so the result is the fp32 kernel's rounded
+    once, except where the different fp32 summation order moves a sum across a rounding boundary: never more than one bf16 ulp, and
+    for at most 0.2 % of the elements.  Padded and node-compact layout, with a keep set, transposed, accumulating.  Hub rows included."""
     from get_amd import _lib, ops
     rng = np.random.default_rng(4000 + h)
     n, r = n_graphs, 100
@@ -552,12 +553,19 @@ def test_spmm_bf16_is_the_fp32_aggregation_rounded_once(h, n_graphs, window):
                 y16 = yin.clone() if acc else torch.empty_like(xin)
                 _lib.call("gh_spmm_bf16", *a._args(), *ops._plan_args(pl), _lib.ptr(xin), _lib.ptr(y16), n, r, h, tr, acc, _lib.stream())
                 torch.cuda.synchronize()
-                rows = slice(None) if pl is not None else None
+                # scale of the sum: the same aggregation of |x| (the weights are positive), plus |y| when accumulating
+                s32 = yin.float().abs().contiguous() if acc else torch.empty_like(x32)
+                _lib.call("gh_spmm", *a._args(), *ops._plan_args(pl), _lib.ptr(x32.abs().contiguous()), _lib.ptr(s32), n, r, h, tr, acc, _lib.stream())
+                torch.cuda.synchronize()
                 want = y32.to(torch.bfloat16)
-                if pl is None:      # (padding rows of the padded layout: both kernels write them, compare everything)
-                    assert torch.equal(y16.view(torch.int16), want.view(torch.int16)), (tr, acc)
-                else:
-                    assert torch.equal(y16.view(torch.int16)[rows], want.view(torch.int16)[rows]), (tr, acc)
+                # (1) against the fp32 sum: half a bf16 ulp of the result + fp32-level error of the sum (cancelling sums included)
+                err = (y16.float() - y32).abs()
+                assert bool((err <= y32.abs() * 2.0 ** -8 + s32 * 4e-6 + 1e-30).all()), (tr, acc, float((err - y32.abs() * 2.0 ** -8 - s32 * 4e-6).max()))
+                # (2) against the fp32 kernel's result rounded once: identical bits except at rounding ties (sums that do not cancel)
+                solid = y32.abs() > 1e-2 * s32
+                d = (y16.view(torch.int16).int() - want.view(torch.int16).int()).abs()
+                assert int(d[solid].max()) <= 1, (tr, acc, int(d[solid].max()))
+                assert float((d[solid] != 0).float().mean()) <= 2e-3, (tr, acc, float((d[solid] != 0).float().mean()))
 
 
 @pytest.mark.parametrize("n_graphs", [9, 300])
