@@ -568,6 +568,36 @@ def test_spmm_bf16_is_the_fp32_aggregation_rounded_once(h, n_graphs, window):
                 assert float((d[solid] != 0).float().mean()) <= 2e-3, (tr, acc, float((d[solid] != 0).float().mean()))
 
 
+@pytest.mark.parametrize("r", [30, 64, 128, 130])
+def test_spmm_bf16_weighted_asymmetric_adjacency(r):
+    """gh_spmm_bf16 on a dense WEIGHTED adjacency with an asymmetric pattern (reference-API hand-over: values, not d^-1/2 products),
+    forward and transposed, against a float64 product of the same bf16 activations: half a bf16 ulp of the result + 4e-6 of the
+    sum's scale.  r = 30 / 64 / 128: one and two bit words per row, k-steps that end exactly at and before the tile edge (the matrix-pipe
+    kernel); r = 130: the edge-list kernel.  13 graphs: not a multiple of the 8 XCD queues."""
+    from get_amd import _lib, ops
+    rng = np.random.default_rng(700 + r)
+    n, h = 13, 264
+    a = rng.standard_normal((n, r, r)) * (rng.random((n, r, r)) < 0.08)
+    a[:, np.arange(r), np.arange(r)] = 1.0
+    a[:, :, r - 1] = 0.0
+    a[:, r - 1, : r // 2] = 0.5
+    a[3] = 0.0                                                                       # a graph without any edge
+    pw = ops.PackedAdj.from_dense(T(a))
+    a32 = pw.to_dense().double()
+    x16 = T(rng.standard_normal((n, r, h)).astype(np.float32)).to(torch.bfloat16)
+    y0 = T(rng.standard_normal((n, r, h)).astype(np.float32)).to(torch.bfloat16)
+    for tr, acc in ((0, 0), (1, 0), (1, 1)):
+        y16 = y0.clone() if acc else torch.full_like(x16, float("nan"))
+        _lib.call("gh_spmm_bf16", *pw._args(), None, 0, _lib.ptr(x16), _lib.ptr(y16), n, r, h, tr, acc, _lib.stream())
+        torch.cuda.synchronize()
+        am = a32.transpose(1, 2) if tr else a32
+        ref = am @ x16.double() + (y0.double() if acc else 0.0)
+        scale = am.abs() @ x16.double().abs() + (y0.double().abs() if acc else 0.0)
+        err = (y16.double() - ref).abs()
+        assert bool(torch.isfinite(y16.float()).all()), (tr, acc)
+        assert bool((err <= ref.abs() * 2.0 ** -8 + scale * 4e-6 + 1e-30).all()), (tr, acc, float((err - ref.abs() * 2.0 ** -8 - scale * 4e-6).max()))
+
+
 @pytest.mark.parametrize("n_graphs", [9, 300])
 def test_spmm_hub_rows_split_over_work_items_match_dense_fp64(n_graphs):
     """Word graphs with a hub node (a token at every third position: degree ~2/3 of the nodes).  In the node-compact layout

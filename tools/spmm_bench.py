@@ -95,6 +95,8 @@ try:
     a = np.frombuffer(buf, dtype=np.uint32).reshape(8192, 8)[:, :7].astype(np.float64)
     a = a[a.sum(1) > 0]
     names = ["issue", "rowwords+scan", "barrier1", "listbuild", "slabwait", "barrier2", "aggregate"]
+    if a.shape[0] == 0:
+        raise RuntimeError("no phase ticks: the matrix-pipe kernel ran (GH_SPMM_MFMA=0 selects the instrumented edge-list kernel)")
     print(f"bf16 phases, thread 0 of each of {a.shape[0]} workgroups (two slabs each: the slab phases hold the LAST slab), mean / p90: " + ", ".join(f"{nm} {a[:, i].mean():.2f}/{np.percentile(a[:, i], 90):.2f}" for i, nm in enumerate(names)) + f"  total {a.sum(1).mean():.2f}")
 except Exception as e:
     print("bf16 section failed:", e)
