@@ -827,7 +827,9 @@ spmm_list_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ di
 //   * Wave w owns the row tiles mi = w and w + 4 (R <= 128) and walks the slab's column tiles; only ceil(NR / 32) k-steps and
 //     ceil(NR / 16) row tiles are computed, so the work follows NR^2 in the node-compact layout.
 // Preconditions (launch_spmm): bf16 rows, R <= 128, h % 8 == 0, 16-byte aligned rows.
-template <int WAVES>
+// PIPE: slabs of 64 columns (128 B per row) in TWO 16 KB buffers -- the next slab's DMA is in flight under the current slab's MFMAs (same LDS
+// footprint as one 128-column slab; 32-byte units swizzled with ((r >> 1) & 1) | ((r >> 3) & 1) << 1: rows alternate between the two bank halves)
+template <int WAVES, bool PIPE>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2)
 spmm_mfma_bf16_kernel(const uint64_t* __restrict__ bits, const float* __restrict__ dinv, const float* __restrict__ vals,
                       const uint64_t* __restrict__ keep, const int32_t* __restrict__ goff, const unsigned short* __restrict__ x,
@@ -836,7 +838,8 @@ spmm_mfma_bf16_kernel(const uint64_t* __restrict__ bits, const float* __restrict
   typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
   typedef float f32x4_t __attribute__((ext_vector_type(4)));
   constexpr int NT = 8 / WAVES, NTHR = WAVES * 64;      // row tiles per wave: wave w owns mi = w + WAVES t
-  __shared__ __attribute__((aligned(16))) unsigned char xs[128 * 256];      // [row][256 B], rows 0 .. KR - 1 of the current slab
+  constexpr int SC = PIPE ? 64 : 128, PITCH = SC * 2, CPR = PITCH / 16, BUFB = 128 * PITCH;      // slab columns, bytes per row, 16-byte chunks per row
+  __shared__ __attribute__((aligned(16))) unsigned char xs[128 * 256];      // [buffer][row][PITCH], rows 0 .. KR - 1 of a slab
   __shared__ float dv[128];
   constexpr unsigned OOB = 0x80000000u;
   int g, sl;
@@ -850,6 +853,10 @@ spmm_mfma_bf16_kernel(const uint64_t* __restrict__ bits, const float* __restrict
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, q = lane >> 4;
+  // row-tile owner: rotated by the graph's position in its XCD queue.  In the node-compact layout most graphs have five row tiles (65 nodes
+  // on average), i.e. ONE wave with two tiles, and wave w of every workgroup runs on SIMD w.  (Measured: no effect -- the tile loop is not
+  // bound by the matrix pipe of one SIMD; kept because it costs nothing.)
+  const int wv = (wave + (g >> 3)) % WAVES;
   const int W = (R + 63) / 64;                 // 1 or 2 words per bit row
   const int row0 = goff ? goff[g] : g * R;
   const int NR = goff ? goff[g + 1] - row0 : R;
@@ -859,15 +866,16 @@ spmm_mfma_bf16_kernel(const uint64_t* __restrict__ bits, const float* __restrict
 
   // ---- the slab DMA (issued first: the operand build below runs under its flight)
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)row0 * H), 0, 0x7fffffff, 0x00020000);
-  auto dma_slab = [&](int c0) __attribute__((always_inline)) {
-    const int chunks = KR * 16;
+  auto dma_slab = [&](int c0, int buf) __attribute__((always_inline)) {
+    const int chunks = KR * CPR;
     for (int base = 0; base < chunks; base += NTHR) {
-      const int it = base + tid;                       // (chunks is a multiple of 512: no partial iteration)
-      const int i = it >> 4, sl16 = it & 15;
-      const int c = sl16 ^ (((i & 3) << 1) | (((i >> 3) & 1) << 3));
+      const int it = base + tid;                       // (chunks is a multiple of the workgroup size: no partial iteration)
+      const int i = it / CPR, sl16 = it % CPR;
+      const int fz = PIPE ? ((((i >> 1) & 1) | (((i >> 3) & 1) << 1)) << 1) : (((i & 3) << 1) | (((i >> 3) & 1) << 3));
+      const int c = sl16 ^ fz;
       const int col = c0 + 8 * c;
       const unsigned off = (i < NR && col < H) ? (unsigned)(i * H + col) * 2u : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + (base + wave * 64) * 16), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + buf * BUFB + (base + wave * 64) * 16), 16, off, 0, 0, 0);
     }
   };
   // Issue order = completion order on the vector-memory counter: the few small loads (bit rows, keep words, d^-1/2) go FIRST, the slab's
@@ -877,7 +885,7 @@ spmm_mfma_bf16_kernel(const uint64_t* __restrict__ bits, const float* __restrict
   if (keep) { kw0 = keep[(size_t)g * W]; if (W > 1) kw1 = keep[(size_t)g * W + 1]; }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int i = 16 * (wave + WAVES * t) + l15;
+    const int i = 16 * (wv + WAVES * t) + l15;
     mw0[t] = 0ull; mw1[t] = 0ull;
     if (i < NR) {
       mw0[t] = bits[((size_t)g * R + i) * W];
@@ -885,7 +893,7 @@ spmm_mfma_bf16_kernel(const uint64_t* __restrict__ bits, const float* __restrict
     }
   }
   __builtin_amdgcn_sched_barrier(0);
-  dma_slab(sl * 128);
+  dma_slab(sl * SC, 0);
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- d^-1/2 of the graph's nodes (pattern mode) for everybody
@@ -897,7 +905,7 @@ spmm_mfma_bf16_kernel(const uint64_t* __restrict__ bits, const float* __restrict
   uint4 aF[NT][4][3];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int mi = wave + WAVES * t;
+    const int mi = wv + WAVES * t;
     const int i = 16 * mi + l15;
     const bool live = i < NR;
     unsigned long long m0 = mw0[t], m1 = mw1[t];
@@ -934,12 +942,12 @@ spmm_mfma_bf16_kernel(const uint64_t* __restrict__ bits, const float* __restrict
       aF[t][ks][2] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
   }
-  const bool t0_live = 16 * wave < NR, t1_live = NT > 1 && 16 * (wave + WAVES) < NR;      // wave-uniform
+  const bool t0_live = 16 * wv < NR, t1_live = NT > 1 && 16 * (wv + WAVES) < NR;      // wave-uniform
 
   // ---- transpose-read base: lane (p = l15, g = q) points at row 8 q + (p >> 2) (+4: second read, +32 ks), four columns 4 (p & 3)
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)xs;
-  const int f5 = (l15 >> 2) | ((q & 1) << 2);
-  const unsigned rbase = lds0 + (unsigned)((8 * q + (l15 >> 2)) * 256 + 8 * (l15 & 3));
+  const int f5 = PIPE ? (((l15 >> 3) & 1) | ((q & 1) << 1)) : ((l15 >> 2) | ((q & 1) << 2));
+  const unsigned rbase = lds0 + (unsigned)((8 * q + (l15 >> 2)) * PITCH + 8 * (l15 & 3));
   auto tr_read = [&](unsigned addr) __attribute__((always_inline)) {
     uint2 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
@@ -948,21 +956,37 @@ spmm_mfma_bf16_kernel(const uint64_t* __restrict__ bits, const float* __restrict
 
   const int sl_end = min(nslab, sl + seq);
   for (int s_ = sl; s_ < sl_end; ++s_) {
-    const int c0 = s_ * 128;
-    if (s_ > sl) {
-      __syncthreads();                    // every wave is done with the previous slab's image
-      dma_slab(c0);
+    const int c0 = s_ * SC;
+    const unsigned bufo = PIPE ? (unsigned)(((s_ - sl) & 1) * BUFB) : 0u;
+    if constexpr (PIPE) {
+      // the other buffer was last read in the previous iteration, which ended with a barrier: restage it now.  The wait below lets
+      // exactly the next slab's DMA instructions of this wave (KR * CPR / NTHR = nks of them) stay in flight; everything older -- this
+      // slab's DMA and the previous slab's stores -- has then completed (vmcnt retires in order).
+      if (s_ + 1 < sl_end) {
+        dma_slab(c0 + SC, ((s_ - sl) & 1) ^ 1);
+        static_assert(!PIPE || WAVES == 4, "the counted wait below assumes nks DMA instructions per wave and slab");
+        if (nks == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (nks == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (nks == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+    } else {
+      if (s_ > sl) {
+        __syncthreads();                    // every wave is done with the previous slab's image
+        dma_slab(c0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int ntile = (min(128, H - c0) + 15) >> 4;
+    const int ntile = (min(SC, H - c0) + 15) >> 4;
     // column tiles in pairs over two fragment sets: the next tile's transpose reads (and, accumulating, its y values) are in flight
     // while the current tile's MFMAs run
     auto load_b = [&](int ni, uint2* b0, uint2* b1) __attribute__((always_inline)) {
-      const unsigned ad = rbase + (unsigned)(((ni ^ f5) & 7) << 5);
+      const unsigned ad = rbase + bufo + (unsigned)(((ni ^ f5) & (PIPE ? 3 : 7)) << 5);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
-        if (ks < nks) { b0[ks] = tr_read(ad + ks * 8192); b1[ks] = tr_read(ad + ks * 8192 + 1024); }
+        if (ks < nks) { b0[ks] = tr_read(ad + ks * 32 * PITCH); b1[ks] = tr_read(ad + ks * 32 * PITCH + 4 * PITCH); }
         else { b0[ks] = make_uint2(0u, 0u); b1[ks] = make_uint2(0u, 0u); }
     };
     auto tile = [&](int ni, uint2* b0, uint2* b1, uint2* nb0, uint2* nb1) __attribute__((always_inline)) {
@@ -970,12 +994,12 @@ spmm_mfma_bf16_kernel(const uint64_t* __restrict__ bits, const float* __restrict
       if (ni + 1 < ntile) load_b(ni + 1, nb0, nb1);
       // acc[r] = y[row 16 mi + l15][column c0 + 16 ni + 4 q + r]: four consecutive bf16 = one 8-byte access
       const int col = c0 + 16 * ni + 4 * q;
-      const int i0r = 16 * wave + l15, i1r = i0r + 16 * WAVES;
+      const int i0r = 16 * wv + l15, i1r = i0r + 16 * WAVES;
       const bool ok0 = i0r < NR && col < H, ok1 = NT > 1 && i1r < NR && col < H;
       uint2* o0 = reinterpret_cast<uint2*>(y + ((size_t)row0 + i0r) * H + col);
       uint2* o1 = reinterpret_cast<uint2*>(y + ((size_t)row0 + i1r) * H + col);
       uint2 p0 = make_uint2(0u, 0u), p1 = make_uint2(0u, 0u);
-      if (accumulate) { if (ok0) p0 = *o0; if (ok1) p1 = *o1; }
+      if (accumulate & 1) { if (ok0) p0 = *o0; if (ok1) p1 = *o1; }
       f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -994,23 +1018,33 @@ spmm_mfma_bf16_kernel(const uint64_t* __restrict__ bits, const float* __restrict
           }
         }
       }
+#ifdef GH_MEASURE
+      if (accumulate & 256) {      // tool build: everything but the stores
+        if (acc0[0] + acc1[0] == 12345.678f) *o0 = make_uint2(0u, 0u);
+        return;
+      }
+#endif
       if (ok0) {
         float4 v = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
-        if (accumulate) { const float4 pv = bf4_to_f4(p0); v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w; }
+        if (accumulate & 1) { const float4 pv = bf4_to_f4(p0); v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w; }
         *o0 = f4_to_bf4(v);
       }
       if (ok1) {
         float4 v = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
-        if (accumulate) { const float4 pv = bf4_to_f4(p1); v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w; }
+        if (accumulate & 1) { const float4 pv = bf4_to_f4(p1); v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w; }
         *o1 = f4_to_bf4(v);
       }
     };
+#ifdef GH_MEASURE
+    if (accumulate & 512) { if constexpr (PIPE) asm volatile("s_barrier" ::: "memory"); continue; }      // tool build: set-up + slab DMA only
+#endif
     uint2 bA0[4], bA1[4], bB0[4], bB1[4];
     load_b(0, bA0, bA1);
     for (int ni = 0; ni < ntile; ni += 2) {
       tile(ni, bA0, bA1, bB0, bB1);
       if (ni + 1 < ntile) tile(ni + 1, bB0, bB1, bA0, bA1);
     }
+    if constexpr (PIPE) asm volatile("s_barrier" ::: "memory");      // (every transpose read of this buffer was waited for in tile())
   }
 #endif
 }
@@ -1071,21 +1105,33 @@ int launch_spmm(const uint64_t* bits, const float* dinv, const float* vals, cons
   if (mfma_agg < 0) mfma_agg = measure_env("GH_SPMM_MFMA", 1);
   if (bf16 && mfma_agg && r <= 128 && h % 8 == 0 && variant >= 3) {
     // bf16 rows: the aggregation as a dense product per graph on the matrix pipe (spmm_mfma_bf16_kernel)
-    const int ns = (h + 127) / 128;
-    static int mseq = -1;
+    static int mseq = -1, mw = -1, mpipe = -1;
     if (mseq < 0) mseq = measure_env("GH_SPMM_MFMA_SEQ", 3);
-    int seq = n < 256 ? 1 : mseq;
+    if (mw < 0) mw = measure_env("GH_SPMM_MFMA_WAVES", 4);
+    if (mpipe < 0) mpipe = measure_env("GH_SPMM_MFMA_PIPE", 0);
+    const bool pipe = mpipe != 0 && mw != 8;
+    const int sc = pipe ? 64 : 128;
+    const int ns = (h + sc - 1) / sc;
+    int seq = n < 256 ? 1 : (pipe ? 2 * mseq : mseq);
     if (seq > ns) seq = ns;
     if (seq < 1) seq = 1;
     const int nchunk = (ns + seq - 1) / seq;
     const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x);
     unsigned short* y16 = reinterpret_cast<unsigned short*>(y);
-    static int mw = -1;
-    if (mw < 0) mw = measure_env("GH_SPMM_MFMA_WAVES", 4);
-    if (mw == 8) hipLaunchKernelGGL(spmm_mfma_bf16_kernel<8>, dim3(((n + 7) / 8) * 8 * nchunk), dim3(512), 0, s, bits, dinv, vals, keep, goff, x16, y16, r, h,
-                                    transpose, accumulate, n, ns, seq);
-    else hipLaunchKernelGGL(spmm_mfma_bf16_kernel<4>, dim3(((n + 7) / 8) * 8 * nchunk), dim3(256), 0, s, bits, dinv, vals, keep, goff, x16, y16, r, h,
-                            transpose, accumulate, n, ns, seq);
+    const dim3 mgrid(((n + 7) / 8) * 8 * nchunk);
+#ifdef GH_MEASURE
+    static int mdbg = -1;
+    if (mdbg < 0) mdbg = measure_env("GH_SPMM_MFMA_NOSTORE", 0);
+    if (mdbg) accumulate |= 256 * mdbg;
+#endif
+    // (measured equal and kept in the tool build only, DESIGN 4.5: eight waves per workgroup with one row tile each -- GH_SPMM_MFMA_WAVES=8 --
+    //  and 64-column slabs in two buffers with the next slab's DMA under the current slab's MFMAs -- GH_SPMM_MFMA_PIPE=1)
+#ifdef GH_MEASURE
+    if (mw == 8) hipLaunchKernelGGL((spmm_mfma_bf16_kernel<8, false>), mgrid, dim3(512), 0, s, bits, dinv, vals, keep, goff, x16, y16, r, h, transpose, accumulate, n, ns, seq);
+    else if (pipe) hipLaunchKernelGGL((spmm_mfma_bf16_kernel<4, true>), mgrid, dim3(256), 0, s, bits, dinv, vals, keep, goff, x16, y16, r, h, transpose, accumulate, n, ns, seq);
+    else
+#endif
+    hipLaunchKernelGGL((spmm_mfma_bf16_kernel<4, false>), mgrid, dim3(256), 0, s, bits, dinv, vals, keep, goff, x16, y16, r, h, transpose, accumulate, n, ns, seq);
   } else
   if (v4 && variant >= 3 && r <= 256 && (!bf16 || hv % 2 == 0)) {
     // edge-list kernel; variant 3: one column per thread, 4 (default): two, 5: three.  LDS pitch = slab columns.
