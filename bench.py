@@ -1143,6 +1143,16 @@ def main():
             cb["speedup_gpu_over_cpu"] = value / cb["value"]
             out["cpu_baseline"] = cb
             out["cpu_baseline_probe"] = probe
+        if args.measure_build and os.environ.get("GH_NT_PHASES"):
+            # tool build: per-kind tick sums of the 256-tile epilogue over everything run so far (gemm_nt_pp_epi.hip.h)
+            import ctypes
+            from get_amd import _lib as _l
+            L_ = _l.load()
+            buf = (ctypes.c_ulonglong * 64)()
+            L_.gh_debug_nt_phases.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            torch.cuda.synchronize()
+            if L_.gh_debug_nt_phases(buf, 0) == 0:
+                out["nt_epilogue_phase_ticks"] = {str(k): [int(buf[k * 4 + j]) for j in range(4)] for k in range(16) if buf[k * 4 + 2]}
         if args.measure_build:
             out["metric"] = "MEASUREMENT BUILD (not a product number): " + out["metric"]
             out["measurement_switches"] = {k: os.environ[k] for k in leaked}

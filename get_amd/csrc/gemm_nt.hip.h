@@ -25,6 +25,11 @@
 #include "gemm.hip.h"
 
 namespace gh {
+#ifdef GH_MEASURE
+// tool build: s_memtime ticks (10 ns) of the 256-tile epilogue, summed over the workgroups of every launch since the last reset (thread 0):
+// [kind][0] = staging (accumulators -> LDS between two barriers), [1] = input requests + compute + stores, [2] = passes, [3] = K loop
+__device__ unsigned long long g_nt_phase[16 * 4];
+#endif
 
 __device__ __forceinline__ int nt_swz(int j) { return (0x78 >> (2 * j)) & 3; }     // {0,2,3,1}
 __device__ __forceinline__ unsigned nt_pack_bf16(float a, float b) {

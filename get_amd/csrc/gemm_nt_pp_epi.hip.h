@@ -88,7 +88,18 @@
     const rsrc_t rs_o0 = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, 0x7fffffff, 0x00020000);
     const rsrc_t rs_o1 = __builtin_amdgcn_make_buffer_rsrc((void*)(NOUT >= 2 ? (void*)out1 : (void*)C), 0, 0x7fffffff, 0x00020000);
     const rsrc_t rs_o2 = __builtin_amdgcn_make_buffer_rsrc((void*)(NOUT >= 3 ? (void*)P.out2 : (void*)C), 0, 0x7fffffff, 0x00020000);
-    pp_u32x4 ra[2][2], rb[2][2], rc[2][2], rg[2][2][2];      // [register set][item]; gin: two 16-byte halves of eight fp32
+    // PREFETCH DISTANCE.  The tool build's tick sums per epilogue kind (thread 0, configs[4] bf16 step): a pass of a kind WITHOUT input
+    // streams (sigmoid z, the attention's t) spends ~1.0 us behind its staging barriers, a pass WITH them 2.1 - 4.5 us -- with the inputs of
+    // pass p + 1 requested only one pass (~2.5 us) ahead, every pass still waited for its loads.  Kinds whose inputs are few registers
+    // therefore request them further ahead: PD passes, PD + 1 register sets of 2 items x (input streams) x 16 B.
+    constexpr int PER_SET = 2 * (NIN + ((GIN || ATT) ? 2 : 0));      // 16-byte registers per set
+#ifdef GH_PP_PD
+    constexpr int PD = PER_SET == 0 ? 1 : (GH_PP_PD);
+#else
+    constexpr int PD = PER_SET == 0 ? 1 : PER_SET <= 2 ? 2 : 1;
+#endif
+    constexpr int NSET = PD + 1;
+    pp_u32x4 ra[NSET][2], rb[NSET][2], rc[NSET][2], rg[NSET][2][2];      // [register set][item]; gin: two 16-byte halves of eight fp32
     float4 sw0 = make_float4(0.f, 0.f, 0.f, 0.f), sw1 = sw0;
     const rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc((void*)(SC ? (void*)P.e : (void*)C), 0, 0x7fffffff, 0x00020000);
     if constexpr (SC) {
@@ -137,7 +148,7 @@
       __builtin_amdgcn_raw_buffer_store_b128(pp_pack(a, b), rs, vo, 0, 2);
     };
     auto compute = [&](auto PT) __attribute__((always_inline)) {
-      constexpr int p_ = decltype(PT)::value, set = p_ & 1;
+      constexpr int p_ = decltype(PT)::value, set = p_ % NSET;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int row, col, rr;
@@ -225,13 +236,31 @@
     };
     auto pass = [&](auto PT) __attribute__((always_inline)) {
       constexpr int p_ = decltype(PT)::value;
+#ifdef GH_MEASURE
+      const bool ticks = (dbg_bits & 1024) != 0;      // GH_DBG=1024: per-kind tick sums (costs atomics: not for timing runs)
+      const unsigned long long tp0 = ticks ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
       pp_stage(PT);
-      if constexpr (p_ + 1 < MI) issue(std::integral_constant<int, p_ + 1>{}, std::integral_constant<int, (p_ + 1) & 1>{});
+#ifdef GH_MEASURE
+      const unsigned long long tp1 = ticks ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
+      if constexpr (p_ + PD < MI) issue(std::integral_constant<int, p_ + PD>{}, std::integral_constant<int, (p_ + PD) % NSET>{});
       compute(PT);
+#ifdef GH_MEASURE
+      if (ticks && tid == 0) {
+        const unsigned long long tp2 = __builtin_amdgcn_s_memtime();
+        const int kslot = (E & 7) + (SC ? 8 : 0);
+        atomicAdd(&g_nt_phase[kslot * 4 + 0], (unsigned long long)(tp1 - tp0));
+        atomicAdd(&g_nt_phase[kslot * 4 + 1], (unsigned long long)(tp2 - tp1));
+        atomicAdd(&g_nt_phase[kslot * 4 + 2], 1ull);
+      }
+#endif
       if constexpr (E == EPI_TANH_H && !SC) { if (rowred) row_reduce(PT); }
       if constexpr (ATT) row_reduce(PT);
     };
     issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    if constexpr (PD >= 2) issue(std::integral_constant<int, 1>{}, std::integral_constant<int, 1 % NSET>{});
+    if constexpr (PD >= 3) issue(std::integral_constant<int, 2>{}, std::integral_constant<int, 2 % NSET>{});
     pass(std::integral_constant<int, 0>{}); pass(std::integral_constant<int, 1>{}); pass(std::integral_constant<int, 2>{});
     pass(std::integral_constant<int, 3>{}); pass(std::integral_constant<int, 4>{}); pass(std::integral_constant<int, 5>{});
     pass(std::integral_constant<int, 6>{}); pass(std::integral_constant<int, 7>{});

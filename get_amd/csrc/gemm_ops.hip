@@ -1610,6 +1610,14 @@ extern "C" int gh_linear_fwd(const float* x, const float* w, const float* bias, 
   return 0;
 }
 
+#ifdef GH_MEASURE
+extern "C" int gh_debug_nt_phases(unsigned long long* out, int reset) {     // out: [16][4]
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nt_phase), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_nt_phase)) != hipSuccess || hipMemset(p, 0, 64 * sizeof(unsigned long long)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
+
 extern "C" int gh_linear_wgrad_bf16(const void* g16, int ldg, const void* x16, int ldx, int m, int n, int k,
                                     float* dw, int lddw, float* db, gh_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
